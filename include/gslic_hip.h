@@ -1,0 +1,249 @@
+/*
+ * gslic_hip.h — C-ABI of libgslic_hip.so: the MI355X (gfx950) differentiable 3D-Gaussian-splatting
+ * hot path of Gaussian-LIC (render forward / backward, sparse Adam, fused SSIM, simple-knn).
+ *
+ * Drop-in boundary.  The reference has no FFI; its seam is the L2 layer of six free functions on
+ * torch::Tensor that only unwrap pointers (src/rasterizer/rasterize_points.h:25-96,
+ * src/fused-ssim/ssim.h:7-26, src/simple-knn/spatial.h:14) and the raw-pointer L1 layer underneath
+ * (src/rasterizer/cuda_rasterizer/rasterizer.h:29-98, adam.h:12-23, src/simple-knn/simple_knn.h:18).
+ * Every entry point below names the L1/L2 function it replaces.  The LibTorch shim that re-exports the
+ * reference's exact L2 signatures on top of this header lives in gaussian-lic_amd/shim/.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch / C++ types.
+ *  - every `const float*` / `float*` / `int*` tensor argument is a DEVICE pointer (HBM), fp32 / int32,
+ *    contiguous row-major, exactly the layouts of the reference (SURVEY.md §8b "Layouts").
+ *  - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream, as the reference uses).
+ *  - every function returns GSLIC_OK (0) or a negative gslic_status; nothing throws across the boundary.
+ *    gslic_last_error() returns a thread-local, NUL-terminated description of the last failure.
+ *  - the library never frees or owns caller memory; scratch is obtained through the caller's allocator
+ *    callbacks in the same order as the reference (geom -> img -> binning -> sample), each at most once.
+ *  - the four scratch buffers are opaque: their internal layout is private to this library (it is NOT
+ *    the reference's GeometryState/ImageState/BinningState/SampleState layout) and the buffers written by
+ *    gslic_rasterize_forward must be handed unchanged to gslic_rasterize_backward.
+ */
+#ifndef GSLIC_HIP_H_INCLUDED
+#define GSLIC_HIP_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSLIC_ABI_VERSION 1
+
+typedef enum gslic_status {
+    GSLIC_OK = 0,
+    GSLIC_ERR_INVALID_ARG = -1,  /* NULL where a pointer is required, negative sizes, bad degree ...       */
+    GSLIC_ERR_UNSUPPORTED = -2,  /* colors_precomp / cov3D_precomp non-NULL (dead in the reference's host) */
+    GSLIC_ERR_ALLOC = -3,        /* an allocator callback returned NULL for a non-zero request             */
+    GSLIC_ERR_HIP = -4,          /* a HIP runtime call or kernel launch failed                            */
+    GSLIC_ERR_PREFILTERED = -5   /* prefiltered=1 and a Gaussian was culled (reference: device __trap)    */
+} gslic_status;
+
+/* Replaces std::function<char*(size_t)> (cuda_rasterizer/rasterizer.h:30-33; built by resizeFunctional,
+ * rasterize_points.cu:40-48).  Must return a device pointer to at least `bytes` bytes (any alignment:
+ * the library re-aligns to 256 B and has already added the slack), valid until the matching backward. */
+typedef char* (*gslic_alloc_fn)(void* ctx, size_t bytes);
+
+/* Scalar arguments of CudaRasterizer::Rasterizer::forward/backward (rasterizer.h:29-98), i.e. the fields
+ * of GaussianRasterizationSettings (src/rasterizer/rasterizer.h:27-73) that reach the kernels. */
+typedef struct gslic_raster_params {
+    int32_t P;              /* number of Gaussians (means3D.size(0))                                   */
+    int32_t D;              /* active SH degree 0..3 (sh_degree_)                                      */
+    int32_t M;              /* number of "rest" SH coefficients per Gaussian = sh.size(1) (15), 0 if sh empty */
+    int32_t width;          /* image_width                                                            */
+    int32_t height;         /* image_height                                                           */
+    float tan_fovx, tan_fovy;
+    float limx_neg, limx_pos, limy_neg, limy_pos; /* asymmetric Jacobian clamp (src/camera.h:63-66)    */
+    float scale_modifier;   /* always 1 in the reference                                               */
+    int32_t prefiltered;    /* bool                                                                    */
+    int32_t debug;          /* bool: synchronise + check after every stage (CHECK_CUDA, auxiliary.h:173-180) */
+    int32_t no_color;       /* bool: transmittance-only render (forward.cu:338,362,412,446,470)         */
+} gslic_raster_params;
+
+/* ------------------------------------------------------------------------------------------------
+ * gslic_rasterize_forward — replaces CudaRasterizer::Rasterizer::forward (rasterizer_impl.cu:312-474),
+ * reached from RasterizeGaussiansCUDA (rasterize_points.cu:50-149).
+ *
+ *  background      [3]      accepted and ignored, like the reference (forward.cu:335,460-469)
+ *  means3D         [P,3]    dc [P,1,3]    shs [P,M,3] (NULL when M==0)
+ *  colors_precomp  must be NULL   cov3D_precomp must be NULL   (rasterizer.cpp:200-201 always passes empty)
+ *  opacities       [P,1] post-sigmoid   scales [P,3] post-exp   rotations [P,4] post-normalise (r,x,y,z)
+ *  viewmatrix, projmatrix   [16] device, element (row r, col c) at [4c+r] (src/camera.h:86,109,60)
+ *  cam_pos         [3] device
+ *  out_color       [3,H,W] (untouched when no_color)   out_final_T [H,W]   radii [P] int32
+ *  num_rendered    host int: R = number of (Gaussian, tile) instances      } the two ints the reference
+ *  num_buckets     host int: B = number of checkpoint buckets (0 if no_color) } returns (rasterizer_impl.cu:473)
+ *
+ * Allocator call order geom(P) -> img(N,T) -> binning(R) -> sample(B); sample is called only when
+ * !no_color (rasterizer_impl.cu:355,359,401,437-447).  The function synchronises `stream` twice (to learn
+ * R and B on the host), exactly where the reference blocks (rasterizer_impl.cu:398,442).
+ * P == 0 returns immediately with R = B = 0 and calls no allocator (rasterize_points.cu:110).
+ */
+int gslic_rasterize_forward(
+    const gslic_raster_params* prm,
+    gslic_alloc_fn geom_alloc, void* geom_ctx,
+    gslic_alloc_fn binning_alloc, void* binning_ctx,
+    gslic_alloc_fn img_alloc, void* img_ctx,
+    gslic_alloc_fn sample_alloc, void* sample_ctx,
+    const float* background,
+    const float* means3D,
+    const float* dc,
+    const float* shs,
+    const float* colors_precomp,
+    const float* opacities,
+    const float* scales,
+    const float* rotations,
+    const float* cov3D_precomp,
+    const float* viewmatrix,
+    const float* projmatrix,
+    const float* cam_pos,
+    float* out_color,
+    float* out_final_T,
+    int32_t* radii,
+    int32_t* num_rendered,
+    int32_t* num_buckets,
+    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * gslic_rasterize_backward — replaces CudaRasterizer::Rasterizer::backward (rasterizer_impl.cu:476-581),
+ * reached from RasterizeGaussiansBackwardCUDA (rasterize_points.cu:151-246).
+ *
+ *  R, B                       the two ints gslic_rasterize_forward returned
+ *  geom/binning/img/sample    the SAME memory the forward filled (rasterizer.cpp:83-98 keeps it alive)
+ *  dL_dpix        [3,H,W]     gradient of the loss w.r.t. out_color
+ *  outputs (each [P,*], EVERY row is written — rows of invisible Gaussians get exact zeros — so the caller
+ *  may pass uninitialised memory; the reference instead requires ten zero-filled tensors,
+ *  rasterize_points.cu:192-201):
+ *    dL_dmean2D [P,3] (NDC-scaled, z = 0)   dL_dconic [P,2,2] (x,y,-,w slots; slot 2 = 0)   dL_dopacity [P,1]
+ *    dL_dcolor [P,3]   dL_dmean3D [P,3]   dL_dcov3D [P,6]   dL_ddc [P,1,3]   dL_dsh [P,M,3]
+ *    dL_dscale [P,3]   dL_drot [P,4]
+ *  dL_dmean2D, dL_dconic, dL_dcolor and dL_dcov3D may be NULL (the host discards them); the others are required
+ *  (dL_dsh may be NULL when M == 0).
+ *  shs == NULL skips the whole SH backward like the reference's `if (shs)` (backward.cu:352): dL_ddc = 0.
+ */
+int gslic_rasterize_backward(
+    const gslic_raster_params* prm,
+    int32_t R, int32_t B,
+    const float* background,
+    const float* means3D,
+    const float* dc,
+    const float* shs,
+    const float* colors_precomp,
+    const float* scales,
+    const float* rotations,
+    const float* cov3D_precomp,
+    const float* viewmatrix,
+    const float* projmatrix,
+    const float* cam_pos,
+    const int32_t* radii,
+    char* geom_buffer,
+    char* binning_buffer,
+    char* img_buffer,
+    char* sample_buffer,
+    const float* dL_dpix,
+    float* dL_dmean2D,
+    float* dL_dconic,
+    float* dL_dopacity,
+    float* dL_dcolor,
+    float* dL_dmean3D,
+    float* dL_dcov3D,
+    float* dL_ddc,
+    float* dL_dsh,
+    float* dL_dscale,
+    float* dL_drot,
+    float lambda_erank,
+    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * gslic_adam_update — replaces ADAM::adamUpdate / adamUpdateCUDA (cuda_rasterizer/adam.cu:9-66), reached
+ * from adamUpdate (rasterize_points.cu:248-273) <- SparseGaussianAdam::custom_step (optim_utils.h:102-137).
+ * In place on param / exp_avg / exp_avg_sq, all [N,M]; rows with visible[g]==0 are left untouched.
+ * No bias correction, p += -lr*m/(sqrt(v)+eps).  `visible` is one byte per Gaussian (torch bool).
+ */
+int gslic_adam_update(
+    float* param, const float* param_grad, float* exp_avg, float* exp_avg_sq,
+    const uint8_t* visible,
+    float lr, float b1, float b2, float eps,
+    uint32_t N, uint32_t M, void* stream);
+
+/* One launch over several parameter groups (the six groups of gaussian.cpp:399-418) — same arithmetic as
+ * n_groups calls of gslic_adam_update; exists to remove five launches and the per-group grad.clone()
+ * (optim_utils.h:130).  `groups` is a HOST array. */
+typedef struct gslic_adam_group {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    float lr; uint32_t M;
+} gslic_adam_group;
+int gslic_adam_update_groups(
+    const gslic_adam_group* groups, int32_t n_groups,
+    const uint8_t* visible, float b1, float b2, float eps, uint32_t N, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * gslic_fusedssim_forward / _backward — replace fusedssim / fusedssim_backward and their kernels
+ * (src/fused-ssim/ssim.cu:186-441).  Images are [B,CH,H,W]; 11-tap separable Gaussian window, zero padding.
+ * Forward writes ssim_map and, when the three dm_* pointers are non-NULL (train=true), the partial
+ * derivative maps; all outputs are fully overwritten (no pre-zeroing needed).
+ */
+int gslic_fusedssim_forward(
+    int32_t B, int32_t CH, int32_t H, int32_t W, float C1, float C2,
+    const float* img1, const float* img2,
+    float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
+    void* stream);
+int gslic_fusedssim_backward(
+    int32_t B, int32_t CH, int32_t H, int32_t W, float C1, float C2,
+    const float* img1, const float* img2, const float* dL_dmap,
+    const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
+    float* dL_dimg1, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * gslic_knn_mean_dist2 — replaces SimpleKNN::knn (src/simple-knn/simple_knn.cu:185-221) behind distCUDA2
+ * (src/simple-knn/spatial.cu:15-26): mean_dists[i] = mean of the 3 smallest squared distances from point i
+ * to the other points (FLT_MAX stands in for a missing neighbour when P < 4, as in the reference).
+ * Scratch comes from the caller's allocator (the reference cudaMalloc's internally, simple_knn.cu:187-216).
+ */
+int gslic_knn_mean_dist2(
+    int32_t P, const float* points, float* mean_dists,
+    gslic_alloc_fn scratch_alloc, void* scratch_ctx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Introspection / measurement (no reference counterpart; used by bench.py and the tests).
+ */
+int gslic_abi_version(void);
+const char* gslic_last_error(void);
+
+/* Sizes the four scratch buffers would need, for hosts that prefer to pre-size (bytes incl. slack). */
+size_t gslic_geom_bytes(int32_t P);
+size_t gslic_img_bytes(int32_t width, int32_t height);
+size_t gslic_binning_bytes(int32_t R, int32_t no_color);
+size_t gslic_sample_bytes(int32_t B);
+
+/* Per-kernel HIP-event timing.  While enabled, every kernel launch of this library is bracketed by a
+ * hipEvent pair recorded on the launch stream; gslic_profile_collect synchronises the device and adds the
+ * elapsed times to per-kernel totals.  Kernel ids are stable and named by gslic_profile_kernel_name. */
+#define GSLIC_PROFILE_MAX_KERNELS 48
+int gslic_profile_enable(int32_t on);
+int gslic_profile_reset(void);
+int gslic_profile_collect(void);
+int gslic_profile_num_kernels(void);
+const char* gslic_profile_kernel_name(int32_t id);
+int gslic_profile_get(int32_t id, double* total_ms, int64_t* launches);
+
+/* Test-only view into the opaque scratch buffers: copies stage boundaries to DEVICE arrays the caller owns
+ * (any pointer may be NULL).  Used by the parity tests to compare tiles_touched / point_list / ranges with
+ * the oracle bit-for-bit; not part of the drop-in surface. */
+int gslic_debug_export(
+    const gslic_raster_params* prm, int32_t R, int32_t B,
+    const char* geom_buffer, const char* binning_buffer, const char* img_buffer, const char* sample_buffer,
+    uint32_t* tiles_touched /*[P]*/, float* means2D /*[P,2]*/, float* depths /*[P]*/,
+    float* conic_opacity /*[P,4]*/, float* rgb /*[P,3]*/,
+    uint64_t* sorted_keys /*[R]*/, uint32_t* point_list /*[R]*/, uint32_t* ranges /*[T,2]*/,
+    uint32_t* n_contrib /*[H*W] row-major image order*/, uint32_t* max_contrib /*[T]*/,
+    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSLIC_HIP_H_INCLUDED */

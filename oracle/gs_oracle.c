@@ -1,0 +1,924 @@
+/*
+ * gs_oracle.c — CPU ORACLE for the Gaussian-LIC splatting hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * (libgslic_hip.so and everything under gaussian-lic_amd/) never links, imports or calls it.
+ *
+ * What it is: a plain-C restatement, stage by stage, of the arithmetic of the reference's CUDA kernels
+ * (all paths relative to /root/reference/src):
+ *   orc_preprocess        rasterizer/cuda_rasterizer/forward.cu:29-319, forward.h:34-78, auxiliary.h:41-171
+ *   orc_binning           rasterizer/cuda_rasterizer/rasterizer_impl.cu:42-231,395-433
+ *   orc_render_forward    rasterizer/cuda_rasterizer/forward.cu:321-481
+ *   orc_render_backward   rasterizer/cuda_rasterizer/backward.cu:379-597
+ *   orc_preprocess_backward  rasterizer/cuda_rasterizer/backward.cu:27-377
+ *   orc_adam              rasterizer/cuda_rasterizer/adam.cu:9-38
+ *   orc_ssim_forward/_backward  fused-ssim/ssim.cu:8-18,35-41,186-365
+ *   orc_knn               simple-knn/simple_knn.cu:147-183 (result only: exact mean of the 3 nearest)
+ *
+ * PARITY PIN STATUS: the reference ships no tests, golden vectors or fixtures for this path and is CUDA-only
+ * (no nvcc / NVIDIA device here), so this restatement is pinned by (a) tests/golden/ vectors produced by the
+ * reference's own kernels compiled through oracle/ref_build (see oracle/README.md; status recorded there) and
+ * (b) independent cross-checks in tests/ (float64 finite differences, a dense PyTorch autograd renderer, the
+ * reference's conv2d SSIM formula loss_utils.h:80-128, brute-force kNN).  Where (a) is absent for a stage the
+ * stage is "parity unpinned".
+ *
+ * Canonical arithmetic: fp32, every multiply/add rounded separately in source order (build with
+ * -ffp-contract=off), IEEE divide and sqrt, ndc2Pix in double (auxiliary.h:41-44 uses double literals), and the
+ * tile-culling threshold logf() evaluated by orc_logf below (a fixed double-precision polynomial) so that the
+ * integer outputs (radii, tiles_touched, sorted point_list, ranges) are reproducible bit-for-bit on any IEEE
+ * machine — the HIP kernels implement the same sequence.  Third-party arithmetic of the reference that is not
+ * in /root/reference (glm mat3 products, cub scans/sorts, CUDA libm) is restated from its published
+ * semantics: glm column-major products summed k = 0,1,2; stable LSD radix sort on bits [0, 32+msb(T)).
+ *
+ * Build -DORC_DOUBLE for a float64 twin (liboracle_f64.so) used only for finite-difference checks.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef ORC_DOUBLE
+typedef double real;
+#define RC(x) x
+#define r_sqrt sqrt
+#define r_exp exp
+#define r_log log
+#define r_ceil ceil
+#define r_fabs fabs
+#define r_copysign copysign
+#else
+typedef float real;
+#define RC(x) x##f
+#define r_sqrt sqrtf
+#define r_exp expf
+#define r_log logf
+#define r_ceil ceilf
+#define r_fabs fabsf
+#define r_copysign copysignf
+#endif
+
+#define TILE 16
+#define TILE_PIX 256
+#define REF_BUCKET 32 /* checkpoint period of the reference (forward.cu:412) */
+
+static inline real r_min(real a, real b) { return (b < a) ? b : a; }
+static inline real r_max(real a, real b) { return (b > a) ? b : a; }
+
+int orc_real_bytes(void) { return (int)sizeof(real); }
+
+/* ---- constants: auxiliary.h:22-39 ---- */
+static const real SH_C0 = RC(0.28209479177387814);
+static const real SH_C1 = RC(0.4886025119029199);
+static const real SH_C2[5] = {RC(1.0925484305920792), RC(-1.0925484305920792), RC(0.31539156525252005),
+                              RC(-1.0925484305920792), RC(0.5462742152960396)};
+static const real SH_C3[7] = {RC(-0.5900435899266435), RC(2.890611442640554), RC(-0.4570457994644658),
+                              RC(0.3731763325901154), RC(-0.4570457994644658), RC(1.445305721320277),
+                              RC(-0.5900435899266435)};
+
+/* Canonical natural log used for the tile-culling threshold logf(opacity*255) (forward.cu:302,
+ * rasterizer_impl.cu:89).  x = m*2^e with m in [sqrt(.5), sqrt(2)); log m = 2*atanh(s), s = (m-1)/(m+1),
+ * series to s^13 in double, plain (uncontracted) double ops in the order written; result rounded to float.
+ * |error| < 1e-11 relative: indistinguishable from CUDA logf (<= 1 ulp) yet identical on CPU and GPU. */
+float orc_logf(float x)
+{
+    union { float f; uint32_t u; } v;
+    v.f = x;
+    if (!(x > 0.0f) || v.u >= 0x7f800000u) return logf(x); /* not reached on the hot path (x >= 1) */
+    int e = (int)(v.u >> 23) - 127;
+    if ((v.u >> 23) == 0) { /* subnormal: normalise */
+        v.f = x * 8388608.0f;
+        e = (int)(v.u >> 23) - 127 - 23;
+    }
+    v.u = (v.u & 0x007fffffu) | 0x3f800000u;
+    double m = (double)v.f;
+    if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1; }
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double p = 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z + 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z + 1.0 / 3.0;
+    p = p * z + 1.0;
+    double r = (double)e * 0.6931471805599453 + 2.0 * s * p;
+    return (float)r;
+}
+
+/* ---- auxiliary.h:70-89 ---- */
+static inline void xform4x3(const real* m, real x, real y, real z, real* o)
+{
+    o[0] = m[0] * x + m[4] * y + m[8] * z + m[12];
+    o[1] = m[1] * x + m[5] * y + m[9] * z + m[13];
+    o[2] = m[2] * x + m[6] * y + m[10] * z + m[14];
+}
+static inline void xform4x4(const real* m, real x, real y, real z, real* o)
+{
+    o[0] = m[0] * x + m[4] * y + m[8] * z + m[12];
+    o[1] = m[1] * x + m[5] * y + m[9] * z + m[13];
+    o[2] = m[2] * x + m[6] * y + m[10] * z + m[14];
+    o[3] = m[3] * x + m[7] * y + m[11] * z + m[15];
+}
+
+/* Standard rotation of quaternion (r,x,y,z), row-major Rm[row][col]; forward.cu:127-137 lists these nine
+ * numbers in the same order (glm stores them as the columns of its mat3, i.e. glm R = Rm^T). */
+static inline void quat_rows(const real* q, real Rm[3][3])
+{
+    real r = q[0], x = q[1], y = q[2], z = q[3];
+    Rm[0][0] = RC(1.) - RC(2.) * (y * y + z * z); Rm[0][1] = RC(2.) * (x * y - r * z); Rm[0][2] = RC(2.) * (x * z + r * y);
+    Rm[1][0] = RC(2.) * (x * y + r * z); Rm[1][1] = RC(1.) - RC(2.) * (x * x + z * z); Rm[1][2] = RC(2.) * (y * z - r * x);
+    Rm[2][0] = RC(2.) * (x * z - r * y); Rm[2][1] = RC(2.) * (y * z + r * x); Rm[2][2] = RC(1.) - RC(2.) * (x * x + y * y);
+}
+
+/* forward.cu:120-149.  glm: M = S*R (M[c][r] = s_r * R_glm[c][r] = s_r * Rm[c][r]); Sigma = M^T M summed over
+ * the scaled axis k = 0,1,2.  cov3D = (S00,S01,S02,S11,S12,S22). */
+static inline void cov3d_from_scale_rot(const real* scale, real mod, const real* q, real* c6)
+{
+    real Rm[3][3];
+    quat_rows(q, Rm);
+    real s[3] = {mod * scale[0], mod * scale[1], mod * scale[2]};
+    real Mk[3][3]; /* Mk[k][a] = s_k * Rm[a][k] */
+    for (int k = 0; k < 3; k++)
+        for (int a = 0; a < 3; a++) Mk[k][a] = s[k] * Rm[a][k];
+#define SIG(a, b) (Mk[0][a] * Mk[0][b] + Mk[1][a] * Mk[1][b] + Mk[2][a] * Mk[2][b])
+    c6[0] = SIG(0, 0); c6[1] = SIG(0, 1); c6[2] = SIG(0, 2);
+    c6[3] = SIG(1, 1); c6[4] = SIG(1, 2); c6[5] = SIG(2, 2);
+#undef SIG
+}
+
+typedef struct {
+    real t[3];          /* view-space mean after the lim clamp */
+    real txtz, tytz;    /* unclamped ratios */
+    real T0[3], T1[3];  /* first two columns of glm T = W*J: T0 = J00*W0 + J02*W2, T1 = J11*W1 + J12*W2 */
+    real cov[3];        /* (a, b, c) dilated 2D covariance */
+} cov2d_t;
+
+/* forward.cu:79-118 (and the identical recomputation in backward.cu:160-201). */
+static inline void cov2d_eval(const real* mean, real fx, real fy, real lxn, real lxp, real lyn, real lyp,
+                              const real* c6, const real* V, cov2d_t* o)
+{
+    real t[3];
+    xform4x3(V, mean[0], mean[1], mean[2], t);
+    o->txtz = t[0] / t[2];
+    o->tytz = t[1] / t[2];
+    t[0] = r_min(lxp, r_max(lxn, o->txtz)) * t[2];
+    t[1] = r_min(lyp, r_max(lyn, o->tytz)) * t[2];
+    o->t[0] = t[0]; o->t[1] = t[1]; o->t[2] = t[2];
+    real J00 = fx / t[2];
+    real J02 = -(fx * t[0]) / (t[2] * t[2]);
+    real J11 = fy / t[2];
+    real J12 = -(fy * t[1]) / (t[2] * t[2]);
+    /* glm W columns: W0 = (V0,V4,V8), W1 = (V1,V5,V9), W2 = (V2,V6,V10) */
+    for (int i = 0; i < 3; i++) {
+        real w0 = V[4 * i + 0], w1 = V[4 * i + 1], w2 = V[4 * i + 2];
+        o->T0[i] = w0 * J00 + w2 * J02;
+        o->T1[i] = w1 * J11 + w2 * J12;
+    }
+    /* Vrk symmetric from c6; A_r[k] = T_r . Vrk[k]; cov = (A0.T0, A1.T0, A1.T1) */
+    const real Vr[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+    real A0[3], A1[3];
+    for (int k = 0; k < 3; k++) {
+        A0[k] = o->T0[0] * Vr[k][0] + o->T0[1] * Vr[k][1] + o->T0[2] * Vr[k][2];
+        A1[k] = o->T1[0] * Vr[k][0] + o->T1[1] * Vr[k][1] + o->T1[2] * Vr[k][2];
+    }
+    o->cov[0] = (A0[0] * o->T0[0] + A0[1] * o->T0[1] + A0[2] * o->T0[2]) + RC(0.3);
+    o->cov[1] = A1[0] * o->T0[0] + A1[1] * o->T0[1] + A1[2] * o->T0[2];
+    o->cov[2] = (A1[0] * o->T1[0] + A1[1] * o->T1[1] + A1[2] * o->T1[2]) + RC(0.3);
+}
+
+/* auxiliary.h:46-56: float->int truncation of (p -/+ r [+15]) / 16 clamped to the grid. */
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline int trunc_clamped(real v, int hi)
+{
+    /* (int)v with the out-of-range cases (undefined in C, saturating in CUDA) pinned before the clamp */
+    if (!(v > RC(-1.0))) return 0;
+    if (v >= (real)(hi + 1)) return hi;
+    return clampi((int)v, 0, hi);
+}
+static inline void get_rect(real px, real py, int radius, int gx, int gy, int* rmin, int* rmax)
+{
+    real r = (real)radius;
+    rmin[0] = trunc_clamped((px - r) / (real)TILE, gx);
+    rmin[1] = trunc_clamped((py - r) / (real)TILE, gy);
+    rmax[0] = trunc_clamped((px + r + (real)(TILE - 1)) / (real)TILE, gx);
+    rmax[1] = trunc_clamped((py + r + (real)(TILE - 1)) / (real)TILE, gy);
+}
+
+/* forward.h:39-78: minimum of 1/2 d^T Q d over the rectangle of pixel centres [tx*16, tx*16+15]x[ty*16, ..]. */
+static inline real saturate_r(real v) { return (v > RC(0.)) ? ((v < RC(1.)) ? v : RC(1.)) : RC(0.); }
+static inline real tile_min_power(const real* co, real mx, real my, int tx, int ty)
+{
+    const real rminx = (real)(tx * TILE), rminy = (real)(ty * TILE);
+    const real rmaxx = (real)((tx + 1) * TILE - 1), rmaxy = (real)((ty + 1) * TILE - 1);
+    const real x_min_diff = rminx - mx;
+    const real x_left = (x_min_diff > RC(0.)) ? RC(1.) : RC(0.);
+    const real not_in_x = x_left + ((mx > rmaxx) ? RC(1.) : RC(0.));
+    const real y_min_diff = rminy - my;
+    const real y_above = (y_min_diff > RC(0.)) ? RC(1.) : RC(0.);
+    const real not_in_y = y_above + ((my > rmaxy) ? RC(1.) : RC(0.));
+    if (!((not_in_y + not_in_x) > RC(0.))) return RC(0.);
+    const real sx = rmaxx - rminx, sy = rmaxy - rminy;
+    const real px = x_left * rminx + (RC(1.) - x_left) * rmaxx;
+    const real py = y_above * rminy + (RC(1.) - y_above) * rmaxy;
+    const real dx = r_copysign(sx, x_min_diff);
+    const real dy = r_copysign(sy, y_min_diff);
+    const real diffx = mx - px;
+    const real diffy = my - py;
+    const real rcpx = RC(1.) / (sx * sx * co[0]);
+    const real rcpy = RC(1.) / (sy * sy * co[2]);
+    const real tx_ = not_in_y * saturate_r((dx * co[0] * diffx + dx * co[1] * diffy) * rcpx);
+    const real ty_ = not_in_x * saturate_r((dy * co[1] * diffx + dy * co[2] * diffy) * rcpy);
+    const real qx = px + tx_ * dx, qy = py + ty_ * dy;
+    const real ex = mx - qx, ey = my - qy;
+    return RC(0.5) * (co[0] * ex * ex + co[2] * ey * ey) + co[1] * ex * ey;
+}
+
+static inline real cull_threshold(real opacity)
+{
+#ifdef ORC_DOUBLE
+    return log(opacity / (1.0 / 255.0));
+#else
+    return orc_logf(opacity / (1.0f / 255.0f));
+#endif
+}
+
+/* ================================================================================================
+ * Stage 1 — forward preprocess (forward.cu:232-319).  Outputs for culled Gaussians: radii = 0,
+ * tiles_touched = 0, everything else 0 (the reference leaves them uninitialised).  cov3D is written for
+ * every Gaussian like the reference (forward.cu:283).
+ */
+void orc_preprocess(int P, int D, int M, const real* means, const real* scales, real scale_mod,
+                    const real* rots, const real* opac, const real* dc, const real* shs, const real* V,
+                    const real* Pm, const real* campos, int W, int H, real tanfovx, real tanfovy, real lxn,
+                    real lxp, real lyn, real lyp, int no_color,
+                    int32_t* radii, real* means2D, real* depths, real* cov3D, real* conic_opacity, real* rgb,
+                    uint8_t* clamped, uint32_t* tiles_touched)
+{
+    const real fx = (real)W / (RC(2.) * tanfovx), fy = (real)H / (RC(2.) * tanfovy); /* rasterizer_impl.cu:348-349 */
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int i = 0; i < P; i++) {
+        radii[i] = 0; tiles_touched[i] = 0;
+        means2D[2 * i] = means2D[2 * i + 1] = 0; depths[i] = 0;
+        for (int k = 0; k < 4; k++) conic_opacity[4 * i + k] = 0;
+        for (int k = 0; k < 3; k++) { rgb[3 * i + k] = 0; clamped[3 * i + k] = 0; }
+        const real* p = means + 3 * i;
+        cov3d_from_scale_rot(scales + 3 * i, scale_mod, rots + 4 * i, cov3D + 6 * i);
+        real pv[3];
+        xform4x3(V, p[0], p[1], p[2], pv);
+        if (pv[2] <= RC(0.2)) continue; /* auxiliary.h:160 */
+        real ph[4];
+        xform4x4(Pm, p[0], p[1], p[2], ph);
+        real pw = RC(1.) / (ph[3] + RC(0.0000001));
+        real projx = ph[0] * pw, projy = ph[1] * pw;
+        cov2d_t c2;
+        cov2d_eval(p, fx, fy, lxn, lxp, lyn, lyp, cov3D + 6 * i, V, &c2);
+        real det = c2.cov[0] * c2.cov[2] - c2.cov[1] * c2.cov[1];
+        if (det == RC(0.)) continue;
+        real det_inv = RC(1.) / det;
+        real co[4] = {c2.cov[2] * det_inv, -c2.cov[1] * det_inv, c2.cov[0] * det_inv, opac[i]};
+        if (co[3] < (RC(1.) / RC(255.))) continue;
+        real mid = RC(0.5) * (c2.cov[0] + c2.cov[2]);
+        real lambda1 = mid + r_sqrt(r_max(RC(0.1), mid * mid - det));
+        real my_radius = r_ceil(RC(3.) * r_sqrt(lambda1));
+        /* ndc2Pix in double (auxiliary.h:41-44) */
+        real mx = (real)((((double)projx + 1.0) * (double)W - 1.0) * 0.5);
+        real my = (real)((((double)projy + 1.0) * (double)H - 1.0) * 0.5);
+        int rmin[2], rmax[2];
+        int radius_i = (my_radius >= RC(2147483520.)) ? 2147483520 : (int)my_radius;
+        get_rect(mx, my, radius_i, gx, gy, rmin, rmax);
+        real thr = cull_threshold(co[3]);
+        uint32_t cnt = 0;
+        for (int ty = rmin[1]; ty < rmax[1]; ty++)
+            for (int tx = rmin[0]; tx < rmax[0]; tx++)
+                cnt += (tile_min_power(co, mx, my, tx, ty) <= thr) ? 1u : 0u;
+        if (cnt == 0) continue;
+        if (!no_color) { /* forward.cu:29-77 */
+            real dir[3] = {p[0] - campos[0], p[1] - campos[1], p[2] - campos[2]};
+            real len = r_sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+            real x = dir[0] / len, y = dir[1] / len, z = dir[2] / len;
+            const real* d0 = dc + 3 * i;
+            const real* sh = shs ? shs + (size_t)3 * M * i : NULL;
+            for (int ch = 0; ch < 3; ch++) {
+                real res = SH_C0 * d0[ch];
+#define S(k) sh[3 * (k) + ch]
+                if (D > 0) {
+                    res = res - SH_C1 * y * S(0) + SH_C1 * z * S(1) - SH_C1 * x * S(2);
+                    if (D > 1) {
+                        real xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        res = res + SH_C2[0] * xy * S(3) + SH_C2[1] * yz * S(4) +
+                              SH_C2[2] * (RC(2.) * zz - xx - yy) * S(5) + SH_C2[3] * xz * S(6) +
+                              SH_C2[4] * (xx - yy) * S(7);
+                        if (D > 2) {
+                            res = res + SH_C3[0] * y * (RC(3.) * xx - yy) * S(8) + SH_C3[1] * xy * z * S(9) +
+                                  SH_C3[2] * y * (RC(4.) * zz - xx - yy) * S(10) +
+                                  SH_C3[3] * z * (RC(2.) * zz - RC(3.) * xx - RC(3.) * yy) * S(11) +
+                                  SH_C3[4] * x * (RC(4.) * zz - xx - yy) * S(12) + SH_C3[5] * z * (xx - yy) * S(13) +
+                                  SH_C3[6] * x * (xx - RC(3.) * yy) * S(14);
+                        }
+                    }
+                }
+#undef S
+                res += RC(0.5);
+                clamped[3 * i + ch] = (res < RC(0.)) ? 1 : 0;
+                rgb[3 * i + ch] = r_max(res, RC(0.));
+            }
+        }
+        depths[i] = pv[2];
+        radii[i] = radius_i;
+        means2D[2 * i] = mx; means2D[2 * i + 1] = my;
+        for (int k = 0; k < 4; k++) conic_opacity[4 * i + k] = co[k];
+        tiles_touched[i] = cnt;
+    }
+}
+
+/* rasterizer_impl.cu:42-57 (binary search for the highest set bit, +1) */
+uint32_t orc_higher_msb(uint32_t n)
+{
+    uint32_t msb = 16, step = 16;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step; else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+/* ================================================================================================
+ * Stage 2 — binning (rasterizer_impl.cu:59-231,395-433): inclusive scan, key emission in (Gaussian,
+ * row-major tile) order, stable LSD radix sort on bits [0, 32+msb(T)), tile ranges.
+ * Returns R.  Caller provides keys/point_list sized >= sum(tiles_touched); ranges is [T][2].
+ * depth bits are the fp32 bit pattern (the float64 twin rounds the depth to float first).
+ */
+static void radix_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* tk, uint32_t* tv, size_t n, int end_bit)
+{
+    const int RB = 11;
+    size_t* hist = (size_t*)malloc(sizeof(size_t) * ((size_t)1 << RB));
+    for (int shift = 0; shift < end_bit; shift += RB) {
+        int bits = (end_bit - shift < RB) ? (end_bit - shift) : RB;
+        uint64_t mask = (((uint64_t)1) << bits) - 1;
+        memset(hist, 0, sizeof(size_t) * ((size_t)1 << RB));
+        for (size_t i = 0; i < n; i++) hist[(keys[i] >> shift) & mask]++;
+        size_t run = 0;
+        for (size_t d = 0; d < ((size_t)1 << bits); d++) { size_t c = hist[d]; hist[d] = run; run += c; }
+        for (size_t i = 0; i < n; i++) {
+            size_t d = (size_t)((keys[i] >> shift) & mask);
+            tk[hist[d]] = keys[i]; tv[hist[d]] = vals[i]; hist[d]++;
+        }
+        memcpy(keys, tk, n * sizeof(uint64_t));
+        memcpy(vals, tv, n * sizeof(uint32_t));
+    }
+    free(hist);
+}
+
+int64_t orc_binning(int P, int W, int H, const int32_t* radii, const real* means2D, const real* depths,
+                    const real* conic_opacity, const uint32_t* tiles_touched,
+                    uint64_t* keys_sorted, uint32_t* point_list, uint32_t* ranges)
+{
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const int T = gx * gy;
+    uint32_t* offs = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(P > 0 ? P : 1));
+    uint64_t run = 0;
+    for (int i = 0; i < P; i++) { run += tiles_touched[i]; offs[i] = (uint32_t)run; }
+    const size_t R = (size_t)run;
+    memset(ranges, 0, sizeof(uint32_t) * 2 * (size_t)T);
+    if (R == 0) { free(offs); return 0; }
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int i = 0; i < P; i++) {
+        if (radii[i] <= 0) continue;
+        size_t off = (i == 0) ? 0 : offs[i - 1];
+        const size_t off_to = offs[i];
+        int rmin[2], rmax[2];
+        get_rect(means2D[2 * i], means2D[2 * i + 1], radii[i], gx, gy, rmin, rmax);
+        const real* co = conic_opacity + 4 * i;
+        real thr = cull_threshold(co[3]);
+        union { float f; uint32_t u; } dv;
+        dv.f = (float)depths[i];
+        for (int ty = rmin[1]; ty < rmax[1]; ty++)
+            for (int tx = rmin[0]; tx < rmax[0]; tx++) {
+                if (off >= off_to) continue;
+                if (tile_min_power(co, means2D[2 * i], means2D[2 * i + 1], tx, ty) <= thr) {
+                    uint64_t key = (uint64_t)(uint32_t)(ty * gx + tx);
+                    key <<= 32;
+                    key |= dv.u;
+                    keys_sorted[off] = key;
+                    point_list[off] = (uint32_t)i;
+                    off++;
+                }
+            }
+        while (off < off_to) { /* rasterizer_impl.cu:121-131: padding (never hit: the test is deterministic) */
+            union { float f; uint32_t u; } mx; mx.f = FLT_MAX;
+            keys_sorted[off] = (((uint64_t)0xFFFFFFFFu) << 32) | mx.u;
+            point_list[off] = 0xFFFFFFFFu;
+            off++;
+        }
+    }
+    uint64_t* tk = (uint64_t*)malloc(sizeof(uint64_t) * R);
+    uint32_t* tv = (uint32_t*)malloc(sizeof(uint32_t) * R);
+    radix_sort_pairs(keys_sorted, point_list, tk, tv, R, 32 + (int)orc_higher_msb((uint32_t)T));
+    free(tk); free(tv); free(offs);
+    /* identifyTileRanges (rasterizer_impl.cu:195-218) */
+    for (size_t idx = 0; idx < R; idx++) {
+        uint32_t cur = (uint32_t)(keys_sorted[idx] >> 32);
+        int valid = cur != 0xFFFFFFFFu;
+        if (idx == 0) { if (valid) ranges[2 * cur] = 0; }
+        else {
+            uint32_t prev = (uint32_t)(keys_sorted[idx - 1] >> 32);
+            if (cur != prev) {
+                ranges[2 * prev + 1] = (uint32_t)idx;
+                if (valid) ranges[2 * cur] = (uint32_t)idx;
+            }
+        }
+        if (idx == R - 1 && valid) ranges[2 * cur + 1] = (uint32_t)R;
+    }
+    return (int64_t)R;
+}
+
+/* ================================================================================================
+ * Stage 3 — blend forward (forward.cu:321-481), one 16x16 tile at a time, pixels in thread_rank order.
+ * out_color CHW (not written when no_color), final_T, n_contrib (image order), max_contrib[T].
+ * Returns through *evals the number of (pixel, Gaussian) pairs visited (for the bench's pair count).
+ */
+void orc_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                        const real* means2D, const real* conic_opacity, const real* rgb, int no_color,
+                        real* out_color, real* out_final_T, uint32_t* n_contrib, uint32_t* max_contrib,
+                        int64_t* evals)
+{
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    int64_t ev = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : ev)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        const int tx0 = (tile % gx) * TILE, ty0 = (tile / gx) * TILE;
+        const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        uint32_t tile_max = 0;
+        for (int tid = 0; tid < TILE_PIX; tid++) {
+            const int px = tx0 + tid % TILE, py = ty0 + tid / TILE;
+            if (!(px < W && py < H)) continue;
+            const real pxf = (real)px, pyf = (real)py;
+            real T = RC(1.), C[3] = {0, 0, 0};
+            uint32_t contributor = 0, last = 0;
+            for (uint32_t k = r0; k < r1; k++) {
+                contributor++;
+                ev++;
+                const uint32_t g = point_list[k];
+                const real dx = means2D[2 * g] - pxf, dy = means2D[2 * g + 1] - pyf;
+                const real* co = conic_opacity + 4 * g;
+                const real power = RC(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (power > RC(0.)) continue;
+                const real alpha = r_min(RC(0.99), co[3] * r_exp(power));
+                if (alpha < RC(1.) / RC(255.)) continue;
+                const real test_T = T * (RC(1.) - alpha);
+                if (test_T < RC(0.0001)) break;
+                if (!no_color)
+                    for (int ch = 0; ch < 3; ch++) C[ch] += rgb[3 * g + ch] * alpha * T;
+                T = test_T;
+                last = contributor;
+            }
+            const size_t pid = (size_t)py * W + px;
+            out_final_T[pid] = T;
+            if (!no_color) {
+                n_contrib[pid] = last;
+                for (int ch = 0; ch < 3; ch++) out_color[(size_t)ch * H * W + pid] = C[ch];
+                if (last > tile_max) tile_max = last;
+            }
+        }
+        if (!no_color) max_contrib[tile] = tile_max;
+    }
+    if (evals) *evals = ev;
+}
+
+/* ================================================================================================
+ * Stage 4 — blend backward (backward.cu:379-597).  For every tile, bucket of 32 list entries and pixel the
+ * reference replays T from the bucket checkpoint and `ar` from (checkpoint colour - final colour); the
+ * replay below reproduces those values by re-running the forward recurrence (identical operations), resetting
+ * `ar` at every 32nd entry exactly like the checkpoint reload (backward.cu:519-530).  Per-(Gaussian, tile)
+ * register sums run over pixels in thread_rank order (backward.cu:477-582); the atomicAdd across tiles
+ * (backward.cu:585-596) is done here in ascending tile order (the reference's order is unspecified).
+ * Outputs must be zero-initialised by the caller: dL_dmean2D[P,3], dL_dconic[P,4], dL_dopacity[P], dL_dcolor[P,3].
+ */
+void orc_render_backward(int W, int H, int P, const uint32_t* ranges, const uint32_t* point_list,
+                         const real* means2D, const real* conic_opacity, const real* rgb,
+                         const real* final_color /*CHW*/, const uint32_t* n_contrib, const real* dL_dpix /*CHW*/,
+                         real* dL_dmean2D, real* dL_dconic, real* dL_dopacity, real* dL_dcolor)
+{
+    (void)P;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const real ddelx_dx = RC(0.5) * (real)W, ddely_dy = RC(0.5) * (real)H;
+    size_t Rtot = 0;
+    for (int t = 0; t < gx * gy; t++)
+        if (ranges[2 * t + 1] > Rtot) Rtot = ranges[2 * t + 1];
+    real* part = (real*)calloc(Rtot * 9 + 1, sizeof(real)); /* per sorted instance: mx,my,cx,cy,cw,op,r,g,b */
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        const int tx0 = (tile % gx) * TILE, ty0 = (tile / gx) * TILE;
+        const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        for (int tid = 0; tid < TILE_PIX; tid++) {
+            const int px = tx0 + tid % TILE, py = ty0 + tid / TILE;
+            if (!(px < W && py < H)) continue;
+            const size_t pid = (size_t)py * W + px;
+            const uint32_t last = n_contrib[pid];
+            const real pxf = (real)px, pyf = (real)py;
+            real g[3], fin[3];
+            for (int ch = 0; ch < 3; ch++) {
+                g[ch] = dL_dpix[(size_t)ch * H * W + pid];
+                fin[ch] = final_color[(size_t)ch * H * W + pid];
+            }
+            real T = RC(1.), C[3] = {0, 0, 0}, ar[3] = {0, 0, 0};
+            for (uint32_t j = 0; j < last && r0 + j < r1; j++) {
+                if (j % REF_BUCKET == 0)
+                    for (int ch = 0; ch < 3; ch++) ar[ch] = C[ch] - fin[ch];
+                const uint32_t k = r0 + j;
+                const uint32_t gi = point_list[k];
+                const real dx = means2D[2 * gi] - pxf, dy = means2D[2 * gi + 1] - pyf;
+                const real* co = conic_opacity + 4 * gi;
+                const real power = RC(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (power > RC(0.)) continue;
+                const real G = r_exp(power);
+                const real alpha = r_min(RC(0.99), co[3] * G);
+                if (alpha < RC(1.) / RC(255.)) continue;
+                real* acc = part + (size_t)k * 9;
+                const real dchannel_dcolor = alpha * T;
+                real dL_dalpha = RC(0.);
+                const real alpha_inv = RC(1.) / (RC(1.) - alpha);
+                for (int ch = 0; ch < 3; ch++) {
+                    const real c = rgb[3 * gi + ch];
+                    ar[ch] += T * alpha * c;
+                    C[ch] += c * alpha * T; /* forward recurrence, forward.cu:449 */
+                    acc[6 + ch] += dchannel_dcolor * g[ch];
+                    dL_dalpha += ((c * T) - alpha_inv * (-ar[ch])) * g[ch];
+                }
+                T *= (RC(1.) - alpha);
+                const real dL_dG = co[3] * dL_dalpha;
+                const real gdx = G * dx, gdy = G * dy;
+                const real dG_ddelx = -gdx * co[0] - gdy * co[1];
+                const real dG_ddely = -gdy * co[2] - gdx * co[1];
+                acc[0] += dL_dG * dG_ddelx * ddelx_dx;
+                acc[1] += dL_dG * dG_ddely * ddely_dy;
+                acc[2] += RC(-0.5) * gdx * dx * dL_dG;
+                acc[3] += RC(-0.5) * gdx * dy * dL_dG;
+                acc[4] += RC(-0.5) * gdy * dy * dL_dG;
+                acc[5] += G * dL_dalpha;
+            }
+        }
+    }
+    for (int tile = 0; tile < gx * gy; tile++)
+        for (uint32_t k = ranges[2 * tile]; k < ranges[2 * tile + 1]; k++) {
+            const uint32_t gi = point_list[k];
+            const real* acc = part + (size_t)k * 9;
+            dL_dmean2D[3 * gi + 0] += acc[0];
+            dL_dmean2D[3 * gi + 1] += acc[1];
+            dL_dconic[4 * gi + 0] += acc[2];
+            dL_dconic[4 * gi + 1] += acc[3];
+            dL_dconic[4 * gi + 3] += acc[4];
+            dL_dopacity[gi] += acc[5];
+            for (int ch = 0; ch < 3; ch++) dL_dcolor[3 * gi + ch] += acc[6 + ch];
+        }
+    free(part);
+}
+
+/* ================================================================================================
+ * Stage 5 — preprocess backward: computeCov2DCUDA (backward.cu:138-255) then preprocessCUDA
+ * (backward.cu:312-377) with computeColorFromSH (27-136) and computeCov3D (257-310).
+ * glm helpers: m[c][r] (column-major), product summed over k = 0,1,2.
+ * All ten outputs must be zero-initialised by the caller (rasterize_points.cu:192-201); rows with
+ * radii <= 0 are left untouched.  shs == NULL skips the SH backward (backward.cu:352).
+ */
+typedef struct { real m[3][3]; } gmat3;
+static inline gmat3 gmul(const gmat3* A, const gmat3* B)
+{
+    gmat3 o;
+    for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) o.m[c][r] = A->m[0][r] * B->m[c][0] + A->m[1][r] * B->m[c][1] + A->m[2][r] * B->m[c][2];
+    return o;
+}
+static inline gmat3 gtranspose(const gmat3* A)
+{
+    gmat3 o;
+    for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) o.m[c][r] = A->m[r][c];
+    return o;
+}
+
+void orc_preprocess_backward(int P, int D, int M, const real* means, const int32_t* radii, const real* dc,
+                             const real* shs, const uint8_t* clamped, const real* scales, const real* rots,
+                             real scale_mod, const real* cov3D, const real* V, const real* Pm, int W, int H,
+                             real tanfovx, real tanfovy, real lxn, real lxp, real lyn, real lyp, const real* campos,
+                             const real* dL_dmean2D, const real* dL_dconic, const real* dL_dcolor,
+                             real* dL_dmeans, real* dL_dcov, real* dL_ddc, real* dL_dsh, real* dL_dscale,
+                             real* dL_drot, real lambda_erank)
+{
+    (void)dc;
+    const real fx = (real)W / (RC(2.) * tanfovx), fy = (real)H / (RC(2.) * tanfovy);
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int idx = 0; idx < P; idx++) {
+        if (!(radii[idx] > 0)) continue;
+        const real* mean = means + 3 * idx;
+        /* ---------------- computeCov2DCUDA ---------------- */
+        const real* c6 = cov3D + 6 * idx;
+        const real gxx = dL_dconic[4 * idx], gyy = dL_dconic[4 * idx + 1], gzz = dL_dconic[4 * idx + 3];
+        cov2d_t c2;
+        cov2d_eval(mean, fx, fy, lxn, lxp, lyn, lyp, c6, V, &c2);
+        const real x_grad_mul = (c2.txtz < lxn || c2.txtz > lxp) ? RC(0.) : RC(1.);
+        const real y_grad_mul = (c2.tytz < lyn || c2.tytz > lyp) ? RC(0.) : RC(1.);
+        const real a = c2.cov[0], b = c2.cov[1], c = c2.cov[2];
+        const real* T0 = c2.T0; const real* T1 = c2.T1;
+        const real denom = a * c - b * b;
+        real dL_da = 0, dL_db = 0, dL_dc = 0;
+        const real denom2inv = RC(1.) / ((denom * denom) + RC(0.0000001));
+        real* dcv = dL_dcov + 6 * idx;
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-c * c * gxx + 2 * b * c * gyy + (denom - a * c) * gzz);
+            dL_dc = denom2inv * (-a * a * gzz + 2 * a * b * gyy + (denom - a * c) * gxx);
+            dL_db = denom2inv * 2 * (b * c * gxx - (denom + 2 * b * b) * gyy + a * b * gzz);
+            dcv[0] = (T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc);
+            dcv[3] = (T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc);
+            dcv[5] = (T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc);
+            dcv[1] = 2 * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2 * T1[0] * T1[1] * dL_dc;
+            dcv[2] = 2 * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2 * T1[0] * T1[2] * dL_dc;
+            dcv[4] = 2 * T0[2] * T0[1] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2 * T1[1] * T1[2] * dL_dc;
+        } else {
+            for (int i = 0; i < 6; i++) dcv[i] = 0;
+        }
+        const real Vr[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+#define DOT3(u, w) ((u)[0] * (w)[0] + (u)[1] * (w)[1] + (u)[2] * (w)[2])
+        const real dL_dT00 = 2 * DOT3(T0, Vr[0]) * dL_da + DOT3(T1, Vr[0]) * dL_db;
+        const real dL_dT01 = 2 * DOT3(T0, Vr[1]) * dL_da + DOT3(T1, Vr[1]) * dL_db;
+        const real dL_dT02 = 2 * DOT3(T0, Vr[2]) * dL_da + DOT3(T1, Vr[2]) * dL_db;
+        const real dL_dT10 = 2 * DOT3(T1, Vr[0]) * dL_dc + DOT3(T0, Vr[0]) * dL_db;
+        const real dL_dT11 = 2 * DOT3(T1, Vr[1]) * dL_dc + DOT3(T0, Vr[1]) * dL_db;
+        const real dL_dT12 = 2 * DOT3(T1, Vr[2]) * dL_dc + DOT3(T0, Vr[2]) * dL_db;
+#undef DOT3
+        /* glm W columns: W0=(V0,V4,V8) W1=(V1,V5,V9) W2=(V2,V6,V10) */
+        const real dL_dJ00 = V[0] * dL_dT00 + V[4] * dL_dT01 + V[8] * dL_dT02;
+        const real dL_dJ02 = V[2] * dL_dT00 + V[6] * dL_dT01 + V[10] * dL_dT02;
+        const real dL_dJ11 = V[1] * dL_dT10 + V[5] * dL_dT11 + V[9] * dL_dT12;
+        const real dL_dJ12 = V[2] * dL_dT10 + V[6] * dL_dT11 + V[10] * dL_dT12;
+        const real tz = RC(1.) / c2.t[2];
+        const real tz2 = tz * tz;
+        const real tz3 = tz2 * tz;
+        const real dL_dtx = x_grad_mul * -fx * tz2 * dL_dJ02;
+        const real dL_dty = y_grad_mul * -fy * tz2 * dL_dJ12;
+        const real dL_dtz = -fx * tz2 * dL_dJ00 - fy * tz2 * dL_dJ11 + (2 * fx * c2.t[0]) * tz3 * dL_dJ02 +
+                            (2 * fy * c2.t[1]) * tz3 * dL_dJ12;
+        real dmean[3]; /* transformVec4x3Transpose, assignment (backward.cu:252-254) */
+        dmean[0] = V[0] * dL_dtx + V[1] * dL_dty + V[2] * dL_dtz;
+        dmean[1] = V[4] * dL_dtx + V[5] * dL_dty + V[6] * dL_dtz;
+        dmean[2] = V[8] * dL_dtx + V[9] * dL_dty + V[10] * dL_dtz;
+
+        /* ---------------- preprocessCUDA (bwd) ---------------- */
+        real ph[4];
+        xform4x4(Pm, mean[0], mean[1], mean[2], ph);
+        const real pw = RC(1.) / (ph[3] + RC(0.0000001));
+        const real mul1 = (Pm[0] * mean[0] + Pm[4] * mean[1] + Pm[8] * mean[2] + Pm[12]) * pw * pw;
+        const real mul2 = (Pm[1] * mean[0] + Pm[5] * mean[1] + Pm[9] * mean[2] + Pm[13]) * pw * pw;
+        const real g2x = dL_dmean2D[3 * idx], g2y = dL_dmean2D[3 * idx + 1];
+        dmean[0] += (Pm[0] * pw - Pm[3] * mul1) * g2x + (Pm[1] * pw - Pm[3] * mul2) * g2y;
+        dmean[1] += (Pm[4] * pw - Pm[7] * mul1) * g2x + (Pm[5] * pw - Pm[7] * mul2) * g2y;
+        dmean[2] += (Pm[8] * pw - Pm[11] * mul1) * g2x + (Pm[9] * pw - Pm[11] * mul2) * g2y;
+
+        if (shs) { /* computeColorFromSH backward, backward.cu:27-136 */
+            const real dir_o[3] = {mean[0] - campos[0], mean[1] - campos[1], mean[2] - campos[2]};
+            const real len = r_sqrt(dir_o[0] * dir_o[0] + dir_o[1] * dir_o[1] + dir_o[2] * dir_o[2]);
+            const real x = dir_o[0] / len, y = dir_o[1] / len, z = dir_o[2] / len;
+            const real* sh = shs + (size_t)3 * M * idx;
+            real dRGB[3];
+            for (int ch = 0; ch < 3; ch++) dRGB[ch] = dL_dcolor[3 * idx + ch] * (clamped[3 * idx + ch] ? RC(0.) : RC(1.));
+            real* ddc = dL_ddc + 3 * idx;
+            real* dsh = dL_dsh ? dL_dsh + (size_t)3 * M * idx : NULL;
+            real dRGBdx[3] = {0, 0, 0}, dRGBdy[3] = {0, 0, 0}, dRGBdz[3] = {0, 0, 0};
+            for (int ch = 0; ch < 3; ch++) ddc[ch] = SH_C0 * dRGB[ch];
+#define S(k, ch) sh[3 * (k) + (ch)]
+#define SETSH(k, coef) for (int ch = 0; ch < 3; ch++) dsh[3 * (k) + ch] = (coef) * dRGB[ch]
+            if (D > 0) {
+                SETSH(0, -SH_C1 * y); SETSH(1, SH_C1 * z); SETSH(2, -SH_C1 * x);
+                for (int ch = 0; ch < 3; ch++) {
+                    dRGBdx[ch] = -SH_C1 * S(2, ch); dRGBdy[ch] = -SH_C1 * S(0, ch); dRGBdz[ch] = SH_C1 * S(1, ch);
+                }
+                if (D > 1) {
+                    const real xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    SETSH(3, SH_C2[0] * xy); SETSH(4, SH_C2[1] * yz); SETSH(5, SH_C2[2] * (RC(2.) * zz - xx - yy));
+                    SETSH(6, SH_C2[3] * xz); SETSH(7, SH_C2[4] * (xx - yy));
+                    for (int ch = 0; ch < 3; ch++) {
+                        dRGBdx[ch] += SH_C2[0] * y * S(3, ch) + SH_C2[2] * RC(2.) * -x * S(5, ch) + SH_C2[3] * z * S(6, ch) + SH_C2[4] * RC(2.) * x * S(7, ch);
+                        dRGBdy[ch] += SH_C2[0] * x * S(3, ch) + SH_C2[1] * z * S(4, ch) + SH_C2[2] * RC(2.) * -y * S(5, ch) + SH_C2[4] * RC(2.) * -y * S(7, ch);
+                        dRGBdz[ch] += SH_C2[1] * y * S(4, ch) + SH_C2[2] * RC(2.) * RC(2.) * z * S(5, ch) + SH_C2[3] * x * S(6, ch);
+                    }
+                    if (D > 2) {
+                        SETSH(8, SH_C3[0] * y * (RC(3.) * xx - yy)); SETSH(9, SH_C3[1] * xy * z);
+                        SETSH(10, SH_C3[2] * y * (RC(4.) * zz - xx - yy));
+                        SETSH(11, SH_C3[3] * z * (RC(2.) * zz - RC(3.) * xx - RC(3.) * yy));
+                        SETSH(12, SH_C3[4] * x * (RC(4.) * zz - xx - yy)); SETSH(13, SH_C3[5] * z * (xx - yy));
+                        SETSH(14, SH_C3[6] * x * (xx - RC(3.) * yy));
+                        for (int ch = 0; ch < 3; ch++) {
+                            dRGBdx[ch] += (SH_C3[0] * S(8, ch) * RC(3.) * RC(2.) * xy + SH_C3[1] * S(9, ch) * yz +
+                                           SH_C3[2] * S(10, ch) * -RC(2.) * xy + SH_C3[3] * S(11, ch) * -RC(3.) * RC(2.) * xz +
+                                           SH_C3[4] * S(12, ch) * (-RC(3.) * xx + RC(4.) * zz - yy) +
+                                           SH_C3[5] * S(13, ch) * RC(2.) * xz + SH_C3[6] * S(14, ch) * RC(3.) * (xx - yy));
+                            dRGBdy[ch] += (SH_C3[0] * S(8, ch) * RC(3.) * (xx - yy) + SH_C3[1] * S(9, ch) * xz +
+                                           SH_C3[2] * S(10, ch) * (-RC(3.) * yy + RC(4.) * zz - xx) +
+                                           SH_C3[3] * S(11, ch) * -RC(3.) * RC(2.) * yz + SH_C3[4] * S(12, ch) * -RC(2.) * xy +
+                                           SH_C3[5] * S(13, ch) * -RC(2.) * yz + SH_C3[6] * S(14, ch) * -RC(3.) * RC(2.) * xy);
+                            dRGBdz[ch] += (SH_C3[1] * S(9, ch) * xy + SH_C3[2] * S(10, ch) * RC(4.) * RC(2.) * yz +
+                                           SH_C3[3] * S(11, ch) * RC(3.) * (RC(2.) * zz - xx - yy) +
+                                           SH_C3[4] * S(12, ch) * RC(4.) * RC(2.) * xz + SH_C3[5] * S(13, ch) * (xx - yy));
+                        }
+                    }
+                }
+            }
+#undef S
+#undef SETSH
+            const real ddir[3] = {dRGBdx[0] * dRGB[0] + dRGBdx[1] * dRGB[1] + dRGBdx[2] * dRGB[2],
+                                  dRGBdy[0] * dRGB[0] + dRGBdy[1] * dRGB[1] + dRGBdy[2] * dRGB[2],
+                                  dRGBdz[0] * dRGB[0] + dRGBdz[1] * dRGB[1] + dRGBdz[2] * dRGB[2]};
+            /* dnormvdv, auxiliary.h:119-129 */
+            const real vx = dir_o[0], vy = dir_o[1], vz = dir_o[2];
+            const real sum2 = vx * vx + vy * vy + vz * vz;
+            const real invsum32 = RC(1.) / r_sqrt(sum2 * sum2 * sum2);
+            dmean[0] += ((+sum2 - vx * vx) * ddir[0] - vy * vx * ddir[1] - vz * vx * ddir[2]) * invsum32;
+            dmean[1] += (-vx * vy * ddir[0] + (sum2 - vy * vy) * ddir[1] - vz * vy * ddir[2]) * invsum32;
+            dmean[2] += (-vx * vz * ddir[0] - vy * vz * ddir[1] + (sum2 - vz * vz) * ddir[2]) * invsum32;
+        }
+        for (int k = 0; k < 3; k++) dL_dmeans[3 * idx + k] = dmean[k];
+
+        { /* computeCov3D backward, backward.cu:257-310 */
+            const real* sc = scales + 3 * idx;
+            const real* q = rots + 4 * idx;
+            const real s[3] = {scale_mod * sc[0], scale_mod * sc[1], scale_mod * sc[2]};
+            real Rm[3][3];
+            quat_rows(q, Rm);
+            gmat3 Rg, Mg, dS;
+            for (int c = 0; c < 3; c++)
+                for (int r = 0; r < 3; r++) { Rg.m[c][r] = Rm[c][r]; Mg.m[c][r] = s[r] * Rm[c][r]; }
+            dS.m[0][0] = dcv[0]; dS.m[0][1] = RC(0.5) * dcv[1]; dS.m[0][2] = RC(0.5) * dcv[2];
+            dS.m[1][0] = RC(0.5) * dcv[1]; dS.m[1][1] = dcv[3]; dS.m[1][2] = RC(0.5) * dcv[4];
+            dS.m[2][0] = RC(0.5) * dcv[2]; dS.m[2][1] = RC(0.5) * dcv[4]; dS.m[2][2] = dcv[5];
+            gmat3 M2 = Mg;
+            for (int c = 0; c < 3; c++)
+                for (int r = 0; r < 3; r++) M2.m[c][r] = RC(2.) * Mg.m[c][r];
+            gmat3 dM = gmul(&M2, &dS);
+            gmat3 Rt = gtranspose(&Rg);
+            gmat3 dMt = gtranspose(&dM);
+            real* dsc = dL_dscale + 3 * idx;
+            for (int k = 0; k < 3; k++)
+                dsc[k] = Rt.m[k][0] * dMt.m[k][0] + Rt.m[k][1] * dMt.m[k][1] + Rt.m[k][2] * dMt.m[k][2];
+            for (int k = 0; k < 3; k++)
+                for (int r = 0; r < 3; r++) dMt.m[k][r] *= s[k];
+            const real r = q[0], x = q[1], y = q[2], z = q[3];
+            real* dq = dL_drot + 4 * idx;
+#define D_(c, rr) dMt.m[c][rr]
+            dq[0] = 2 * z * (D_(0, 1) - D_(1, 0)) + 2 * y * (D_(2, 0) - D_(0, 2)) + 2 * x * (D_(1, 2) - D_(2, 1));
+            dq[1] = 2 * y * (D_(0, 1) + D_(1, 0)) + 2 * z * (D_(2, 0) + D_(0, 2)) + 2 * r * (D_(1, 2) - D_(2, 1)) - 4 * x * (D_(2, 2) + D_(1, 1));
+            dq[2] = 2 * x * (D_(0, 1) + D_(1, 0)) + 2 * r * (D_(2, 0) - D_(0, 2)) + 2 * z * (D_(1, 2) + D_(2, 1)) - 4 * y * (D_(2, 2) + D_(0, 0));
+            dq[3] = 2 * r * (D_(0, 1) - D_(1, 0)) + 2 * x * (D_(2, 0) + D_(0, 2)) + 2 * y * (D_(1, 2) + D_(2, 1)) - 4 * z * (D_(1, 1) + D_(0, 0));
+#undef D_
+            if (lambda_erank > 0) { /* backward.cu:358-375 (uses the post-exp scale, q = s / sum(s^2)) */
+                const real s1s1 = sc[0] * sc[0], s2s2 = sc[1] * sc[1], s3s3 = sc[2] * sc[2];
+                const real sum = s1s1 + s2s2 + s3s3;
+                const real q1 = sc[0] / sum, q2 = sc[1] / sum, q3 = sc[2] / sum;
+                const real erank = r_exp(-q1 * r_log(q1) - q2 * r_log(q2) - q3 * r_log(q3));
+                if (-log((double)erank - 1 + 1e-5) > 0) {
+                    const real f = (real)((double)erank / ((double)erank - 1 + 1e-5));
+                    const real d1 = f * (-r_log(q1) - 1), d2 = f * (-r_log(q2) - 1), d3 = f * (-r_log(q3) - 1);
+                    const real le = lambda_erank * RC(2.) / (sum * sum);
+                    dsc[0] += le * sc[0] * (d1 * (s2s2 + s3s3) - d2 * s2s2 - d3 * s3s3);
+                    dsc[1] += le * sc[1] * (-d1 * s1s1 + d2 * (s1s1 + s3s3) - d3 * s3s3);
+                    dsc[2] += le * sc[2] * (-d1 * s1s1 - d2 * s2s2 + d3 * (s1s1 + s2s2));
+                }
+                dsc[2] += 1;
+            }
+        }
+    }
+}
+
+/* ================================================================================================
+ * Adam (adam.cu:9-38): visibility-masked, no bias correction.
+ */
+void orc_adam(real* param, const real* grad, real* m, real* v, const uint8_t* visible, real lr, real b1,
+              real b2, real eps, uint32_t N, uint32_t M)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t g = 0; g < (int64_t)N; g++) {
+        if (!visible[g]) continue;
+        for (uint32_t k = 0; k < M; k++) {
+            size_t p = (size_t)g * M + k;
+            real gr = grad[p];
+            real m1 = b1 * m[p] + (RC(1.) - b1) * gr;
+            real v1 = b2 * v[p] + (RC(1.) - b2) * gr * gr;
+            real step = -lr * m1 / (r_sqrt(v1) + eps);
+            param[p] += step;
+            m[p] = m1;
+            v[p] = v1;
+        }
+    }
+}
+
+/* ================================================================================================
+ * Fused SSIM (ssim.cu:8-18,35-41,186-365): 11-tap separable window, zero padding, taps summed 0..10
+ * starting from 0.0f, x pass then y pass.  Images [B,CH,H,W].
+ */
+static const real GW[11] = {RC(0.001028380123898387), RC(0.0075987582094967365), RC(0.036000773310661316),
+                            RC(0.10936068743467331), RC(0.21300552785396576), RC(0.26601171493530273),
+                            RC(0.21300552785396576), RC(0.10936068743467331), RC(0.036000773310661316),
+                            RC(0.0075987582094967365), RC(0.001028380123898387)};
+
+static inline real pixz(const real* img, int H, int W, int y, int x)
+{
+    return (x >= W || y >= H || x < 0 || y < 0) ? RC(0.) : img[(size_t)y * W + x];
+}
+/* separable conv at (y,x) of f(img1,img2) with mode: 0 a, 1 a*a, 2 b, 3 b*b, 4 a*b */
+static real sepconv(const real* a, const real* b, int H, int W, int y, int x, int mode)
+{
+    real col = RC(0.);
+    for (int j = 0; j < 11; j++) {
+        int yy = y + j - 5;
+        real row = RC(0.);
+        for (int i = 0; i < 11; i++) {
+            int xx = x + i - 5;
+            real pa = pixz(a, H, W, yy, xx), pb = b ? pixz(b, H, W, yy, xx) : RC(0.);
+            real val = mode == 0 ? pa : mode == 1 ? pa * pa : mode == 2 ? pb : mode == 3 ? pb * pb : pa * pb;
+            row += GW[i] * val;
+        }
+        col += GW[j] * row;
+    }
+    return col;
+}
+
+void orc_ssim_forward(int B, int CH, int H, int W, real C1, real C2, const real* img1, const real* img2,
+                      real* ssim_map, real* dm_dmu1, real* dm_dsigma1_sq, real* dm_dsigma12)
+{
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+    for (int bc = 0; bc < B * CH; bc++)
+        for (int y = 0; y < H; y++) {
+            const real* a = img1 + (size_t)bc * H * W;
+            const real* b = img2 + (size_t)bc * H * W;
+            for (int x = 0; x < W; x++) {
+                real mu1 = sepconv(a, b, H, W, y, x, 0);
+                real sigma1_sq = sepconv(a, b, H, W, y, x, 1) - mu1 * mu1;
+                real mu2 = sepconv(a, b, H, W, y, x, 2);
+                real sigma2_sq = sepconv(a, b, H, W, y, x, 3) - mu2 * mu2;
+                real sigma12 = sepconv(a, b, H, W, y, x, 4) - mu1 * mu2;
+                real mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu1_mu2 = mu1 * mu2;
+                real C = (RC(2.) * mu1_mu2 + C1), Dd = (RC(2.) * sigma12 + C2);
+                real A = (mu1_sq + mu2_sq + C1), Bq = (sigma1_sq + sigma2_sq + C2);
+                size_t o = (size_t)bc * H * W + (size_t)y * W + x;
+                ssim_map[o] = (C * Dd) / (A * Bq);
+                if (dm_dmu1) {
+                    dm_dmu1[o] = ((mu2 * RC(2.) * Dd) / (A * Bq) - (mu2 * RC(2.) * C) / (A * Bq) -
+                                  (mu1 * RC(2.) * C * Dd) / (A * A * Bq) + (mu1 * RC(2.) * C * Dd) / (A * Bq * Bq));
+                    dm_dsigma1_sq[o] = ((-C * Dd) / (A * Bq * Bq));
+                    dm_dsigma12[o] = ((2 * C) / (A * Bq));
+                }
+            }
+        }
+}
+
+void orc_ssim_backward(int B, int CH, int H, int W, const real* img1, const real* img2, const real* dL_dmap,
+                       const real* dm_dmu1, const real* dm_dsigma1_sq, const real* dm_dsigma12, real* dL_dimg1)
+{
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+    for (int bc = 0; bc < B * CH; bc++)
+        for (int y = 0; y < H; y++) {
+            size_t base = (size_t)bc * H * W;
+            for (int x = 0; x < W; x++) {
+                size_t o = base + (size_t)y * W + x;
+                real t1 = sepconv(dm_dmu1 + base, dL_dmap + base, H, W, y, x, 4);
+                real t2 = img1[o] * RC(2.) * sepconv(dm_dsigma1_sq + base, dL_dmap + base, H, W, y, x, 4);
+                real t3 = img2[o] * sepconv(dm_dsigma12 + base, dL_dmap + base, H, W, y, x, 4);
+                real acc = RC(0.);
+                acc += t1; acc += t2; acc += t3;
+                dL_dimg1[o] = acc;
+            }
+        }
+}
+
+/* ================================================================================================
+ * simple-knn result (simple_knn.cu:130-183): mean of the three smallest squared distances to other points,
+ * FLT_MAX for missing neighbours.  Brute force O(P^2): the Morton/box structure of the reference only prunes.
+ */
+void orc_knn(int P, const real* pts, real* out)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int i = 0; i < P; i++) {
+        real best[3] = {(real)FLT_MAX, (real)FLT_MAX, (real)FLT_MAX};
+        for (int j = 0; j < P; j++) {
+            if (j == i) continue;
+            real dx = pts[3 * j] - pts[3 * i], dy = pts[3 * j + 1] - pts[3 * i + 1], dz = pts[3 * j + 2] - pts[3 * i + 2];
+            real dist = dx * dx + dy * dy + dz * dz;
+            for (int k = 0; k < 3; k++)
+                if (best[k] > dist) { real t = best[k]; best[k] = dist; dist = t; }
+        }
+        out[i] = (best[0] + best[1] + best[2]) / RC(3.);
+    }
+}
+
+void orc_set_threads(int n);
+#ifdef _OPENMP
+#include <omp.h>
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int orc_max_threads(void) { return omp_get_max_threads(); }
+#else
+void orc_set_threads(int n) { (void)n; }
+int orc_max_threads(void) { return 1; }
+#endif
