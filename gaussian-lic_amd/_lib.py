@@ -1,0 +1,132 @@
+"""ctypes binding of libgslic_hip.so (the C-ABI of include/gslic_hip.h).
+
+There is NO fallback: if the library is missing or fails to load, every operator of this package raises.
+torch is imported first so that the process has exactly one HIP runtime (torch's bundled libamdhip64.so.7;
+libgslic_hip.so's DT_NEEDED entry resolves to the already-loaded object).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgslic_hip.so")
+
+ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
+
+class RasterParams(ctypes.Structure):
+    _fields_ = [("P", ctypes.c_int32), ("D", ctypes.c_int32), ("M", ctypes.c_int32), ("width", ctypes.c_int32),
+                ("height", ctypes.c_int32), ("tan_fovx", ctypes.c_float), ("tan_fovy", ctypes.c_float),
+                ("limx_neg", ctypes.c_float), ("limx_pos", ctypes.c_float), ("limy_neg", ctypes.c_float),
+                ("limy_pos", ctypes.c_float), ("scale_modifier", ctypes.c_float), ("prefiltered", ctypes.c_int32),
+                ("debug", ctypes.c_int32), ("no_color", ctypes.c_int32)]
+
+
+class AdamGroup(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("lr", ctypes.c_float), ("M", ctypes.c_uint32)]
+
+
+EXPORTS = [
+    "gslic_rasterize_forward", "gslic_rasterize_backward", "gslic_adam_update", "gslic_adam_update_groups",
+    "gslic_fusedssim_forward", "gslic_fusedssim_backward", "gslic_knn_mean_dist2", "gslic_abi_version",
+    "gslic_last_error", "gslic_geom_bytes", "gslic_img_bytes", "gslic_binning_bytes", "gslic_sample_bytes",
+    "gslic_profile_enable", "gslic_profile_reset", "gslic_profile_collect", "gslic_profile_num_kernels",
+    "gslic_profile_kernel_name", "gslic_profile_get", "gslic_debug_export",
+]
+
+_lib = None
+
+
+class GslicError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it is not built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GslicError(f"{LIB_PATH} is missing: run `python gaussian-lic_amd/build.py` (hipcc, gfx950). "
+                         "There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    vp, i32, f32, u32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_uint32
+    L.gslic_last_error.restype = ctypes.c_char_p
+    L.gslic_profile_kernel_name.restype = ctypes.c_char_p
+    L.gslic_profile_kernel_name.argtypes = [i32]
+    L.gslic_profile_get.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
+    for n in ("gslic_geom_bytes", "gslic_img_bytes", "gslic_binning_bytes", "gslic_sample_bytes"):
+        getattr(L, n).restype = ctypes.c_size_t
+    L.gslic_geom_bytes.argtypes = [i32]
+    L.gslic_img_bytes.argtypes = [i32, i32]
+    L.gslic_binning_bytes.argtypes = [i32, i32]
+    L.gslic_sample_bytes.argtypes = [i32]
+    L.gslic_rasterize_forward.argtypes = (
+        [ctypes.POINTER(RasterParams)] + [ALLOC_FN, vp] * 4 + [vp] * 12 + [vp, vp, vp] +
+        [ctypes.POINTER(i32), ctypes.POINTER(i32), vp])
+    L.gslic_rasterize_backward.argtypes = (
+        [ctypes.POINTER(RasterParams), i32, i32] + [vp] * 12 + [vp] * 4 + [vp] + [vp] * 10 + [f32, vp])
+    L.gslic_adam_update.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, u32, u32, vp]
+    L.gslic_adam_update_groups.argtypes = [ctypes.POINTER(AdamGroup), i32, vp, f32, f32, f32, u32, vp]
+    L.gslic_fusedssim_forward.argtypes = [i32, i32, i32, i32, f32, f32] + [vp] * 6 + [vp]
+    L.gslic_fusedssim_backward.argtypes = [i32, i32, i32, i32, f32, f32] + [vp] * 7 + [vp]
+    L.gslic_knn_mean_dist2.argtypes = [i32, vp, vp, ALLOC_FN, vp, vp]
+    L.gslic_debug_export.argtypes = [ctypes.POINTER(RasterParams), i32, i32] + [vp] * 4 + [vp] * 10 + [vp]
+    if L.gslic_abi_version() != 1:
+        raise GslicError("libgslic_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise GslicError(f"libgslic_hip error {rc}: {lib().gslic_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None / empty tensor -> NULL, like .data<float>() of an empty tensor)."""
+    if t is None or t.numel() == 0:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class TensorAllocator:
+    """Allocator callback backed by torch's caching allocator — the role of resizeFunctional
+    (rasterize_points.cu:40-48): one growable uint8 tensor per scratch buffer."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.cb = ALLOC_FN(self._alloc)
+
+    def _alloc(self, _ctx, nbytes):
+        self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self.tensor.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------- profiling
+def profile_enable(on=True):
+    check(lib().gslic_profile_enable(1 if on else 0))
+
+
+def profile_reset():
+    check(lib().gslic_profile_reset())
+
+
+def profile_collect():
+    """Synchronise and return {kernel_name: (total_ms, launches)} accumulated since the last reset."""
+    L = lib()
+    check(L.gslic_profile_collect())
+    out = {}
+    for i in range(L.gslic_profile_num_kernels()):
+        ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+        check(L.gslic_profile_get(i, ctypes.byref(ms), ctypes.byref(n)))
+        if n.value:
+            out[L.gslic_profile_kernel_name(i).decode()] = (ms.value, n.value)
+    return out

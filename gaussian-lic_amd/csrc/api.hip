@@ -1,0 +1,471 @@
+// api.hip — the C-ABI of include/gslic_hip.h: argument validation, scratch carving, stage sequencing,
+// per-kernel HIP-event profiling and the test-only debug export.  Stage sequencing follows
+// CudaRasterizer::Rasterizer::forward/backward (rasterizer_impl.cu:312-581); kernels live in the other .hip files.
+#include "gslic_common.h"
+#include "kernels.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+namespace gslic {
+
+// ---------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+int set_error(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+bool g_prof_on = false;
+static const char* const k_names[K_COUNT] = {
+    "preprocess", "scan_reduce", "scan_spine", "scan_apply", "keybuild", "sort_hist", "sort_scatter", "finalize_lists",
+    "bucket_count", "render_fwd", "render_bwd", "preprocess_bwd", "adam", "ssim_fwd", "ssim_bwd", "knn_minmax", "knn_morton",
+    "knn_boxes", "knn_search", "debug_export"};
+struct ProfRec { int id; hipEvent_t a, b; };
+static std::vector<ProfRec> g_pending;
+static std::vector<hipEvent_t> g_pool;
+static double g_total_ms[K_COUNT];
+static int64_t g_launches[K_COUNT];
+static hipEvent_t g_cur = nullptr;
+
+static hipEvent_t ev_get()
+{
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void prof_begin(int id, hipStream_t s)
+{
+    (void)id;
+    g_cur = ev_get();
+    (void)hipEventRecord(g_cur, s);
+}
+void prof_end(int id, hipStream_t s)
+{
+    hipEvent_t b = ev_get();
+    (void)hipEventRecord(b, s);
+    g_pending.push_back({id, g_cur, b});
+    g_cur = nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+GeomState GeomState::carve(const void* base, size_t P, size_t* bytes)
+{
+    Carver c(base);
+    GeomState g;
+    g.rec = c.take<float4>(3 * P);
+    g.tiles_touched = c.take<uint32_t>(P);
+    g.point_offsets = c.take<uint32_t>(P);
+    g.scan_temp = c.take<uint32_t>(scan_temp_elems(P));
+    g.flags = c.take<uint32_t>(16);
+    if (bytes) *bytes = c.used(base) + 256;
+    return g;
+}
+ImageState ImageState::carve(const void* base, size_t T, size_t* bytes)
+{
+    Carver c(base);
+    ImageState g;
+    g.ranges = c.take<uint2>(T);
+    g.bucket_offsets = c.take<uint32_t>(T);
+    g.max_contrib = c.take<uint32_t>(T);
+    g.pix_final = c.take<float4>(T * GS_TILE_PIX);
+    g.scan_temp = c.take<uint32_t>(scan_temp_elems(T));
+    if (bytes) *bytes = c.used(base) + 256;
+    return g;
+}
+BinningState BinningState::carve(const void* base, size_t R, int end_bit, bool no_color, size_t* bytes)
+{
+    Carver c(base);
+    BinningState g;
+    g.plan = sort_plan(R, end_bit);
+    g.keys[0] = c.take<uint64_t>(R);
+    g.keys[1] = c.take<uint64_t>(R);
+    g.vals[0] = c.take<uint32_t>(R);
+    g.vals[1] = c.take<uint32_t>(R);
+    g.inst_gauss = c.take<uint32_t>(R);
+    g.point_list = c.take<uint32_t>(R);
+    g.hist = c.take<uint32_t>(g.plan.hist_elems);
+    g.scan_temp = c.take<uint32_t>(scan_temp_elems(g.plan.hist_elems));
+    g.partials = no_color ? nullptr : c.take<float4>(3 * R);
+    if (bytes) *bytes = c.used(base) + 256;
+    return g;
+}
+SampleState SampleState::carve(const void* base, size_t B, size_t* bytes)
+{
+    Carver c(base);
+    SampleState g;
+    g.bucket_to_tile = c.take<uint32_t>(B);
+    g.ckpt = c.take<float4>(B * GS_TILE_PIX);
+    if (bytes) *bytes = c.used(base) + 256;
+    return g;
+}
+
+static inline char* align256(char* p) { return reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 255) & ~uintptr_t(255)); }
+static inline int tile_grid(int W, int H, int& gx, int& gy)
+{
+    gx = (W + GS_TILE - 1) / GS_TILE;
+    gy = (H + GS_TILE - 1) / GS_TILE;
+    return gx * gy;
+}
+static inline int sort_end_bit(int T) { return 32 + (int)higher_msb((uint32_t)T); }
+
+int adam_update(float*, const float*, float*, float*, const uint8_t*, float, float, float, float, uint32_t, uint32_t, hipStream_t);
+int adam_update_groups(const gslic_adam_group*, int, const uint8_t*, float, float, float, uint32_t, hipStream_t);
+int ssim_forward(int, int, int, int, float, float, const float*, const float*, float*, float*, float*, float*, hipStream_t);
+int ssim_backward(int, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*, float*,
+                  hipStream_t);
+int knn_mean_dist2(int, const float*, float*, gslic_alloc_fn, void*, hipStream_t);
+
+static int check_params(const gslic_raster_params* p)
+{
+    if (!p) return set_error(GSLIC_ERR_INVALID_ARG, "params is NULL");
+    if (p->P < 0 || p->width <= 0 || p->height <= 0) return set_error(GSLIC_ERR_INVALID_ARG, "bad sizes P=%d W=%d H=%d", p->P, p->width, p->height);
+    if (p->D < 0 || p->D > 3) return set_error(GSLIC_ERR_INVALID_ARG, "SH degree %d out of range 0..3", p->D);
+    if (p->M < 0 || (p->D > 0 && p->M < (p->D + 1) * (p->D + 1) - 1))
+        return set_error(GSLIC_ERR_INVALID_ARG, "M=%d rest coefficients cannot hold SH degree %d", p->M, p->D);
+    return GSLIC_OK;
+}
+
+#define DEBUG_SYNC(prm, s)                                                   \
+    do {                                                                     \
+        if ((prm)->debug) GS_HIP(hipStreamSynchronize(s));                   \
+    } while (0)
+
+}  // namespace gslic
+
+using namespace gslic;
+
+extern "C" {
+
+int gslic_abi_version(void) { return GSLIC_ABI_VERSION; }
+const char* gslic_last_error(void) { return g_err; }
+
+size_t gslic_geom_bytes(int32_t P) { size_t b; GeomState::carve(nullptr, (size_t)(P > 0 ? P : 0), &b); return b; }
+size_t gslic_img_bytes(int32_t W, int32_t H)
+{
+    int gx, gy; size_t b;
+    ImageState::carve(nullptr, (size_t)tile_grid(W, H, gx, gy), &b);
+    return b;
+}
+size_t gslic_binning_bytes(int32_t R, int32_t no_color)
+{
+    size_t b;
+    BinningState::carve(nullptr, (size_t)(R > 0 ? R : 0), 64, no_color != 0, &b);  // end_bit only changes the pass count
+    return b;
+}
+size_t gslic_sample_bytes(int32_t B) { size_t b; SampleState::carve(nullptr, (size_t)(B > 0 ? B : 0), &b); return b; }
+
+int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_alloc, void* geom_ctx, gslic_alloc_fn binning_alloc,
+                            void* binning_ctx, gslic_alloc_fn img_alloc, void* img_ctx, gslic_alloc_fn sample_alloc,
+                            void* sample_ctx, const float* background, const float* means3D, const float* dc, const float* shs,
+                            const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
+                            const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                            float* out_color, float* out_final_T, int32_t* radii, int32_t* num_rendered, int32_t* num_buckets,
+                            void* stream)
+{
+    (void)background;
+    GS_TRY(check_params(prm));
+    if (!num_rendered || !num_buckets) return set_error(GSLIC_ERR_INVALID_ARG, "num_rendered / num_buckets is NULL");
+    *num_rendered = 0;
+    *num_buckets = 0;
+    const int P = prm->P;
+    if (P == 0) return GSLIC_OK;  // rasterize_points.cu:110
+    if (colors_precomp || cov3D_precomp)
+        return set_error(GSLIC_ERR_UNSUPPORTED, "colors_precomp / cov3D_precomp are not supported (the reference host always passes empty tensors)");
+    if (!geom_alloc || !binning_alloc || !img_alloc || (!prm->no_color && !sample_alloc))
+        return set_error(GSLIC_ERR_INVALID_ARG, "allocator callback is NULL");
+    if (!means3D || !dc || !opacities || !scales || !rotations || !viewmatrix || !projmatrix || !cam_pos || !out_final_T || !radii ||
+        (!prm->no_color && !out_color) || (prm->M > 0 && !shs))
+        return set_error(GSLIC_ERR_INVALID_ARG, "required tensor pointer is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    const bool no_color = prm->no_color != 0;
+    int gx, gy;
+    const int T = tile_grid(prm->width, prm->height, gx, gy);
+
+    size_t geom_bytes, img_bytes;
+    GeomState::carve(nullptr, (size_t)P, &geom_bytes);
+    char* geom_base = geom_alloc(geom_ctx, geom_bytes);
+    if (!geom_base) return set_error(GSLIC_ERR_ALLOC, "geometry allocator returned NULL for %zu bytes", geom_bytes);
+    GeomState geom = GeomState::carve(align256(geom_base), (size_t)P, nullptr);
+    ImageState::carve(nullptr, (size_t)T, &img_bytes);
+    char* img_base = img_alloc(img_ctx, img_bytes);
+    if (!img_base) return set_error(GSLIC_ERR_ALLOC, "image allocator returned NULL for %zu bytes", img_bytes);
+    ImageState img = ImageState::carve(align256(img_base), (size_t)T, nullptr);
+
+    GS_HIP(hipMemsetAsync(geom.flags, 0, 16 * sizeof(uint32_t), s));
+    PreprocessArgs pa;
+    pa.P = P; pa.D = prm->D; pa.M = prm->M; pa.W = prm->width; pa.H = prm->height; pa.gx = gx; pa.gy = gy;
+    pa.focal_y = prm->height / (2.0f * prm->tan_fovy);  // rasterizer_impl.cu:348-349
+    pa.focal_x = prm->width / (2.0f * prm->tan_fovx);
+    pa.limx_neg = prm->limx_neg; pa.limx_pos = prm->limx_pos; pa.limy_neg = prm->limy_neg; pa.limy_pos = prm->limy_pos;
+    pa.scale_modifier = prm->scale_modifier; pa.prefiltered = prm->prefiltered; pa.no_color = prm->no_color;
+    pa.means = means3D; pa.scales = scales; pa.rots = rotations; pa.opac = opacities; pa.dc = dc; pa.shs = shs;
+    pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = cam_pos;
+    pa.radii = radii; pa.rec = geom.rec; pa.tiles_touched = geom.tiles_touched; pa.flags = geom.flags;
+    GS_TRY(launch_preprocess(pa, s));
+    DEBUG_SYNC(prm, s);
+
+    GS_TRY(scan_u32(geom.tiles_touched, geom.point_offsets, (size_t)P, false, geom.scan_temp, s));
+    uint32_t hostbuf[2] = {0, 0};
+    GS_HIP(hipMemcpyAsync(&hostbuf[0], geom.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GS_HIP(hipMemcpyAsync(&hostbuf[1], geom.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GS_HIP(hipStreamSynchronize(s));  // host needs R to size the binning buffer (rasterizer_impl.cu:398)
+    if (prm->prefiltered && hostbuf[1]) return set_error(GSLIC_ERR_PREFILTERED, "a point was culled although prefiltered is set");
+    if (hostbuf[0] > 0x7fffffffu) return set_error(GSLIC_ERR_INVALID_ARG, "more than 2^31 (Gaussian, tile) instances");
+    const uint32_t R = hostbuf[0];
+
+    size_t bin_bytes;
+    const int end_bit = sort_end_bit(T);
+    BinningState::carve(nullptr, (size_t)R, end_bit, no_color, &bin_bytes);
+    char* bin_base = binning_alloc(binning_ctx, bin_bytes);
+    if (!bin_base) return set_error(GSLIC_ERR_ALLOC, "binning allocator returned NULL for %zu bytes", bin_bytes);
+    BinningState bin = BinningState::carve(align256(bin_base), (size_t)R, end_bit, no_color, nullptr);
+
+    GS_HIP(hipMemsetAsync(img.ranges, 0, (size_t)T * sizeof(uint2), s));  // rasterizer_impl.cu:426
+    if (R > 0) {
+        KeybuildArgs ka;
+        ka.P = P; ka.gx = gx; ka.gy = gy; ka.radii = radii; ka.rec = geom.rec; ka.offsets = geom.point_offsets;
+        ka.keys = bin.keys[0]; ka.vals = bin.vals[0]; ka.inst_gauss = bin.inst_gauss;
+        GS_TRY(launch_keybuild(ka, s));
+        DEBUG_SYNC(prm, s);
+        GS_TRY(radix_sort_pairs(bin.keys, bin.vals, bin.plan, bin.hist, bin.scan_temp, s));
+        DEBUG_SYNC(prm, s);
+        const int fin = bin.plan.passes & 1;
+        GS_TRY(launch_finalize_lists(R, bin.keys[fin], bin.vals[fin], bin.inst_gauss, bin.point_list, img.ranges, s));
+        DEBUG_SYNC(prm, s);
+    }
+
+    SampleState smp;
+    memset(&smp, 0, sizeof(smp));
+    uint32_t B = 0;
+    if (!no_color) {
+        GS_TRY(launch_bucket_count(T, img.ranges, img.bucket_offsets, s));
+        GS_TRY(scan_u32(img.bucket_offsets, img.bucket_offsets, (size_t)T, false, img.scan_temp, s));
+        GS_HIP(hipMemcpyAsync(&hostbuf[0], img.bucket_offsets + (T - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        GS_HIP(hipStreamSynchronize(s));  // rasterizer_impl.cu:442
+        B = hostbuf[0];
+        size_t smp_bytes;
+        SampleState::carve(nullptr, (size_t)B, &smp_bytes);
+        char* smp_base = sample_alloc(sample_ctx, smp_bytes);
+        if (!smp_base) return set_error(GSLIC_ERR_ALLOC, "sample allocator returned NULL for %zu bytes", smp_bytes);
+        smp = SampleState::carve(align256(smp_base), (size_t)B, nullptr);
+    }
+
+    RenderFwdArgs ra;
+    ra.W = prm->width; ra.H = prm->height; ra.gx = gx; ra.gy = gy; ra.no_color = prm->no_color;
+    ra.ranges = img.ranges; ra.point_list = bin.point_list; ra.rec = geom.rec; ra.bucket_offsets = img.bucket_offsets;
+    ra.bucket_to_tile = smp.bucket_to_tile; ra.ckpt = smp.ckpt; ra.pix_final = img.pix_final; ra.max_contrib = img.max_contrib;
+    ra.out_color = out_color; ra.out_final_T = out_final_T;
+    GS_TRY(launch_render_fwd(ra, s));
+    DEBUG_SYNC(prm, s);
+
+    *num_rendered = (int32_t)R;
+    *num_buckets = (int32_t)B;
+    return GSLIC_OK;
+}
+
+int gslic_rasterize_backward(const gslic_raster_params* prm, int32_t R, int32_t B, const float* background, const float* means3D,
+                             const float* dc, const float* shs, const float* colors_precomp, const float* scales,
+                             const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                             const float* cam_pos, const int32_t* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
+                             char* sample_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                             float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_ddc, float* dL_dsh, float* dL_dscale,
+                             float* dL_drot, float lambda_erank, void* stream)
+{
+    (void)background; (void)dc;
+    GS_TRY(check_params(prm));
+    const int P = prm->P;
+    if (P == 0) return GSLIC_OK;  // rasterize_points.cu:203
+    if (colors_precomp || cov3D_precomp)
+        return set_error(GSLIC_ERR_UNSUPPORTED, "colors_precomp / cov3D_precomp are not supported");
+    if (prm->no_color) return set_error(GSLIC_ERR_INVALID_ARG, "backward of a no_color forward is undefined (no checkpoints were stored)");
+    if (R < 0 || B < 0) return set_error(GSLIC_ERR_INVALID_ARG, "negative R / B");
+    if (!means3D || !scales || !rotations || !viewmatrix || !projmatrix || !cam_pos || !radii || !geom_buffer || !binning_buffer ||
+        !img_buffer || !sample_buffer || !dL_dpix || !dL_dopacity || !dL_dmean3D || !dL_ddc || !dL_dscale || !dL_drot ||
+        (prm->M > 0 && (!shs || !dL_dsh)))
+        return set_error(GSLIC_ERR_INVALID_ARG, "required tensor pointer is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    int gx, gy;
+    const int T = tile_grid(prm->width, prm->height, gx, gy);
+    GeomState geom = GeomState::carve(align256(geom_buffer), (size_t)P, nullptr);
+    ImageState img = ImageState::carve(align256(img_buffer), (size_t)T, nullptr);
+    BinningState bin = BinningState::carve(align256(binning_buffer), (size_t)R, sort_end_bit(T), false, nullptr);
+    SampleState smp = SampleState::carve(align256(sample_buffer), (size_t)B, nullptr);
+
+    RenderBwdArgs rb;
+    rb.W = prm->width; rb.H = prm->height; rb.gx = gx; rb.B = B;
+    rb.ranges = img.ranges; rb.point_list = bin.point_list; rb.inst_slot = bin.vals[bin.plan.passes & 1]; rb.rec = geom.rec;
+    rb.bucket_offsets = img.bucket_offsets; rb.bucket_to_tile = smp.bucket_to_tile; rb.ckpt = smp.ckpt; rb.pix_final = img.pix_final;
+    rb.max_contrib = img.max_contrib; rb.dL_dpix = dL_dpix; rb.partials = bin.partials;
+    GS_TRY(launch_render_bwd(rb, s));
+    DEBUG_SYNC(prm, s);
+
+    PreprocessBwdArgs pb;
+    pb.P = P; pb.D = prm->D; pb.M = prm->M; pb.W = prm->width; pb.H = prm->height;
+    pb.focal_y = prm->height / (2.0f * prm->tan_fovy);
+    pb.focal_x = prm->width / (2.0f * prm->tan_fovx);
+    pb.limx_neg = prm->limx_neg; pb.limx_pos = prm->limx_pos; pb.limy_neg = prm->limy_neg; pb.limy_pos = prm->limy_pos;
+    pb.scale_modifier = prm->scale_modifier; pb.lambda_erank = lambda_erank;
+    pb.means = means3D; pb.scales = scales; pb.rots = rotations; pb.dc = dc; pb.shs = shs; pb.view = viewmatrix; pb.proj = projmatrix;
+    pb.campos = cam_pos; pb.radii = radii; pb.rec = geom.rec; pb.offsets = geom.point_offsets; pb.partials = bin.partials;
+    pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
+    pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_ddc = dL_ddc; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale;
+    pb.dL_drot = dL_drot;
+    GS_TRY(launch_preprocess_bwd(pb, s));
+    DEBUG_SYNC(prm, s);
+    return GSLIC_OK;
+}
+
+int gslic_adam_update(float* param, const float* param_grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible, float lr,
+                      float b1, float b2, float eps, uint32_t N, uint32_t M, void* stream)
+{
+    if ((size_t)N * M == 0) return GSLIC_OK;
+    if (!param || !param_grad || !exp_avg || !exp_avg_sq || !visible) return set_error(GSLIC_ERR_INVALID_ARG, "adam: NULL tensor pointer");
+    return adam_update(param, param_grad, exp_avg, exp_avg_sq, visible, lr, b1, b2, eps, N, M, (hipStream_t)stream);
+}
+
+int gslic_adam_update_groups(const gslic_adam_group* groups, int32_t n_groups, const uint8_t* visible, float b1, float b2, float eps,
+                             uint32_t N, void* stream)
+{
+    if (n_groups <= 0 || N == 0) return GSLIC_OK;
+    if (!groups || !visible) return set_error(GSLIC_ERR_INVALID_ARG, "adam groups: NULL pointer");
+    for (int i = 0; i < n_groups; i++)
+        if (groups[i].M == 0 || !groups[i].param || !groups[i].grad || !groups[i].exp_avg || !groups[i].exp_avg_sq)
+            return set_error(GSLIC_ERR_INVALID_ARG, "adam group %d has a NULL pointer or M == 0", i);
+    return adam_update_groups(groups, n_groups, visible, b1, b2, eps, N, (hipStream_t)stream);
+}
+
+int gslic_fusedssim_forward(int32_t B, int32_t CH, int32_t H, int32_t W, float C1, float C2, const float* img1, const float* img2,
+                            float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream)
+{
+    if (B < 0 || CH < 0 || H < 0 || W < 0) return set_error(GSLIC_ERR_INVALID_ARG, "ssim: negative size");
+    if ((size_t)B * CH * H * W == 0) return GSLIC_OK;
+    if (!img1 || !img2 || !ssim_map) return set_error(GSLIC_ERR_INVALID_ARG, "ssim: NULL tensor pointer");
+    const int nd = (dm_dmu1 != nullptr) + (dm_dsigma1_sq != nullptr) + (dm_dsigma12 != nullptr);
+    if (nd != 0 && nd != 3) return set_error(GSLIC_ERR_INVALID_ARG, "ssim: pass all three derivative maps or none");
+    return ssim_forward(B, CH, H, W, C1, C2, img1, img2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (hipStream_t)stream);
+}
+
+int gslic_fusedssim_backward(int32_t B, int32_t CH, int32_t H, int32_t W, float C1, float C2, const float* img1, const float* img2,
+                             const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
+                             float* dL_dimg1, void* stream)
+{
+    (void)C1; (void)C2;
+    if (B < 0 || CH < 0 || H < 0 || W < 0) return set_error(GSLIC_ERR_INVALID_ARG, "ssim: negative size");
+    if ((size_t)B * CH * H * W == 0) return GSLIC_OK;
+    if (!img1 || !img2 || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1)
+        return set_error(GSLIC_ERR_INVALID_ARG, "ssim backward: NULL tensor pointer");
+    return ssim_backward(B, CH, H, W, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1, (hipStream_t)stream);
+}
+
+int gslic_knn_mean_dist2(int32_t P, const float* points, float* mean_dists, gslic_alloc_fn scratch_alloc, void* scratch_ctx,
+                         void* stream)
+{
+    if (P < 0) return set_error(GSLIC_ERR_INVALID_ARG, "knn: negative P");
+    if (P == 0) return GSLIC_OK;
+    if (!points || !mean_dists || !scratch_alloc) return set_error(GSLIC_ERR_INVALID_ARG, "knn: NULL pointer");
+    return knn_mean_dist2(P, points, mean_dists, scratch_alloc, scratch_ctx, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+int gslic_profile_enable(int32_t on) { g_prof_on = on != 0; return GSLIC_OK; }
+int gslic_profile_reset(void)
+{
+    GS_HIP(hipDeviceSynchronize());
+    for (auto& r : g_pending) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+    g_pending.clear();
+    memset(g_total_ms, 0, sizeof(g_total_ms));
+    memset(g_launches, 0, sizeof(g_launches));
+    return GSLIC_OK;
+}
+int gslic_profile_collect(void)
+{
+    GS_HIP(hipDeviceSynchronize());
+    for (auto& r : g_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { g_total_ms[r.id] += ms; g_launches[r.id] += 1; }
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_pending.clear();
+    return GSLIC_OK;
+}
+int gslic_profile_num_kernels(void) { return K_COUNT; }
+const char* gslic_profile_kernel_name(int32_t id) { return (id >= 0 && id < K_COUNT) ? k_names[id] : ""; }
+int gslic_profile_get(int32_t id, double* total_ms, int64_t* launches)
+{
+    if (id < 0 || id >= K_COUNT) return set_error(GSLIC_ERR_INVALID_ARG, "bad kernel id %d", id);
+    if (total_ms) *total_ms = g_total_ms[id];
+    if (launches) *launches = g_launches[id];
+    return GSLIC_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// test-only export of stage boundaries
+namespace gslic {
+__global__ __launch_bounds__(256) void export_geom_kernel(int P, const float4* __restrict__ rec, const uint32_t* __restrict__ tiles,
+                                                          uint32_t* o_tiles, float* o_m2d, float* o_depth, float* o_co, float* o_rgb)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const bool vis = tiles[i] > 0;
+    const float4 r0 = vis ? rec[3 * (size_t)i] : make_float4(0, 0, 0, 0);
+    const float4 r1 = vis ? rec[3 * (size_t)i + 1] : make_float4(0, 0, 0, 0);
+    const float4 r2 = vis ? rec[3 * (size_t)i + 2] : make_float4(0, 0, 0, 0);
+    if (o_tiles) o_tiles[i] = tiles[i];
+    if (o_m2d) { o_m2d[2 * i] = r0.x; o_m2d[2 * i + 1] = r0.y; }
+    if (o_depth) o_depth[i] = r2.y;
+    if (o_co) { o_co[4 * i] = r0.z; o_co[4 * i + 1] = r0.w; o_co[4 * i + 2] = r1.x; o_co[4 * i + 3] = r1.y; }
+    if (o_rgb) { o_rgb[3 * i] = r1.z; o_rgb[3 * i + 1] = r1.w; o_rgb[3 * i + 2] = r2.x; }
+}
+__global__ __launch_bounds__(256) void export_ncontrib_kernel(int W, int H, int gx, const float4* __restrict__ pix_final, uint32_t* o)
+{
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= W || y >= H) return;
+    const int tile = blockIdx.y * gx + blockIdx.x;
+    o[(size_t)y * W + x] = __float_as_uint(pix_final[(size_t)tile * GS_TILE_PIX + threadIdx.x].w);
+}
+}  // namespace gslic
+
+extern "C" int gslic_debug_export(const gslic_raster_params* prm, int32_t R, int32_t B, const char* geom_buffer,
+                                  const char* binning_buffer, const char* img_buffer, const char* sample_buffer,
+                                  uint32_t* tiles_touched, float* means2D, float* depths, float* conic_opacity, float* rgb,
+                                  uint64_t* sorted_keys, uint32_t* point_list, uint32_t* ranges, uint32_t* n_contrib,
+                                  uint32_t* max_contrib, void* stream)
+{
+    (void)B; (void)sample_buffer;
+    GS_TRY(check_params(prm));
+    hipStream_t s = (hipStream_t)stream;
+    const int P = prm->P;
+    int gx, gy;
+    const int T = tile_grid(prm->width, prm->height, gx, gy);
+    if (P == 0) return GSLIC_OK;
+    GeomState geom = GeomState::carve(align256(const_cast<char*>(geom_buffer)), (size_t)P, nullptr);
+    ImageState img = ImageState::carve(align256(const_cast<char*>(img_buffer)), (size_t)T, nullptr);
+    BinningState bin = BinningState::carve(align256(const_cast<char*>(binning_buffer)), (size_t)R, sort_end_bit(T), prm->no_color != 0, nullptr);
+    if (tiles_touched || means2D || depths || conic_opacity || rgb)
+        GS_LAUNCH(K_DEBUG_EXPORT, export_geom_kernel, dim3(div_up(P, 256)), dim3(256), 0, s, P, (const float4*)geom.rec,
+                  (const uint32_t*)geom.tiles_touched, tiles_touched, means2D, depths, conic_opacity, rgb);
+    if (R > 0 && sorted_keys)
+        GS_HIP(hipMemcpyAsync(sorted_keys, bin.keys[bin.plan.passes & 1], (size_t)R * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+    if (R > 0 && point_list)
+        GS_HIP(hipMemcpyAsync(point_list, bin.point_list, (size_t)R * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    if (ranges) GS_HIP(hipMemcpyAsync(ranges, img.ranges, (size_t)T * sizeof(uint2), hipMemcpyDeviceToDevice, s));
+    if (!prm->no_color) {
+        if (max_contrib) GS_HIP(hipMemcpyAsync(max_contrib, img.max_contrib, (size_t)T * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        if (n_contrib)
+            GS_LAUNCH(K_DEBUG_EXPORT, export_ncontrib_kernel, dim3(gx, gy), dim3(256), 0, s, prm->width, prm->height, gx,
+                      (const float4*)img.pix_final, n_contrib);
+    }
+    return GSLIC_OK;
+}

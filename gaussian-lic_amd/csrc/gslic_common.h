@@ -1,0 +1,280 @@
+// gslic_common.h — shared declarations of libgslic_hip.so (gfx950 only; wave = 64 lanes everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/gslic_hip.h"
+
+#define GS_TILE 16        // tile edge in pixels (config.h:16-17 of the reference; part of the tile-list contract)
+#define GS_TILE_PIX 256   // pixels per tile
+#define GS_BUCKET 64      // checkpoint period = one wave of list entries (reference: 32 = one CUDA warp)
+#define GS_WAVE 64
+
+namespace gslic {
+
+// ---------------------------------------------------------------------------------------------------------
+// errors
+int set_error(int code, const char* fmt, ...);
+#define GS_HIP(call)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e__ = (call);                                                                           \
+        if (e__ != hipSuccess)                                                                             \
+            return ::gslic::set_error(GSLIC_ERR_HIP, "%s: %s (%s:%d)", #call, hipGetErrorString(e__),      \
+                                      __FILE__, __LINE__);                                                 \
+    } while (0)
+#define GS_TRY(expr)                                                                                       \
+    do {                                                                                                   \
+        int rc__ = (expr);                                                                                 \
+        if (rc__ != GSLIC_OK) return rc__;                                                                 \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// per-kernel profiling (HIP events on the launch stream)
+enum KernelId {
+    K_PREPROCESS = 0,
+    K_SCAN_REDUCE,
+    K_SCAN_SPINE,
+    K_SCAN_APPLY,
+    K_KEYBUILD,
+    K_SORT_HIST,
+    K_SORT_SCATTER,
+    K_FINALIZE_LISTS,
+    K_BUCKET_COUNT,
+    K_RENDER_FWD,
+    K_RENDER_BWD,
+    K_PREPROCESS_BWD,
+    K_ADAM,
+    K_SSIM_FWD,
+    K_SSIM_BWD,
+    K_KNN_MINMAX,
+    K_KNN_MORTON,
+    K_KNN_BOXES,
+    K_KNN_SEARCH,
+    K_DEBUG_EXPORT,
+    K_COUNT
+};
+void prof_begin(int id, hipStream_t s);
+void prof_end(int id, hipStream_t s);
+extern bool g_prof_on;
+
+#define GS_LAUNCH(id, kernel, grid, block, shmem, stream, ...)                                             \
+    do {                                                                                                   \
+        if (::gslic::g_prof_on) ::gslic::prof_begin(id, stream);                                           \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                               \
+        if (::gslic::g_prof_on) ::gslic::prof_end(id, stream);                                             \
+        GS_HIP(hipGetLastError());                                                                         \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// scratch-buffer carving: 256-B aligned bump allocation inside one caller-provided byte buffer
+struct Carver {
+    uintptr_t p;
+    explicit Carver(const void* base) : p(reinterpret_cast<uintptr_t>(base)) {}
+    template <typename T>
+    T* take(size_t count)
+    {
+        p = (p + 255) & ~uintptr_t(255);
+        T* r = reinterpret_cast<T*>(p);
+        p += count * sizeof(T);
+        return r;
+    }
+    size_t used(const void* base) const { return p - reinterpret_cast<uintptr_t>(base); }
+};
+
+static inline int div_up(int a, int b) { return (a + b - 1) / b; }
+static inline size_t div_up_sz(size_t a, size_t b) { return (a + b - 1) / b; }
+
+// rasterizer_impl.cu:42-57: number of bits needed for the tile id in the sort key
+static inline uint32_t higher_msb(uint32_t n)
+{
+    uint32_t bits = 0;
+    while (bits < 32 && (n >> bits) != 0) ++bits;
+    return bits == 0 ? 1 : bits;
+}
+
+// scan.hip ------------------------------------------------------------------------------------------------
+size_t scan_temp_elems(size_t n);  // u32 elements of scratch needed by scan_u32 for n inputs
+// inclusive (or exclusive) prefix sum of n u32 values; in == out allowed
+int scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, uint32_t* temp, hipStream_t s);
+
+// radix_sort.hip ------------------------------------------------------------------------------------------
+#define GS_SORT_ITEMS 16
+#define GS_SORT_BLOCK 256
+#define GS_SORT_TILE (GS_SORT_ITEMS * GS_SORT_BLOCK)
+struct SortPlan {
+    size_t n;
+    int passes;      // ceil(end_bit / 8)
+    size_t nblk;     // ceil(n / GS_SORT_TILE)
+    size_t hist_elems;  // 256 * nblk
+};
+SortPlan sort_plan(size_t n, int end_bit);
+// Stable LSD radix sort of (u64 key, u32 value) pairs on bits [0, end_bit).  Ping-pongs between the two
+// buffer pairs starting from index 0; the result is in buffers [plan.passes & 1].
+int radix_sort_pairs(uint64_t* keys[2], uint32_t* vals[2], const SortPlan& plan, uint32_t* hist,
+                     uint32_t* scan_temp, hipStream_t s);
+
+// opaque scratch layouts ----------------------------------------------------------------------------------
+struct GeomState {
+    float4* rec;             // [3P] per Gaussian: {mx,my,conic.x,conic.y} {conic.z,opacity,r,g} {b,depth,clamped-bits,0}
+    uint32_t* tiles_touched; // [P]
+    uint32_t* point_offsets; // [P] inclusive scan of tiles_touched
+    uint32_t* scan_temp;
+    uint32_t* flags;         // [16] device-side status words ([0] = prefiltered violation)
+    static GeomState carve(const void* base, size_t P, size_t* bytes);
+};
+struct ImageState {
+    uint2* ranges;            // [T]
+    uint32_t* bucket_offsets; // [T] inclusive scan of ceil(n_t / GS_BUCKET)
+    uint32_t* max_contrib;    // [T]
+    float4* pix_final;        // [T*256] tile-major {C.r,C.g,C.b, n_contrib bits}
+    uint32_t* scan_temp;
+    static ImageState carve(const void* base, size_t T, size_t* bytes);
+};
+struct BinningState {
+    uint64_t* keys[2];        // [R] ping-pong
+    uint32_t* vals[2];        // [R] ping-pong payload = emission slot u
+    uint32_t* inst_gauss;     // [R] emission slot -> Gaussian id
+    uint32_t* point_list;     // [R] sorted position -> Gaussian id
+    uint32_t* hist;           // [256 * nblk]
+    uint32_t* scan_temp;
+    float4* partials;         // [3R] per emission slot: 9 partial gradients (+3 pad), only when !no_color
+    SortPlan plan;
+    static BinningState carve(const void* base, size_t R, int end_bit, bool no_color, size_t* bytes);
+};
+struct SampleState {
+    uint32_t* bucket_to_tile; // [B]
+    float4* ckpt;             // [B*256] {T, C.r, C.g, C.b} at the start of each bucket, per pixel
+    static SampleState carve(const void* base, size_t B, size_t* bytes);
+};
+
+}  // namespace gslic
+
+// =========================================================================================================
+// Device-side canonical arithmetic for everything that decides an integer (radii, tiles_touched, keys).
+// Must be compiled with -ffp-contract=off; mirrors oracle/gs_oracle.c operation by operation.
+// =========================================================================================================
+#if defined(__HIPCC__)
+namespace gslic {
+
+__device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+
+// 64-lane inclusive scan and 256-thread block exclusive prefix (lds: >= 4 u32, reusable after return)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t block256_exclusive_prefix(uint32_t thread_sum, uint32_t& block_total, uint32_t* lds)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(thread_sum);
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    uint32_t wave_base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t s = lds[w];
+        if (w < wave) wave_base += s;
+        total += s;
+    }
+    __syncthreads();
+    block_total = total;
+    return wave_base + inc - thread_sum;
+}
+__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ uint32_t readlane_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+// whole-wave shift right by one lane (lane l receives lane l-1; lane 0 keeps its own value): v_mov_b32 dpp wave_shr:1
+__device__ __forceinline__ float wave_shr1_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint32_t wave_shr1_u(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
+}
+
+// Canonical logf for the culling threshold (forward.cu:302): fixed double polynomial, identical to orc_logf.
+__device__ __forceinline__ float canon_logf(float x)
+{
+    uint32_t u = __float_as_uint(x);
+    int e = (int)(u >> 23) - 127;
+    if ((u >> 23) == 0) {
+        x = x * 8388608.0f;
+        u = __float_as_uint(x);
+        e = (int)(u >> 23) - 127 - 23;
+    }
+    u = (u & 0x007fffffu) | 0x3f800000u;
+    double m = (double)__uint_as_float(u);
+    if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1; }
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double p = 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z + 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z + 1.0 / 3.0;
+    p = p * z + 1.0;
+    double r = (double)e * 0.6931471805599453 + 2.0 * s * p;
+    return (float)r;
+}
+
+__device__ __forceinline__ float cull_threshold(float opacity) { return canon_logf(opacity / (1.0f / 255.0f)); }
+
+__device__ __forceinline__ int trunc_clamped(float v, int hi)
+{
+    if (!(v > -1.0f)) return 0;
+    if (v >= (float)(hi + 1)) return hi;
+    int i = (int)v;
+    return i < 0 ? 0 : (i > hi ? hi : i);
+}
+
+// auxiliary.h:46-56
+__device__ __forceinline__ void get_rect(float px, float py, int radius, int gx, int gy, int& x0, int& y0, int& x1, int& y1)
+{
+    const float r = (float)radius;
+    x0 = trunc_clamped((px - r) / (float)GS_TILE, gx);
+    y0 = trunc_clamped((py - r) / (float)GS_TILE, gy);
+    x1 = trunc_clamped((px + r + (float)(GS_TILE - 1)) / (float)GS_TILE, gx);
+    y1 = trunc_clamped((py + r + (float)(GS_TILE - 1)) / (float)GS_TILE, gy);
+}
+
+__device__ __forceinline__ float saturate_f(float v) { return (v > 0.0f) ? ((v < 1.0f) ? v : 1.0f) : 0.0f; }
+
+// forward.h:39-78: min over the tile's pixel-centre rectangle of 1/2 d^T Q d; co = (A, B, C) conic.
+__device__ __forceinline__ float tile_min_power(float cA, float cB, float cC, float mx, float my, int tx, int ty)
+{
+    const float rminx = (float)(tx * GS_TILE), rminy = (float)(ty * GS_TILE);
+    const float rmaxx = (float)((tx + 1) * GS_TILE - 1), rmaxy = (float)((ty + 1) * GS_TILE - 1);
+    const float x_min_diff = rminx - mx;
+    const float x_left = (x_min_diff > 0.0f) ? 1.0f : 0.0f;
+    const float not_in_x = x_left + ((mx > rmaxx) ? 1.0f : 0.0f);
+    const float y_min_diff = rminy - my;
+    const float y_above = (y_min_diff > 0.0f) ? 1.0f : 0.0f;
+    const float not_in_y = y_above + ((my > rmaxy) ? 1.0f : 0.0f);
+    if (!((not_in_y + not_in_x) > 0.0f)) return 0.0f;
+    const float sx = rmaxx - rminx, sy = rmaxy - rminy;
+    const float px = x_left * rminx + (1.0f - x_left) * rmaxx;
+    const float py = y_above * rminy + (1.0f - y_above) * rmaxy;
+    const float dx = copysignf(sx, x_min_diff);
+    const float dy = copysignf(sy, y_min_diff);
+    const float diffx = mx - px;
+    const float diffy = my - py;
+    const float rcpx = 1.0f / (sx * sx * cA);
+    const float rcpy = 1.0f / (sy * sy * cC);
+    const float tx_ = not_in_y * saturate_f((dx * cA * diffx + dx * cB * diffy) * rcpx);
+    const float ty_ = not_in_x * saturate_f((dy * cB * diffx + dy * cC * diffy) * rcpy);
+    const float qx = px + tx_ * dx, qy = py + ty_ * dy;
+    const float ex = mx - qx, ey = my - qy;
+    return 0.5f * (cA * ex * ex + cC * ey * ey) + cB * ex * ey;
+}
+
+}  // namespace gslic
+#endif

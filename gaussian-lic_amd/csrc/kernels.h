@@ -1,0 +1,78 @@
+// kernels.h — argument blocks and host-side launchers of the rasterizer kernels (internal to libgslic_hip.so).
+#pragma once
+#include "gslic_common.h"
+
+namespace gslic {
+
+struct PreprocessArgs {
+    int P, D, M, W, H, gx, gy;
+    float focal_x, focal_y;
+    float limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier;
+    int prefiltered, no_color;
+    const float *means, *scales, *rots, *opac, *dc, *shs, *view, *proj, *campos;
+    int32_t* radii;
+    float4* rec;
+    uint32_t* tiles_touched;
+    uint32_t* flags;
+};
+int launch_preprocess(const PreprocessArgs& a, hipStream_t s);
+
+struct KeybuildArgs {
+    int P, gx, gy;
+    const int32_t* radii;
+    const float4* rec;
+    const uint32_t* offsets;
+    uint64_t* keys;
+    uint32_t* vals;
+    uint32_t* inst_gauss;
+};
+int launch_keybuild(const KeybuildArgs& a, hipStream_t s);
+int launch_finalize_lists(uint32_t R, const uint64_t* keys, const uint32_t* slots, const uint32_t* inst_gauss,
+                          uint32_t* point_list, uint2* ranges, hipStream_t s);
+int launch_bucket_count(int T, const uint2* ranges, uint32_t* bucket_count, hipStream_t s);
+
+struct RenderFwdArgs {
+    int W, H, gx, gy, no_color;
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const float4* rec;
+    const uint32_t* bucket_offsets;
+    uint32_t* bucket_to_tile;
+    float4* ckpt;
+    float4* pix_final;
+    uint32_t* max_contrib;
+    float* out_color;
+    float* out_final_T;
+};
+int launch_render_fwd(const RenderFwdArgs& a, hipStream_t s);
+
+struct RenderBwdArgs {
+    int W, H, gx, B;
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const uint32_t* inst_slot;
+    const float4* rec;
+    const uint32_t* bucket_offsets;
+    const uint32_t* bucket_to_tile;
+    const float4* ckpt;
+    const float4* pix_final;
+    const uint32_t* max_contrib;
+    const float* dL_dpix;
+    float4* partials;
+};
+int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
+
+struct PreprocessBwdArgs {
+    int P, D, M, W, H;
+    float focal_x, focal_y;
+    float limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier, lambda_erank;
+    const float *means, *scales, *rots, *dc, *shs, *view, *proj, *campos;
+    const int32_t* radii;
+    const float4* rec;
+    const uint32_t* offsets;
+    const float4* partials;
+    float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_ddc, *dL_dsh, *dL_dscale, *dL_drot;
+};
+int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
+
+}  // namespace gslic

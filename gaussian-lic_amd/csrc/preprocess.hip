@@ -1,0 +1,315 @@
+// preprocess.hip — per-Gaussian forward stage and the binning kernels.  COMPILE WITH -ffp-contract=off:
+// everything here decides integers (radii, tiles_touched, sort keys) and follows the canonical operation
+// order of oracle/gs_oracle.c bit for bit.
+//
+//   preprocess_kernel   replaces preprocessCUDA<3> fwd (forward.cu:232-319)
+//   keybuild_kernel     replaces duplicateWithKeys (rasterizer_impl.cu:59-193)
+//   finalize_lists_kernel replaces identifyTileRanges (rasterizer_impl.cu:195-218) + resolves payload -> Gaussian id
+//   bucket_count_kernel replaces perTileBucketCount (rasterizer_impl.cu:221-231), bucket = 64 entries
+//
+// Wave64 load balancing: every lane tests the first SEQ_TILES tiles of its own rectangle; rectangles with
+// more tiles are then swept one Gaussian at a time by the whole wave (64 tiles per step, ballot + mbcnt
+// compaction), selected by a 64-bit ballot.  The per-tile test is a pure function of the Gaussian, so the
+// schedule cannot change the result.
+#include "gslic_common.h"
+#include "kernels.h"
+
+namespace gslic {
+
+static constexpr int SEQ_TILES = 16;
+
+__constant__ float c_SH_C0 = 0.28209479177387814f;
+__constant__ float c_SH_C1 = 0.4886025119029199f;
+__constant__ float c_SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                                 0.5462742152960396f};
+__constant__ float c_SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                 -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+__device__ __forceinline__ float fmin_c(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float fmax_c(float a, float b) { return (b > a) ? b : a; }
+
+__global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool active = idx < a.P;
+    const float* __restrict__ V = a.view;
+    const float* __restrict__ Pm = a.proj;
+
+    float px = 0, py = 0, pz = 0, depth = 0;
+    float mx = 0, my = 0, cA = 0, cB = 0, cC = 0, op = 0, thr = 0;
+    int radius = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+
+    if (active) {
+        px = a.means[3 * idx]; py = a.means[3 * idx + 1]; pz = a.means[3 * idx + 2];
+        // in_frustum (auxiliary.h:149-171): near cull only
+        const float vz = V[2] * px + V[6] * py + V[10] * pz + V[14];
+        depth = vz;
+        if (vz <= 0.2f) {
+            active = false;
+            if (a.prefiltered) a.flags[0] = 1u;
+        }
+    }
+    if (active) {
+        const float hx = Pm[0] * px + Pm[4] * py + Pm[8] * pz + Pm[12];
+        const float hy = Pm[1] * px + Pm[5] * py + Pm[9] * pz + Pm[13];
+        const float hw = Pm[3] * px + Pm[7] * py + Pm[11] * pz + Pm[15];
+        const float pw = 1.0f / (hw + 0.0000001f);
+        const float projx = hx * pw, projy = hy * pw;
+
+        // computeCov3D (forward.cu:120-149)
+        const float qr = a.rots[4 * idx], qx = a.rots[4 * idx + 1], qy = a.rots[4 * idx + 2], qz = a.rots[4 * idx + 3];
+        float Rm[3][3];
+        Rm[0][0] = 1.f - 2.f * (qy * qy + qz * qz); Rm[0][1] = 2.f * (qx * qy - qr * qz); Rm[0][2] = 2.f * (qx * qz + qr * qy);
+        Rm[1][0] = 2.f * (qx * qy + qr * qz); Rm[1][1] = 1.f - 2.f * (qx * qx + qz * qz); Rm[1][2] = 2.f * (qy * qz - qr * qx);
+        Rm[2][0] = 2.f * (qx * qz - qr * qy); Rm[2][1] = 2.f * (qy * qz + qr * qx); Rm[2][2] = 1.f - 2.f * (qx * qx + qy * qy);
+        const float s[3] = {a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
+                            a.scale_modifier * a.scales[3 * idx + 2]};
+        float Mk[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) Mk[k][c] = s[k] * Rm[c][k];
+#define SIG(i, j) (Mk[0][i] * Mk[0][j] + Mk[1][i] * Mk[1][j] + Mk[2][i] * Mk[2][j])
+        const float c6[6] = {SIG(0, 0), SIG(0, 1), SIG(0, 2), SIG(1, 1), SIG(1, 2), SIG(2, 2)};
+#undef SIG
+        // computeCov2D (forward.cu:79-118)
+        float t0 = V[0] * px + V[4] * py + V[8] * pz + V[12];
+        float t1 = V[1] * px + V[5] * py + V[9] * pz + V[13];
+        const float t2 = V[2] * px + V[6] * py + V[10] * pz + V[14];
+        const float txtz = t0 / t2, tytz = t1 / t2;
+        t0 = fmin_c(a.limx_pos, fmax_c(a.limx_neg, txtz)) * t2;
+        t1 = fmin_c(a.limy_pos, fmax_c(a.limy_neg, tytz)) * t2;
+        const float J00 = a.focal_x / t2;
+        const float J02 = -(a.focal_x * t0) / (t2 * t2);
+        const float J11 = a.focal_y / t2;
+        const float J12 = -(a.focal_y * t1) / (t2 * t2);
+        float T0[3], T1[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float w0 = V[4 * i + 0], w1 = V[4 * i + 1], w2 = V[4 * i + 2];
+            T0[i] = w0 * J00 + w2 * J02;
+            T1[i] = w1 * J11 + w2 * J12;
+        }
+        const float Vr[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+        float A0[3], A1[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            A0[k] = T0[0] * Vr[k][0] + T0[1] * Vr[k][1] + T0[2] * Vr[k][2];
+            A1[k] = T1[0] * Vr[k][0] + T1[1] * Vr[k][1] + T1[2] * Vr[k][2];
+        }
+        const float cov0 = (A0[0] * T0[0] + A0[1] * T0[1] + A0[2] * T0[2]) + 0.3f;
+        const float cov1 = A1[0] * T0[0] + A1[1] * T0[1] + A1[2] * T0[2];
+        const float cov2 = (A1[0] * T1[0] + A1[1] * T1[1] + A1[2] * T1[2]) + 0.3f;
+
+        const float det = cov0 * cov2 - cov1 * cov1;
+        op = a.opac[idx];
+        if (det == 0.0f || op < (1.0f / 255.0f)) {
+            active = false;
+        } else {
+            const float det_inv = 1.f / det;
+            cA = cov2 * det_inv; cB = -cov1 * det_inv; cC = cov0 * det_inv;
+            const float mid = 0.5f * (cov0 + cov2);
+            const float lambda1 = mid + sqrtf(fmax_c(0.1f, mid * mid - det));
+            const float my_radius = ceilf(3.f * sqrtf(lambda1));
+            mx = (float)((((double)projx + 1.0) * (double)a.W - 1.0) * 0.5);  // ndc2Pix, double (auxiliary.h:41-44)
+            my = (float)((((double)projy + 1.0) * (double)a.H - 1.0) * 0.5);
+            radius = (my_radius >= 2147483520.f) ? 2147483520 : (int)my_radius;
+            get_rect(mx, my, radius, a.gx, a.gy, x0, y0, x1, y1);
+            thr = cull_threshold(op);
+        }
+    }
+
+    // ---- exact tile count (forward.cu:151-230) ----
+    const int rw = x1 - x0;
+    const int ntiles = active ? rw * (y1 - y0) : 0;
+    uint32_t cnt = 0;
+    {
+        int tx = x0, ty = y0;
+        const int nseq = ntiles < SEQ_TILES ? ntiles : SEQ_TILES;
+        for (int t = 0; t < nseq; t++) {
+            cnt += (tile_min_power(cA, cB, cC, mx, my, tx, ty) <= thr) ? 1u : 0u;
+            if (++tx == x1) { tx = x0; ++ty; }
+        }
+    }
+    uint64_t todo = __ballot(ntiles > SEQ_TILES);
+    while (todo) {
+        const int src = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const float sA = readlane_f(cA, src), sB = readlane_f(cB, src), sC = readlane_f(cC, src);
+        const float smx = readlane_f(mx, src), smy = readlane_f(my, src), sthr = readlane_f(thr, src);
+        const int sx0 = __builtin_amdgcn_readlane(x0, src), sy0 = __builtin_amdgcn_readlane(y0, src);
+        const int srw = __builtin_amdgcn_readlane(rw, src), sn = __builtin_amdgcn_readlane(ntiles, src);
+        uint32_t c = 0;
+        for (int base = SEQ_TILES; base < sn; base += 64) {
+            const int t = base + lane;
+            const bool in = t < sn;
+            const int ty = sy0 + t / srw, tx = sx0 + t % srw;
+            const bool ok = in && (tile_min_power(sA, sB, sC, smx, smy, tx, ty) <= sthr);
+            c += (uint32_t)__popcll(__ballot(ok));
+        }
+        if (lane == src) cnt += c;
+    }
+    const bool visible = active && cnt > 0;
+
+    if (idx < a.P) {
+        a.radii[idx] = visible ? radius : 0;
+        a.tiles_touched[idx] = visible ? cnt : 0u;
+    }
+    if (!visible) return;
+
+    // ---- SH -> RGB (forward.cu:29-77) ----
+    float rgb[3] = {0.f, 0.f, 0.f};
+    uint32_t clamp_bits = 0;
+    if (!a.no_color) {
+        float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float x = dx / len, y = dy / len, z = dz / len;
+        const float* __restrict__ d0 = a.dc + 3 * (size_t)idx;
+        const float* __restrict__ sh = a.shs ? a.shs + (size_t)3 * a.M * idx : nullptr;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            float res = c_SH_C0 * d0[ch];
+#define S(k) sh[3 * (k) + ch]
+            if (a.D > 0) {
+                res = res - c_SH_C1 * y * S(0) + c_SH_C1 * z * S(1) - c_SH_C1 * x * S(2);
+                if (a.D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    res = res + c_SH_C2[0] * xy * S(3) + c_SH_C2[1] * yz * S(4) + c_SH_C2[2] * (2.0f * zz - xx - yy) * S(5) +
+                          c_SH_C2[3] * xz * S(6) + c_SH_C2[4] * (xx - yy) * S(7);
+                    if (a.D > 2) {
+                        res = res + c_SH_C3[0] * y * (3.0f * xx - yy) * S(8) + c_SH_C3[1] * xy * z * S(9) +
+                              c_SH_C3[2] * y * (4.0f * zz - xx - yy) * S(10) +
+                              c_SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * S(11) +
+                              c_SH_C3[4] * x * (4.0f * zz - xx - yy) * S(12) + c_SH_C3[5] * z * (xx - yy) * S(13) +
+                              c_SH_C3[6] * x * (xx - 3.0f * yy) * S(14);
+                    }
+                }
+            }
+#undef S
+            res += 0.5f;
+            if (res < 0.0f) clamp_bits |= (1u << ch);
+            rgb[ch] = fmax_c(res, 0.0f);
+        }
+    }
+    float4* rec = a.rec + 3 * (size_t)idx;
+    rec[0] = make_float4(mx, my, cA, cB);
+    rec[1] = make_float4(cC, op, rgb[0], rgb[1]);
+    rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), 0.f);
+}
+
+// Emission slot u in [offsets[g-1], offsets[g]) in row-major tile order; key = tile << 32 | depth bits;
+// payload = u (so the backward can write per-instance partial gradients contiguously per Gaussian).
+__global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool active = idx < a.P && a.radii[idx] > 0;
+    float mx = 0, my = 0, cA = 0, cB = 0, cC = 0, thr = 0;
+    uint32_t dbits = 0, off = 0;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    if (active) {
+        const float4 r0 = a.rec[3 * (size_t)idx], r1 = a.rec[3 * (size_t)idx + 1], r2 = a.rec[3 * (size_t)idx + 2];
+        mx = r0.x; my = r0.y; cA = r0.z; cB = r0.w; cC = r1.x;
+        thr = cull_threshold(r1.y);
+        dbits = __float_as_uint(r2.y);
+        off = (idx == 0) ? 0u : a.offsets[idx - 1];
+        get_rect(mx, my, a.radii[idx], a.gx, a.gy, x0, y0, x1, y1);
+    }
+    const int rw = x1 - x0;
+    const int ntiles = active ? rw * (y1 - y0) : 0;
+    {
+        int tx = x0, ty = y0;
+        const int nseq = ntiles < SEQ_TILES ? ntiles : SEQ_TILES;
+        for (int t = 0; t < nseq; t++) {
+            if (tile_min_power(cA, cB, cC, mx, my, tx, ty) <= thr) {
+                a.keys[off] = ((uint64_t)(uint32_t)(ty * a.gx + tx) << 32) | dbits;
+                a.vals[off] = off;
+                a.inst_gauss[off] = (uint32_t)idx;
+                off++;
+            }
+            if (++tx == x1) { tx = x0; ++ty; }
+        }
+    }
+    uint64_t todo = __ballot(ntiles > SEQ_TILES);
+    while (todo) {
+        const int src = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const float sA = readlane_f(cA, src), sB = readlane_f(cB, src), sC = readlane_f(cC, src);
+        const float smx = readlane_f(mx, src), smy = readlane_f(my, src), sthr = readlane_f(thr, src);
+        const int sx0 = __builtin_amdgcn_readlane(x0, src), sy0 = __builtin_amdgcn_readlane(y0, src);
+        const int srw = __builtin_amdgcn_readlane(rw, src), sn = __builtin_amdgcn_readlane(ntiles, src);
+        const uint32_t sd = readlane_u(dbits, src);
+        const uint32_t sidx = (uint32_t)__builtin_amdgcn_readlane(idx, src);
+        uint32_t soff = readlane_u(off, src);
+        for (int base = SEQ_TILES; base < sn; base += 64) {
+            const int t = base + lane;
+            const bool in = t < sn;
+            const int ty = sy0 + t / srw, tx = sx0 + t % srw;
+            const bool ok = in && (tile_min_power(sA, sB, sC, smx, smy, tx, ty) <= sthr);
+            const uint64_t m = __ballot(ok);
+            if (ok) {
+                const uint32_t o = soff + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                a.keys[o] = ((uint64_t)(uint32_t)(ty * a.gx + tx) << 32) | sd;
+                a.vals[o] = o;
+                a.inst_gauss[o] = sidx;
+            }
+            soff += (uint32_t)__popcll(m);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void finalize_lists_kernel(uint32_t R, const uint64_t* __restrict__ keys,
+                                                             const uint32_t* __restrict__ slots,
+                                                             const uint32_t* __restrict__ inst_gauss,
+                                                             uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= R) return;
+    const uint32_t tile = (uint32_t)(keys[k] >> 32);
+    point_list[k] = inst_gauss[slots[k]];
+    if (k == 0) {
+        ranges[tile].x = 0;
+    } else {
+        const uint32_t prev = (uint32_t)(keys[k - 1] >> 32);
+        if (tile != prev) {
+            ranges[prev].y = k;
+            ranges[tile].x = k;
+        }
+    }
+    if (k == R - 1) ranges[tile].y = R;
+}
+
+__global__ __launch_bounds__(256) void bucket_count_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ bucket_count)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const uint2 r = ranges[t];
+    bucket_count[t] = (r.y - r.x + (GS_BUCKET - 1)) / GS_BUCKET;
+}
+
+int launch_preprocess(const PreprocessArgs& a, hipStream_t s)
+{
+    GS_LAUNCH(K_PREPROCESS, preprocess_kernel, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+    return GSLIC_OK;
+}
+int launch_keybuild(const KeybuildArgs& a, hipStream_t s)
+{
+    GS_LAUNCH(K_KEYBUILD, keybuild_kernel, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+    return GSLIC_OK;
+}
+int launch_finalize_lists(uint32_t R, const uint64_t* keys, const uint32_t* slots, const uint32_t* inst_gauss,
+                          uint32_t* point_list, uint2* ranges, hipStream_t s)
+{
+    if (R == 0) return GSLIC_OK;
+    GS_LAUNCH(K_FINALIZE_LISTS, finalize_lists_kernel, dim3((R + 255u) / 256u), dim3(256), 0, s, R, keys, slots, inst_gauss,
+              point_list, ranges);
+    return GSLIC_OK;
+}
+int launch_bucket_count(int T, const uint2* ranges, uint32_t* bucket_count, hipStream_t s)
+{
+    GS_LAUNCH(K_BUCKET_COUNT, bucket_count_kernel, dim3(div_up(T, 256)), dim3(256), 0, s, T, ranges, bucket_count);
+    return GSLIC_OK;
+}
+
+}  // namespace gslic

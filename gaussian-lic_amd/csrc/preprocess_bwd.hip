@@ -1,0 +1,272 @@
+// preprocess_bwd.hip — one fused per-Gaussian backward pass.
+//
+// preprocess_bwd_kernel replaces, in ONE launch and one read of each input,
+//   * the nine atomicAdd targets of PerGaussianRenderCUDA (backward.cu:585-596): here a contiguous segmented
+//     sum over the Gaussian's emission slots [offsets[g-1], offsets[g]) of the partials render_bwd wrote;
+//   * computeCov2DCUDA (backward.cu:138-255);
+//   * preprocessCUDA<3> bwd + computeColorFromSH bwd + computeCov3D bwd (backward.cu:27-136,257-377);
+//   * the ten torch::zeros() of RasterizeGaussiansBackwardCUDA (rasterize_points.cu:192-201): every output row
+//     is written here, zeros for invisible Gaussians, so callers may pass uninitialised memory.
+// Sigma_3D is recomputed from scale/rotation instead of being stored by the forward (24 B/Gaussian saved).
+#include "gslic_common.h"
+#include "kernels.h"
+
+namespace gslic {
+
+#define SHC0 0.28209479177387814f
+#define SHC1 0.4886025119029199f
+__constant__ float b_SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                                 0.5462742152960396f};
+__constant__ float b_SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                 -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+__global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreprocessBwdArgs a)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.P) return;
+    const bool visible = a.radii[idx] > 0;
+    const int M = a.M;
+
+    if (!visible) {
+        if (a.dL_dmean2D) { a.dL_dmean2D[3 * idx] = 0; a.dL_dmean2D[3 * idx + 1] = 0; a.dL_dmean2D[3 * idx + 2] = 0; }
+        if (a.dL_dconic) reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(0, 0, 0, 0);
+        a.dL_dopacity[idx] = 0;
+        if (a.dL_dcolor) { a.dL_dcolor[3 * idx] = 0; a.dL_dcolor[3 * idx + 1] = 0; a.dL_dcolor[3 * idx + 2] = 0; }
+        a.dL_dmean3D[3 * idx] = 0; a.dL_dmean3D[3 * idx + 1] = 0; a.dL_dmean3D[3 * idx + 2] = 0;
+        if (a.dL_dcov3D)
+            for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * idx + k] = 0;
+        a.dL_ddc[3 * idx] = 0; a.dL_ddc[3 * idx + 1] = 0; a.dL_ddc[3 * idx + 2] = 0;
+        if (a.dL_dsh)
+            for (int k = 0; k < 3 * M; k++) a.dL_dsh[(size_t)3 * M * idx + k] = 0;
+        a.dL_dscale[3 * idx] = 0; a.dL_dscale[3 * idx + 1] = 0; a.dL_dscale[3 * idx + 2] = 0;
+        reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0, 0, 0, 0);
+        return;
+    }
+
+    // ---- segmented sum of the per-instance partial gradients (ascending tile order) ----
+    float s_mx = 0, s_my = 0, s_cx = 0, s_cy = 0, s_cw = 0, s_op = 0, s_r = 0, s_g = 0, s_b = 0;
+    {
+        const uint32_t u0 = (idx == 0) ? 0u : a.offsets[idx - 1];
+        const uint32_t u1 = a.offsets[idx];
+        for (uint32_t u = u0; u < u1; u++) {
+            const float4* p = a.partials + 3 * (size_t)u;
+            const float4 p0 = p[0], p1 = p[1], p2 = p[2];
+            s_mx += p0.x; s_my += p0.y; s_cx += p0.z; s_cy += p0.w;
+            s_cw += p1.x; s_op += p1.y; s_r += p1.z; s_g += p1.w;
+            s_b += p2.x;
+        }
+    }
+    if (a.dL_dmean2D) { a.dL_dmean2D[3 * idx] = s_mx; a.dL_dmean2D[3 * idx + 1] = s_my; a.dL_dmean2D[3 * idx + 2] = 0; }
+    if (a.dL_dconic) reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(s_cx, s_cy, 0.f, s_cw);
+    a.dL_dopacity[idx] = s_op;
+    if (a.dL_dcolor) { a.dL_dcolor[3 * idx] = s_r; a.dL_dcolor[3 * idx + 1] = s_g; a.dL_dcolor[3 * idx + 2] = s_b; }
+
+    const float* __restrict__ V = a.view;
+    const float* __restrict__ Pm = a.proj;
+    const float mx3 = a.means[3 * idx], my3 = a.means[3 * idx + 1], mz3 = a.means[3 * idx + 2];
+
+    // ---- Sigma_3D from scale / rotation (forward.cu:120-149) ----
+    const float qr = a.rots[4 * idx], qx = a.rots[4 * idx + 1], qy = a.rots[4 * idx + 2], qz = a.rots[4 * idx + 3];
+    float Rm[3][3];
+    Rm[0][0] = 1.f - 2.f * (qy * qy + qz * qz); Rm[0][1] = 2.f * (qx * qy - qr * qz); Rm[0][2] = 2.f * (qx * qz + qr * qy);
+    Rm[1][0] = 2.f * (qx * qy + qr * qz); Rm[1][1] = 1.f - 2.f * (qx * qx + qz * qz); Rm[1][2] = 2.f * (qy * qz - qr * qx);
+    Rm[2][0] = 2.f * (qx * qz - qr * qy); Rm[2][1] = 2.f * (qy * qz + qr * qx); Rm[2][2] = 1.f - 2.f * (qx * qx + qy * qy);
+    const float sc[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+    const float s[3] = {a.scale_modifier * sc[0], a.scale_modifier * sc[1], a.scale_modifier * sc[2]};
+    float Mk[3][3];  // Mk[k][c] = s_k * Rm[c][k]  (= glm M[c][k])
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) Mk[k][c] = s[k] * Rm[c][k];
+#define SIG(i, j) (Mk[0][i] * Mk[0][j] + Mk[1][i] * Mk[1][j] + Mk[2][i] * Mk[2][j])
+    const float c6[6] = {SIG(0, 0), SIG(0, 1), SIG(0, 2), SIG(1, 1), SIG(1, 2), SIG(2, 2)};
+#undef SIG
+
+    // ---- computeCov2DCUDA (backward.cu:138-255) ----
+    float t0 = V[0] * mx3 + V[4] * my3 + V[8] * mz3 + V[12];
+    float t1 = V[1] * mx3 + V[5] * my3 + V[9] * mz3 + V[13];
+    const float t2 = V[2] * mx3 + V[6] * my3 + V[10] * mz3 + V[14];
+    const float txtz = t0 / t2, tytz = t1 / t2;
+    t0 = fminf(a.limx_pos, fmaxf(a.limx_neg, txtz)) * t2;
+    t1 = fminf(a.limy_pos, fmaxf(a.limy_neg, tytz)) * t2;
+    const float x_grad_mul = (txtz < a.limx_neg || txtz > a.limx_pos) ? 0.f : 1.f;
+    const float y_grad_mul = (tytz < a.limy_neg || tytz > a.limy_pos) ? 0.f : 1.f;
+    const float fx = a.focal_x, fy = a.focal_y;
+    const float J00 = fx / t2, J02 = -(fx * t0) / (t2 * t2), J11 = fy / t2, J12 = -(fy * t1) / (t2 * t2);
+    float T0[3], T1[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        T0[i] = V[4 * i + 0] * J00 + V[4 * i + 2] * J02;
+        T1[i] = V[4 * i + 1] * J11 + V[4 * i + 2] * J12;
+    }
+    const float Vr[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+    float VT0[3], VT1[3];  // Vr[k] . T0, Vr[k] . T1
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        VT0[k] = T0[0] * Vr[k][0] + T0[1] * Vr[k][1] + T0[2] * Vr[k][2];
+        VT1[k] = T1[0] * Vr[k][0] + T1[1] * Vr[k][1] + T1[2] * Vr[k][2];
+    }
+    const float ca = (VT0[0] * T0[0] + VT0[1] * T0[1] + VT0[2] * T0[2]) + 0.3f;
+    const float cb = VT1[0] * T0[0] + VT1[1] * T0[1] + VT1[2] * T0[2];
+    const float cc = (VT1[0] * T1[0] + VT1[1] * T1[1] + VT1[2] * T1[2]) + 0.3f;
+    const float denom = ca * cc - cb * cb;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    float dcv[6] = {0, 0, 0, 0, 0, 0};
+    if (denom2inv != 0) {
+        dL_da = denom2inv * (-cc * cc * s_cx + 2 * cb * cc * s_cy + (denom - ca * cc) * s_cw);
+        dL_dc = denom2inv * (-ca * ca * s_cw + 2 * ca * cb * s_cy + (denom - ca * cc) * s_cx);
+        dL_db = denom2inv * 2 * (cb * cc * s_cx - (denom + 2 * cb * cb) * s_cy + ca * cb * s_cw);
+        dcv[0] = (T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc);
+        dcv[3] = (T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc);
+        dcv[5] = (T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc);
+        dcv[1] = 2 * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2 * T1[0] * T1[1] * dL_dc;
+        dcv[2] = 2 * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2 * T1[0] * T1[2] * dL_dc;
+        dcv[4] = 2 * T0[2] * T0[1] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2 * T1[1] * T1[2] * dL_dc;
+    }
+    if (a.dL_dcov3D)
+#pragma unroll
+        for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * idx + k] = dcv[k];
+
+    const float dL_dT00 = 2 * VT0[0] * dL_da + VT1[0] * dL_db;
+    const float dL_dT01 = 2 * VT0[1] * dL_da + VT1[1] * dL_db;
+    const float dL_dT02 = 2 * VT0[2] * dL_da + VT1[2] * dL_db;
+    const float dL_dT10 = 2 * VT1[0] * dL_dc + VT0[0] * dL_db;
+    const float dL_dT11 = 2 * VT1[1] * dL_dc + VT0[1] * dL_db;
+    const float dL_dT12 = 2 * VT1[2] * dL_dc + VT0[2] * dL_db;
+    const float dL_dJ00 = V[0] * dL_dT00 + V[4] * dL_dT01 + V[8] * dL_dT02;
+    const float dL_dJ02 = V[2] * dL_dT00 + V[6] * dL_dT01 + V[10] * dL_dT02;
+    const float dL_dJ11 = V[1] * dL_dT10 + V[5] * dL_dT11 + V[9] * dL_dT12;
+    const float dL_dJ12 = V[2] * dL_dT10 + V[6] * dL_dT11 + V[10] * dL_dT12;
+    const float tz = 1.f / t2, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dL_dtx = x_grad_mul * -fx * tz2 * dL_dJ02;
+    const float dL_dty = y_grad_mul * -fy * tz2 * dL_dJ12;
+    const float dL_dtz = -fx * tz2 * dL_dJ00 - fy * tz2 * dL_dJ11 + (2 * fx * t0) * tz3 * dL_dJ02 + (2 * fy * t1) * tz3 * dL_dJ12;
+    float dmean[3];
+    dmean[0] = V[0] * dL_dtx + V[1] * dL_dty + V[2] * dL_dtz;
+    dmean[1] = V[4] * dL_dtx + V[5] * dL_dty + V[6] * dL_dtz;
+    dmean[2] = V[8] * dL_dtx + V[9] * dL_dty + V[10] * dL_dtz;
+
+    // ---- mean2D -> mean3D through the projection (backward.cu:339-350) ----
+    {
+        const float hw = Pm[3] * mx3 + Pm[7] * my3 + Pm[11] * mz3 + Pm[15];
+        const float pw = 1.0f / (hw + 0.0000001f);
+        const float mul1 = (Pm[0] * mx3 + Pm[4] * my3 + Pm[8] * mz3 + Pm[12]) * pw * pw;
+        const float mul2 = (Pm[1] * mx3 + Pm[5] * my3 + Pm[9] * mz3 + Pm[13]) * pw * pw;
+        dmean[0] += (Pm[0] * pw - Pm[3] * mul1) * s_mx + (Pm[1] * pw - Pm[3] * mul2) * s_my;
+        dmean[1] += (Pm[4] * pw - Pm[7] * mul1) * s_mx + (Pm[5] * pw - Pm[7] * mul2) * s_my;
+        dmean[2] += (Pm[8] * pw - Pm[11] * mul1) * s_mx + (Pm[9] * pw - Pm[11] * mul2) * s_my;
+    }
+
+    // ---- SH backward (backward.cu:27-136); skipped entirely when shs == NULL (backward.cu:352) ----
+    if (a.shs) {
+        const uint32_t clamp_bits = __float_as_uint(a.rec[3 * (size_t)idx + 2].z);
+        const float dox = mx3 - a.campos[0], doy = my3 - a.campos[1], doz = mz3 - a.campos[2];
+        const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+        const float x = dox / len, y = doy / len, z = doz / len;
+        const float* __restrict__ sh = a.shs + (size_t)3 * M * idx;
+        float* __restrict__ dsh = a.dL_dsh + (size_t)3 * M * idx;
+        if (a.D < 3 || M != 15)  // coefficients above the active degree keep the reference's zero-fill
+            for (int k = 0; k < 3 * M; k++) dsh[k] = 0.f;
+        const float dRGB[3] = {(clamp_bits & 1u) ? 0.f : s_r, (clamp_bits & 2u) ? 0.f : s_g, (clamp_bits & 4u) ? 0.f : s_b};
+        float ddir[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float g = dRGB[ch];
+            a.dL_ddc[3 * idx + ch] = SHC0 * g;
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#define S(k) sh[3 * (k) + ch]
+#define SET(k, coef) dsh[3 * (k) + ch] = (coef) * g
+            if (a.D > 0) {
+                SET(0, -SHC1 * y); SET(1, SHC1 * z); SET(2, -SHC1 * x);
+                ddx = -SHC1 * S(2); ddy = -SHC1 * S(0); ddz = SHC1 * S(1);
+                if (a.D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    SET(3, b_SH_C2[0] * xy); SET(4, b_SH_C2[1] * yz); SET(5, b_SH_C2[2] * (2.f * zz - xx - yy));
+                    SET(6, b_SH_C2[3] * xz); SET(7, b_SH_C2[4] * (xx - yy));
+                    ddx += b_SH_C2[0] * y * S(3) + b_SH_C2[2] * 2.f * -x * S(5) + b_SH_C2[3] * z * S(6) + b_SH_C2[4] * 2.f * x * S(7);
+                    ddy += b_SH_C2[0] * x * S(3) + b_SH_C2[1] * z * S(4) + b_SH_C2[2] * 2.f * -y * S(5) + b_SH_C2[4] * 2.f * -y * S(7);
+                    ddz += b_SH_C2[1] * y * S(4) + b_SH_C2[2] * 2.f * 2.f * z * S(5) + b_SH_C2[3] * x * S(6);
+                    if (a.D > 2) {
+                        SET(8, b_SH_C3[0] * y * (3.f * xx - yy)); SET(9, b_SH_C3[1] * xy * z);
+                        SET(10, b_SH_C3[2] * y * (4.f * zz - xx - yy));
+                        SET(11, b_SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+                        SET(12, b_SH_C3[4] * x * (4.f * zz - xx - yy)); SET(13, b_SH_C3[5] * z * (xx - yy));
+                        SET(14, b_SH_C3[6] * x * (xx - 3.f * yy));
+                        ddx += (b_SH_C3[0] * S(8) * 3.f * 2.f * xy + b_SH_C3[1] * S(9) * yz + b_SH_C3[2] * S(10) * -2.f * xy +
+                                b_SH_C3[3] * S(11) * -3.f * 2.f * xz + b_SH_C3[4] * S(12) * (-3.f * xx + 4.f * zz - yy) +
+                                b_SH_C3[5] * S(13) * 2.f * xz + b_SH_C3[6] * S(14) * 3.f * (xx - yy));
+                        ddy += (b_SH_C3[0] * S(8) * 3.f * (xx - yy) + b_SH_C3[1] * S(9) * xz +
+                                b_SH_C3[2] * S(10) * (-3.f * yy + 4.f * zz - xx) + b_SH_C3[3] * S(11) * -3.f * 2.f * yz +
+                                b_SH_C3[4] * S(12) * -2.f * xy + b_SH_C3[5] * S(13) * -2.f * yz + b_SH_C3[6] * S(14) * -3.f * 2.f * xy);
+                        ddz += (b_SH_C3[1] * S(9) * xy + b_SH_C3[2] * S(10) * 4.f * 2.f * yz +
+                                b_SH_C3[3] * S(11) * 3.f * (2.f * zz - xx - yy) + b_SH_C3[4] * S(12) * 4.f * 2.f * xz +
+                                b_SH_C3[5] * S(13) * (xx - yy));
+                    }
+                }
+            }
+#undef S
+#undef SET
+            ddir[0] += ddx * g; ddir[1] += ddy * g; ddir[2] += ddz * g;
+        }
+        // dnormvdv (auxiliary.h:119-129)
+        const float sum2 = dox * dox + doy * doy + doz * doz;
+        const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        dmean[0] += ((+sum2 - dox * dox) * ddir[0] - doy * dox * ddir[1] - doz * dox * ddir[2]) * invsum32;
+        dmean[1] += (-dox * doy * ddir[0] + (sum2 - doy * doy) * ddir[1] - doz * doy * ddir[2]) * invsum32;
+        dmean[2] += (-dox * doz * ddir[0] - doy * doz * ddir[1] + (sum2 - doz * doz) * ddir[2]) * invsum32;
+    } else {
+        a.dL_ddc[3 * idx] = 0; a.dL_ddc[3 * idx + 1] = 0; a.dL_ddc[3 * idx + 2] = 0;
+    }
+    a.dL_dmean3D[3 * idx] = dmean[0]; a.dL_dmean3D[3 * idx + 1] = dmean[1]; a.dL_dmean3D[3 * idx + 2] = dmean[2];
+
+    // ---- Sigma_3D -> scale, quaternion (backward.cu:257-310) ----
+    // dL/dSigma symmetrised (1/2 on off-diagonals); dM[c][r] = 2 * sum_k M[k][r] * dS[c][k]  (glm column-major)
+    const float dS[3][3] = {{dcv[0], 0.5f * dcv[1], 0.5f * dcv[2]}, {0.5f * dcv[1], dcv[3], 0.5f * dcv[4]}, {0.5f * dcv[2], 0.5f * dcv[4], dcv[5]}};
+    float dMt[3][3];  // dMt[c][r] = dM[r][c];  glm M[c][r] = s_r * Rm[c][r] = Mk[r][c]
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            dMt[c][r] = 2.f * Mk[c][0] * dS[r][0] + 2.f * Mk[c][1] * dS[r][1] + 2.f * Mk[c][2] * dS[r][2];
+    // dM_glm[rr][cc] = sum_k (2M)_glm[k][cc] * dS[rr][k] = sum_k 2*Mk[cc][k]*dS[rr][k]; dMt[c][r] = dM_glm[r][c] -> cc = c, rr = r. ok
+    float dscale[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) dscale[k] = Rm[0][k] * dMt[k][0] + Rm[1][k] * dMt[k][1] + Rm[2][k] * dMt[k][2];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) dMt[k][r] *= s[k];
+#define D_(c, r) dMt[c][r]
+    float4 dq;
+    dq.x = 2 * qz * (D_(0, 1) - D_(1, 0)) + 2 * qy * (D_(2, 0) - D_(0, 2)) + 2 * qx * (D_(1, 2) - D_(2, 1));
+    dq.y = 2 * qy * (D_(0, 1) + D_(1, 0)) + 2 * qz * (D_(2, 0) + D_(0, 2)) + 2 * qr * (D_(1, 2) - D_(2, 1)) - 4 * qx * (D_(2, 2) + D_(1, 1));
+    dq.z = 2 * qx * (D_(0, 1) + D_(1, 0)) + 2 * qr * (D_(2, 0) - D_(0, 2)) + 2 * qz * (D_(1, 2) + D_(2, 1)) - 4 * qy * (D_(2, 2) + D_(0, 0));
+    dq.w = 2 * qr * (D_(0, 1) - D_(1, 0)) + 2 * qx * (D_(2, 0) + D_(0, 2)) + 2 * qy * (D_(1, 2) + D_(2, 1)) - 4 * qz * (D_(1, 1) + D_(0, 0));
+#undef D_
+    if (a.lambda_erank > 0) {  // backward.cu:358-375
+        const float s1s1 = sc[0] * sc[0], s2s2 = sc[1] * sc[1], s3s3 = sc[2] * sc[2];
+        const float sum = s1s1 + s2s2 + s3s3;
+        const float q1 = sc[0] / sum, q2 = sc[1] / sum, q3 = sc[2] / sum;
+        const float erank = expf(-q1 * logf(q1) - q2 * logf(q2) - q3 * logf(q3));
+        if (-log((double)erank - 1 + 1e-5) > 0) {
+            const float f = (float)((double)erank / ((double)erank - 1 + 1e-5));
+            const float d1 = f * (-logf(q1) - 1), d2 = f * (-logf(q2) - 1), d3 = f * (-logf(q3) - 1);
+            const float le = a.lambda_erank * 2.f / (sum * sum);
+            dscale[0] += le * sc[0] * (d1 * (s2s2 + s3s3) - d2 * s2s2 - d3 * s3s3);
+            dscale[1] += le * sc[1] * (-d1 * s1s1 + d2 * (s1s1 + s3s3) - d3 * s3s3);
+            dscale[2] += le * sc[2] * (-d1 * s1s1 - d2 * s2s2 + d3 * (s1s1 + s2s2));
+        }
+        dscale[2] += 1;
+    }
+    a.dL_dscale[3 * idx] = dscale[0]; a.dL_dscale[3 * idx + 1] = dscale[1]; a.dL_dscale[3 * idx + 2] = dscale[2];
+    reinterpret_cast<float4*>(a.dL_drot)[idx] = dq;
+}
+
+int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
+{
+    GS_LAUNCH(K_PREPROCESS_BWD, preprocess_bwd_kernel, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+    return GSLIC_OK;
+}
+
+}  // namespace gslic

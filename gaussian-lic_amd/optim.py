@@ -1,0 +1,70 @@
+"""SparseGaussianAdam — mirrors src/optim_utils.h:26-142 and adamUpdate (rasterize_points.cu:248-273).
+
+step() applies the visibility-masked, bias-correction-free Adam of adam.cu:26-37 to every parameter group in
+ONE kernel launch (gslic_adam_update_groups) and without the per-group grad.clone() of optim_utils.h:130.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def adam_update(param, param_grad, exp_avg, exp_avg_sq, visible, lr, b1, b2, eps, N, M):
+    """adamUpdate(param, grad, exp_avg, exp_avg_sq, visible, lr, b1, b2, eps, N, M) — in place."""
+    for t in (param, param_grad, exp_avg, exp_avg_sq):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    vis = visible.contiguous()
+    assert vis.dtype in (torch.bool, torch.uint8)
+    p = _lib.ptr
+    _lib.check(_lib.lib().gslic_adam_update(p(param), p(param_grad), p(exp_avg), p(exp_avg_sq), p(vis), float(lr), float(b1),
+                                            float(b2), float(eps), int(N), int(M), _lib.current_stream_ptr()))
+
+
+class SparseGaussianAdam:
+    """Six single-tensor parameter groups with their own learning rates (gaussian.cpp:399-418); state keyed by
+    group index; `step` counter kept but unused, like the reference (optim_utils.h:135)."""
+
+    def __init__(self, params, lrs, eps=1e-15, betas=(0.9, 0.999)):
+        self.params = list(params)
+        self.lrs = [float(x) for x in lrs]
+        self.eps, self.betas = float(eps), betas
+        self.state = [None] * len(self.params)
+        self.visibility, self.N = None, 0
+
+    def set_visibility_and_N(self, visibility, N):
+        self.visibility, self.N = visibility, int(N)
+
+    def _ensure_state(self, i):
+        if self.state[i] is None:
+            p = self.params[i]
+            self.state[i] = dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
+        return self.state[i]
+
+    def step(self, grads=None):
+        """grads: optional list of gradient tensors (defaults to each param's .grad)."""
+        groups, keep = [], []
+        for i, prm in enumerate(self.params):
+            g = grads[i] if grads is not None else prm.grad
+            if g is None:
+                continue
+            st = self._ensure_state(i)
+            g = g.contiguous()
+            keep.append(g)
+            M = prm.numel() // self.N
+            groups.append(_lib.AdamGroup(prm.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                         self.lrs[i], M))
+            st["step"] += 1
+        if not groups:
+            return
+        arr = (_lib.AdamGroup * len(groups))(*groups)
+        vis = self.visibility.contiguous()
+        _lib.check(_lib.lib().gslic_adam_update_groups(arr, len(groups), _lib.ptr(vis), self.betas[0], self.betas[1], self.eps,
+                                                       self.N, _lib.current_stream_ptr()))
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()

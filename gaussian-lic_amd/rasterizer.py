@@ -1,0 +1,207 @@
+"""Host-side mirror of the reference's rasterizer operator interface on top of the C-ABI.
+
+Same names and argument meaning as the reference's L2/L3 layers:
+  rasterize_gaussians / rasterize_gaussians_backward  <- RasterizeGaussiansCUDA / ...BackwardCUDA
+                                                         (src/rasterizer/rasterize_points.h:25-82)
+  GaussianRasterizationSettings, GaussianRasterizerFunction, GaussianRasterizer
+                                                      <- src/rasterizer/rasterizer.h:27-114, rasterizer.cpp:21-216
+  render                                              <- src/rasterizer/renderer.cpp:21-88
+torch is used for device memory, streams and autograd plumbing only; all arithmetic runs in libgslic_hip.so.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class GaussianRasterizationSettings:
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    limx_neg: float
+    limx_pos: float
+    limy_neg: float
+    limy_pos: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor   # [4,4] world_view_transform_ (stored transposed, camera.h:86)
+    projmatrix: torch.Tensor   # [4,4] full_proj_transform_
+    sh_degree: int
+    campos: torch.Tensor       # [3]
+    prefiltered: bool = False
+    debug: bool = False
+    no_color: bool = False
+    lambda_erank: float = 0.0
+
+
+def _params(P, D, M, H, W, tanfovx, tanfovy, lxn, lxp, lyn, lyp, scale_modifier, prefiltered, debug, no_color):
+    return _lib.RasterParams(int(P), int(D), int(M), int(W), int(H), float(tanfovx), float(tanfovy), float(lxn), float(lxp),
+                             float(lyn), float(lyp), float(scale_modifier), int(bool(prefiltered)), int(bool(debug)),
+                             int(bool(no_color)))
+
+
+def _f32c(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                        projmatrix, tan_fovx, tan_fovy, image_height, image_width, limx_neg, limx_pos, limy_neg, limy_pos,
+                        dc, sh, degree, campos, prefiltered, debug, no_color=False):
+    """RasterizeGaussiansCUDA (rasterize_points.cu:50-149): returns
+    (num_rendered, num_buckets, out_color, out_final_T, radii, geomBuffer, binningBuffer, imgBuffer, sampleBuffer)."""
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise ValueError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:77-80
+    L = _lib.lib()
+    dev = means3D.device
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    M = sh.size(1) if sh is not None and sh.size(0) != 0 else 0
+    out_color = torch.zeros(3, H, W, dtype=torch.float32, device=dev) if (P == 0 or no_color) else \
+        torch.empty(3, H, W, dtype=torch.float32, device=dev)
+    out_final_T = torch.zeros(H, W, dtype=torch.float32, device=dev) if P == 0 else torch.empty(H, W, dtype=torch.float32, device=dev)
+    radii = torch.empty(P, dtype=torch.int32, device=dev)
+    allocs = [_lib.TensorAllocator(dev) for _ in range(4)]  # geom, binning, img, sample
+    R, B = ctypes.c_int32(0), ctypes.c_int32(0)
+    if P != 0:
+        means3D, dc, opacity, scales, rotations = map(_f32c, (means3D, dc, opacity, scales, rotations))
+        sh_c = _f32c(sh) if M > 0 else None
+        viewmatrix, projmatrix, campos, background = map(_f32c, (viewmatrix, projmatrix, campos, background))
+        prm = _params(P, degree, M, H, W, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier,
+                      prefiltered, debug, no_color)
+        p = _lib.ptr
+        _lib.check(L.gslic_rasterize_forward(
+            ctypes.byref(prm), allocs[0].cb, None, allocs[1].cb, None, allocs[2].cb, None, allocs[3].cb, None,
+            p(background), p(means3D), p(dc), p(sh_c), p(colors), p(opacity), p(scales), p(rotations), p(cov3D_precomp),
+            p(viewmatrix), p(projmatrix), p(campos), p(out_color), p(out_final_T), p(radii),
+            ctypes.byref(R), ctypes.byref(B), _lib.current_stream_ptr()))
+    return (R.value, B.value, out_color, out_final_T, radii, allocs[0].tensor, allocs[1].tensor, allocs[2].tensor, allocs[3].tensor)
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                                 projmatrix, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, dL_dout_color, dc, sh,
+                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, B, sampleBuffer, lambda_erank, debug):
+    """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:151-246): returns (dL_dmeans2D, dL_dcolors_precomp,
+    dL_dopacities, dL_dmeans3D, dL_dcov3Ds_precomp, dL_ddc, dL_dsh, dL_dscales, dL_drotations)."""
+    L = _lib.lib()
+    dev = means3D.device
+    P, H, W = means3D.size(0), dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if sh is not None and sh.size(0) != 0 else 0
+    mk = (lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)) if P != 0 else \
+        (lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev))
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors = mk(P, 3), mk(P, 3), mk(P, 3)
+    dL_dconic, dL_dopacities, dL_dcov3D = mk(P, 2, 2), mk(P, 1), mk(P, 6)
+    dL_ddc, dL_dsh, dL_dscales, dL_drotations = mk(P, 1, 3), mk(P, M, 3), mk(P, 3), mk(P, 4)
+    if P != 0:
+        means3D, dc, scales, rotations, dL = map(_f32c, (means3D, dc, scales, rotations, dL_dout_color))
+        sh_c = _f32c(sh) if M > 0 else None
+        viewmatrix, projmatrix, campos, background = map(_f32c, (viewmatrix, projmatrix, campos, background))
+        prm = _params(P, degree, M, H, W, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier,
+                      False, debug, False)
+        p = _lib.ptr
+        _lib.check(L.gslic_rasterize_backward(
+            ctypes.byref(prm), int(R), int(B), p(background), p(means3D), p(dc), p(sh_c), p(colors), p(scales), p(rotations),
+            p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos), p(radii.contiguous()),
+            ctypes.c_void_p(geomBuffer.data_ptr()), ctypes.c_void_p(binningBuffer.data_ptr()),
+            ctypes.c_void_p(imageBuffer.data_ptr()), ctypes.c_void_p(sampleBuffer.data_ptr()), p(dL),
+            p(dL_dmeans2D), p(dL_dconic), p(dL_dopacities), p(dL_dcolors), p(dL_dmeans3D), p(dL_dcov3D), p(dL_ddc),
+            p(dL_dsh), p(dL_dscales), p(dL_drotations), float(lambda_erank), _lib.current_stream_ptr()))
+    return (dL_dmeans2D, dL_dcolors, dL_dopacities, dL_dmeans3D, dL_dcov3D, dL_ddc, dL_dsh, dL_dscales, dL_drotations)
+
+
+class GaussianRasterizerFunction(torch.autograd.Function):
+    """rasterizer.cpp:21-183.  forward returns (color, radii, final_T); only d/dcolor flows back."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs):
+        (R, B, color, final_T, radii, geom, binning, img, sample) = rasterize_gaussians(
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, rs.limx_neg, rs.limx_pos, rs.limy_neg,
+            rs.limy_pos, dc, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, rs.no_color)
+        ctx.rs, ctx.R, ctx.B = rs, R, B
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, dc, sh, geom, binning, img, sample)
+        ctx.mark_non_differentiable(radii, final_T)
+        return color, radii, final_T
+
+    @staticmethod
+    def backward(ctx, dL_dcolor, _dL_dradii, _dL_dfinal_T):
+        rs = ctx.rs
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, dc, sh, geom, binning, img, sample = ctx.saved_tensors
+        (dL_dmeans2D, dL_dcolors_precomp, dL_dopacities, dL_dmeans3D, dL_dcov3Ds_precomp, dL_ddc, dL_dsh, dL_dscales,
+         dL_drotations) = rasterize_gaussians_backward(
+            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.limx_neg, rs.limx_pos, rs.limy_neg, rs.limy_pos, dL_dcolor, dc, sh,
+            rs.sh_degree, rs.campos, geom, ctx.R, binning, img, ctx.B, sample, rs.lambda_erank, False)
+        return (dL_dmeans3D, dL_dmeans2D, dL_ddc, dL_dsh, None, dL_dopacities, dL_dscales, dL_drotations, None, None)
+
+
+class GaussianRasterizer(torch.nn.Module):
+    """rasterizer.cpp:185-216."""
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, dc, shs, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+        dev = means3D.device
+        colors_precomp = torch.empty(0, device=dev)   # rasterizer.cpp:200-201: always empty
+        cov3D_precomp = torch.empty(0, device=dev)
+        return GaussianRasterizerFunction.apply(means3D, means2D, dc, shs, colors_precomp, opacities, scales, rotations,
+                                                cov3D_precomp, self.raster_settings)
+
+
+def render(camera, model, bg_color, no_color=False, scaling_modifier=1.0):
+    """renderer.cpp:21-88.  `camera` = gaussian_lic_amd.camera.Camera with device tensors attached via to_device();
+    `model` exposes get_xyz/get_opacity/get_scaling/get_rotation/get_features_dc/get_features_rest, sh_degree,
+    lambda_erank.  Returns (image, final_T, screenspace_points, visible, radii)."""
+    xyz = model.get_xyz()
+    screenspace_points = torch.zeros_like(xyz, requires_grad=True)
+    rs = GaussianRasterizationSettings(
+        camera.image_height, camera.image_width, float(camera.tanfovx), float(camera.tanfovy), float(camera.limx_neg),
+        float(camera.limx_pos), float(camera.limy_neg), float(camera.limy_pos), bg_color, scaling_modifier,
+        camera.d_world_view_transform, camera.d_full_proj_transform, model.sh_degree, camera.d_camera_center, False, False,
+        no_color, model.lambda_erank)
+    rasterizer = GaussianRasterizer(rs)
+    image, radii, final_T = rasterizer(xyz, screenspace_points, model.get_opacity(), model.get_features_dc(),
+                                       model.get_features_rest(), None, model.get_scaling(), model.get_rotation(), None)
+    return image, final_T, screenspace_points, radii > 0, radii
+
+
+def debug_export(settings, P, M, R, B, geom, binning, img, sample, what=("tiles_touched", "point_list", "ranges")):
+    """Test-only: copy stage boundaries out of the opaque scratch buffers (gslic_debug_export)."""
+    L = _lib.lib()
+    rs = settings
+    dev = geom.device
+    H, W = rs.image_height, rs.image_width
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    prm = _params(P, rs.sh_degree, M, H, W, rs.tanfovx, rs.tanfovy, rs.limx_neg, rs.limx_pos, rs.limy_neg, rs.limy_pos,
+                  rs.scale_modifier, False, False, rs.no_color)
+    out = {}
+    mk = dict(
+        tiles_touched=lambda: torch.zeros(P, dtype=torch.int32, device=dev),
+        means2D=lambda: torch.zeros(P, 2, device=dev), depths=lambda: torch.zeros(P, device=dev),
+        conic_opacity=lambda: torch.zeros(P, 4, device=dev), rgb=lambda: torch.zeros(P, 3, device=dev),
+        sorted_keys=lambda: torch.zeros(max(R, 1), dtype=torch.int64, device=dev),
+        point_list=lambda: torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
+        ranges=lambda: torch.zeros(T, 2, dtype=torch.int32, device=dev),
+        n_contrib=lambda: torch.zeros(H, W, dtype=torch.int32, device=dev),
+        max_contrib=lambda: torch.zeros(T, dtype=torch.int32, device=dev))
+    order = ["tiles_touched", "means2D", "depths", "conic_opacity", "rgb", "sorted_keys", "point_list", "ranges", "n_contrib",
+             "max_contrib"]
+    args = []
+    for k in order:
+        if k in what:
+            out[k] = mk[k]()
+            args.append(ctypes.c_void_p(out[k].data_ptr()))
+        else:
+            args.append(None)
+    bp = lambda t: ctypes.c_void_p(t.data_ptr()) if t.numel() else None
+    _lib.check(L.gslic_debug_export(ctypes.byref(prm), int(R), int(B), bp(geom), bp(binning), bp(img), bp(sample), *args,
+                                    _lib.current_stream_ptr()))
+    torch.cuda.synchronize()
+    for k in ("sorted_keys", "point_list"):
+        if k in out:
+            out[k] = out[k][:R]
+    return out
