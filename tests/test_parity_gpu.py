@@ -56,7 +56,11 @@ def test_forward_backward_parity(oracle32, kind, P, W, H, deg, seed):
     gref = oracle32.backward(sc, camd, ref, dL.numpy())
     ggot = hip_backward(got, dL)
     for k in ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_ddc", "dL_dsh", "dL_dscale", "dL_drot"):
-        e = rel_err(ggot[k].reshape(-1), gref[k].reshape(-1))
+        a_, b_ = ggot[k].reshape(-1).astype(np.float64), gref[k].reshape(-1).astype(np.float64)
+        scale = np.abs(b_).max() if b_.size else 0.0
+        if k == "dL_drot":  # exactly 0 for isotropic Gaussians: measure against the magnitude of the cancelling terms
+            scale = max(scale, float(np.abs(gref["dL_dscale"]).max() * sc["scales"].max()))
+        e = float(np.abs(a_ - b_).max() / max(scale, 1e-30)) if b_.size else 0.0
         assert e < TOL, f"{k}: rel err {e:.3e}"
         assert np.all(ggot[k].reshape(P, -1)[~vis] == 0), f"{k}: invisible rows must be exact zeros"
 
