@@ -105,14 +105,32 @@ class TensorAllocator:
         self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
         self.cb = ALLOC_FN(self._alloc)
 
+    GRANULE = 32 << 20  # large requests are rounded up so that step-to-step drift of R / B (the Gaussians move)
+                        # keeps hitting the same cached block instead of forcing a fresh hipMalloc
+
     def _alloc(self, _ctx, nbytes):
-        self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        n = int(nbytes)
+        if n > (1 << 20):
+            n = (n + self.GRANULE - 1) // self.GRANULE * self.GRANULE
+        self.tensor = torch.empty(n, dtype=torch.uint8, device=self.device)
         return self.tensor.data_ptr()
 
 
 # ------------------------------------------------------------------------------------------- profiling
-def profile_enable(on=True):
-    check(lib().gslic_profile_enable(1 if on else 0))
+def profile_enable(on=True, only=None):
+    """on=False: off.  only=None: time every kernel; only=[names]: time just those kernels."""
+    L = lib()
+    if not on:
+        check(L.gslic_profile_enable(0))
+        return
+    if only is None:
+        check(L.gslic_profile_enable(1))
+        return
+    names = [L.gslic_profile_kernel_name(i).decode() for i in range(L.gslic_profile_num_kernels())]
+    mask = 0
+    for n in only:
+        mask |= 1 << names.index(n)
+    check(L.gslic_profile_enable(mask if mask not in (0, 1) else (mask | (1 << 30))))
 
 
 def profile_reset():

@@ -51,6 +51,14 @@ class Camera:
         self.tanfovx = np.float32(np.tan(np.float32(self.FoVx * np.float32(0.5))))
         self.tanfovy = np.float32(np.tan(np.float32(self.FoVy * np.float32(0.5))))
 
+    def to_device(self, device):
+        """Attach device copies of the three tensors the rasterizer reads (camera.h:86,109,60-61 keep them on CUDA)."""
+        import torch
+        self.d_world_view_transform = torch.from_numpy(self.world_view_transform).to(device)
+        self.d_full_proj_transform = torch.from_numpy(self.full_proj_transform).to(device)
+        self.d_camera_center = torch.from_numpy(self.camera_center).to(device)
+        return self
+
     def as_dict(self):
         """Plain dict consumed by the oracle front-end and the HIP front-end alike."""
         return dict(W=self.image_width, H=self.image_height,

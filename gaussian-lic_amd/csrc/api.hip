@@ -24,6 +24,8 @@ int set_error(int code, const char* fmt, ...)
 
 // ---------------------------------------------------------------------------------------------------------
 bool g_prof_on = false;
+static uint32_t g_prof_mask = 0xffffffffu;
+static bool g_prof_cur_on = false;
 static const char* const k_names[K_COUNT] = {
     "preprocess", "scan_reduce", "scan_spine", "scan_apply", "keybuild", "sort_hist", "sort_scatter", "finalize_lists",
     "bucket_count", "render_fwd", "render_bwd", "preprocess_bwd", "adam", "ssim_fwd", "ssim_bwd", "knn_minmax", "knn_morton",
@@ -44,12 +46,14 @@ static hipEvent_t ev_get()
 }
 void prof_begin(int id, hipStream_t s)
 {
-    (void)id;
+    g_prof_cur_on = (g_prof_mask >> id) & 1u;
+    if (!g_prof_cur_on) return;
     g_cur = ev_get();
     (void)hipEventRecord(g_cur, s);
 }
 void prof_end(int id, hipStream_t s)
 {
+    if (!g_prof_cur_on) return;
     hipEvent_t b = ev_get();
     (void)hipEventRecord(b, s);
     g_pending.push_back({id, g_cur, b});
@@ -376,7 +380,12 @@ int gslic_knn_mean_dist2(int32_t P, const float* points, float* mean_dists, gsli
 }
 
 // ---------------------------------------------------------------------------------------------------------
-int gslic_profile_enable(int32_t on) { g_prof_on = on != 0; return GSLIC_OK; }
+int gslic_profile_enable(int32_t on)
+{
+    g_prof_on = on != 0;
+    g_prof_mask = (on == 1 || on == -1) ? 0xffffffffu : (uint32_t)on;  // 1 / -1: every kernel; otherwise bit i = kernel id i
+    return GSLIC_OK;
+}
 int gslic_profile_reset(void)
 {
     GS_HIP(hipDeviceSynchronize());

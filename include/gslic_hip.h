@@ -224,7 +224,7 @@ size_t gslic_sample_bytes(int32_t B);
  * hipEvent pair recorded on the launch stream; gslic_profile_collect synchronises the device and adds the
  * elapsed times to per-kernel totals.  Kernel ids are stable and named by gslic_profile_kernel_name. */
 #define GSLIC_PROFILE_MAX_KERNELS 48
-int gslic_profile_enable(int32_t on);
+int gslic_profile_enable(int32_t on); /* 0 = off, 1 or -1 = every kernel, otherwise bit i selects kernel id i (ids < 31) */
 int gslic_profile_reset(void);
 int gslic_profile_collect(void);
 int gslic_profile_num_kernels(void);
