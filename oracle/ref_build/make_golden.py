@@ -1,0 +1,75 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own kernels (oracle/_ref/libref_hip.so, built by
+build_ref.py from /root/reference) on the MI355X over seeded synthetic scenes.  Run on the GPU box:
+
+    python oracle/ref_build/make_golden.py gpurun_out/golden        # then copy the .npz into tests/golden/
+
+The exact fp32 inputs (activated Gaussians, camera matrices, dL/dimage) are stored next to the outputs: the synthetic
+generator uses vectorised exp/log/sigmoid whose last ulp differs between CPUs, so seeds alone do not reproduce them.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CASES = [  # name, kind, P, W, H, deg, seed, lambda_erank
+    # P is a multiple of 256 on purpose: with a partial last block the reference's duplicateWithKeys lets the
+    # out-of-range threads (clamped to idx = P-1, rasterizer_impl.cu:73-78) race pad keys over the last Gaussian's slots.
+    ("random_1536_160x120_d3", "random", 1536, 160, 120, 3, 11, 0.0),
+    ("lidar_1536_160x120_d3", "lidar", 1536, 160, 120, 3, 12, 0.0),
+    ("random_1536_70x50_d1", "random", 1536, 70, 50, 1, 13, 0.0),
+    ("random_1024_96x64_d0", "random", 1024, 96, 64, 0, 14, 0.0),
+    ("random_1024_128x96_d3_erank", "random", 1024, 128, 96, 3, 15, 0.01),
+]
+
+
+def input_digest(sc, cam):
+    h = hashlib.sha256()
+    for k in ("means", "scales", "rots", "opac", "dc", "shs"):
+        h.update(np.ascontiguousarray(sc[k], np.float32).tobytes())
+    for k in ("view", "proj", "campos"):
+        h.update(np.ascontiguousarray(cam[k], np.float32).tobytes())
+    return h.hexdigest()
+
+
+def main(outdir):
+    from conftest import make_scene
+    from gaussian_lic_amd.synthetic import pixel_grad
+    from oracle.ref_build.refkernels import RefKernels
+    os.makedirs(outdir, exist_ok=True)
+    rk = RefKernels()
+    for name, kind, P, W, H, deg, seed, le in CASES:
+        raw, sc, camd, cam = make_scene(kind, P, W, H, deg, seed)
+        dL = pixel_grad(H, W, seed=1).numpy()
+        out = rk.run(sc, camd, dL, lambda_erank=le)
+        nc = rk.run(sc, camd, None, no_color=True)
+        keep = {k: v for k, v in out.items() if isinstance(v, np.ndarray)}
+        keep["final_T_no_color"] = nc["final_T"]
+        for k in ("means", "scales", "rots", "opac", "dc", "shs"):
+            keep["in_" + k] = np.ascontiguousarray(sc[k], np.float32)
+        for k in ("view", "proj", "campos"):
+            keep["cam_" + k] = np.ascontiguousarray(camd[k], np.float32)
+        keep["cam_scalars"] = np.array([camd[k] for k in ("tanfovx", "tanfovy", "limx_neg", "limx_pos", "limy_neg", "limy_pos")], np.float64)
+        keep["in_dL_dpix"] = dL
+        meta = dict(kind=kind, P=P, W=W, H=H, deg=deg, seed=seed, lambda_erank=le, R=out["R"], B32=out["B"],
+                    R_no_color=nc["R"], B_no_color=nc["B"], digest=input_digest(sc, camd))
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), meta=np.array(repr(meta)), **keep)
+        print(name, "R", out["R"], "B32", out["B"], "visible", int((out["radii"] > 0).sum()), flush=True)
+    # Adam golden (adam.cu through ADAM::adamUpdate)
+    rng = np.random.default_rng(0)
+    N, M = 500, 45
+    p, g = rng.standard_normal((N, M)).astype(np.float32), rng.standard_normal((N, M)).astype(np.float32)
+    m, v = (0.1 * rng.standard_normal((N, M))).astype(np.float32), (0.01 * rng.random((N, M))).astype(np.float32)
+    vis = rng.random(N) < 0.6
+    p1, m1, v1 = p.copy(), m.copy(), v.copy()
+    rk.adam(p1, g, m1, v1, vis, 2.5e-3)
+    np.savez_compressed(os.path.join(outdir, "adam_500x45.npz"), p=p, g=g, m=m, v=v, vis=vis, p1=p1, m1=m1, v1=v1, lr=np.float32(2.5e-3))
+    print("adam ok")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "golden"))

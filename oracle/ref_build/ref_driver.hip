@@ -1,0 +1,146 @@
+// ref_driver.hip — C entry points around the REFERENCE's own CudaRasterizer::Rasterizer::forward/backward and
+// ADAM::adamUpdate, compiled from /root/reference sources (unmodified) through oracle/ref_build/shim.
+// Test infrastructure: produces golden vectors on the MI355X (tests/golden/), never shipped, never linked by
+// the product.  All pointer arguments are HOST arrays; the driver owns the device copies.
+#include "rasterizer_impl.h"  // reference: src/rasterizer/cuda_rasterizer/rasterizer_impl.h (state layouts)
+#include "adam.h"
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "ref_driver: %s -> %s\n", #x, hipGetErrorString(e_)); return -1; } } while (0)
+
+namespace {
+struct Ctx {
+    std::vector<void*> allocs;
+    int P = 0, D = 0, M = 0, W = 0, H = 0, R = 0, B = 0;
+    float tanfovx, tanfovy, lxn, lxp, lyn, lyp;
+    float *means = nullptr, *dc = nullptr, *shs = nullptr, *opac = nullptr, *scales = nullptr, *rots = nullptr;
+    float *view = nullptr, *proj = nullptr, *campos = nullptr, *bg = nullptr;
+    float *out_color = nullptr, *out_T = nullptr;
+    int* radii = nullptr;
+    char *geom = nullptr, *binning = nullptr, *img = nullptr, *sample = nullptr;
+    template <typename T> T* dev(const T* host, size_t n)
+    {
+        void* p = nullptr;
+        if (hipMalloc(&p, n * sizeof(T) + 256) != hipSuccess) return nullptr;
+        allocs.push_back(p);
+        if (host && n) hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice);
+        else if (n) hipMemset(p, 0, n * sizeof(T));
+        return (T*)p;
+    }
+    char* scratch(size_t n)
+    {
+        void* p = nullptr;
+        const size_t pad = (size_t)4 << 20;  // the reference's backward reads past the last tile/bucket
+        if (hipMalloc(&p, n + pad) != hipSuccess) return nullptr;
+        hipMemset(p, 0, n + pad);
+        allocs.push_back(p);
+        return (char*)p;
+    }
+    ~Ctx() { for (void* p : allocs) hipFree(p); }
+};
+}  // namespace
+
+extern "C" {
+
+void* ref_create() { return new Ctx(); }
+void ref_destroy(void* c) { delete (Ctx*)c; }
+
+int ref_forward(void* vc, int P, int D, int M, int W, int H, const float* means, const float* dc, const float* shs,
+                const float* opac, const float* scales, const float* rots, const float* view, const float* proj,
+                const float* campos, float tanfovx, float tanfovy, float lxn, float lxp, float lyn, float lyp, int no_color,
+                float* out_color, float* out_T, int* radii, int* R_out, int* B_out)
+{
+    Ctx& c = *(Ctx*)vc;
+    c.P = P; c.D = D; c.M = M; c.W = W; c.H = H;
+    c.tanfovx = tanfovx; c.tanfovy = tanfovy; c.lxn = lxn; c.lxp = lxp; c.lyn = lyn; c.lyp = lyp;
+    c.means = c.dev(means, (size_t)3 * P); c.dc = c.dev(dc, (size_t)3 * P);
+    c.shs = M > 0 ? c.dev(shs, (size_t)3 * M * P) : nullptr;
+    c.opac = c.dev(opac, P); c.scales = c.dev(scales, (size_t)3 * P); c.rots = c.dev(rots, (size_t)4 * P);
+    c.view = c.dev(view, 16); c.proj = c.dev(proj, 16); c.campos = c.dev(campos, 3);
+    c.bg = c.dev<float>(nullptr, 3);
+    c.out_color = c.dev<float>(nullptr, (size_t)3 * W * H + (size_t)W * 64);
+    c.out_T = c.dev<float>(nullptr, (size_t)W * H);
+    c.radii = c.dev<int>(nullptr, P);
+    std::function<char*(size_t)> fg = [&](size_t n) { return c.geom = c.scratch(n); };
+    std::function<char*(size_t)> fb = [&](size_t n) { return c.binning = c.scratch(n); };
+    std::function<char*(size_t)> fi = [&](size_t n) { return c.img = c.scratch(n); };
+    std::function<char*(size_t)> fs = [&](size_t n) { return c.sample = c.scratch(n); };
+    auto t = CudaRasterizer::Rasterizer::forward(fg, fb, fi, fs, P, D, M, c.bg, W, H, c.means, c.dc, c.shs, nullptr, c.opac, c.scales,
+                                                 1.0f, c.rots, nullptr, c.view, c.proj, c.campos, tanfovx, tanfovy, lxn, lxp, lyn, lyp,
+                                                 false, c.out_color, c.out_T, c.radii, false, no_color != 0);
+    HCHK(hipDeviceSynchronize());
+    c.R = std::get<0>(t); c.B = std::get<1>(t);
+    *R_out = c.R; *B_out = c.B;
+    HCHK(hipMemcpy(out_color, c.out_color, sizeof(float) * 3 * W * H, hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(out_T, c.out_T, sizeof(float) * W * H, hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(radii, c.radii, sizeof(int) * P, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// stage boundaries out of the reference's own state structs (rasterizer_impl.cu:233-291)
+int ref_export(void* vc, unsigned* tiles_touched, float* means2D, float* depths, float* conic_opacity, float* rgb,
+               unsigned char* clamped, unsigned long long* keys, unsigned* point_list, unsigned* ranges, unsigned* n_contrib,
+               unsigned* max_contrib)
+{
+    Ctx& c = *(Ctx*)vc;
+    const int T = ((c.W + 15) / 16) * ((c.H + 15) / 16);
+    char* g = c.geom; char* b = c.binning; char* i = c.img;
+    auto gs = CudaRasterizer::GeometryState::fromChunk(g, c.P);
+    auto is = CudaRasterizer::ImageState::fromChunk(i, (size_t)c.W * c.H, T);
+    HCHK(hipMemcpy(tiles_touched, gs.tiles_touched, sizeof(unsigned) * c.P, hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(means2D, gs.means2D, sizeof(float) * 2 * c.P, hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(depths, gs.depths, sizeof(float) * c.P, hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(conic_opacity, gs.conic_opacity, sizeof(float) * 4 * c.P, hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(rgb, gs.rgb, sizeof(float) * 3 * c.P, hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(clamped, gs.clamped, 3 * (size_t)c.P, hipMemcpyDeviceToHost));
+    if (c.R > 0) {
+        auto bs = CudaRasterizer::BinningState::fromChunk(b, c.R);
+        HCHK(hipMemcpy(keys, bs.point_list_keys, sizeof(unsigned long long) * c.R, hipMemcpyDeviceToHost));
+        HCHK(hipMemcpy(point_list, bs.point_list, sizeof(unsigned) * c.R, hipMemcpyDeviceToHost));
+    }
+    HCHK(hipMemcpy(ranges, is.ranges, sizeof(unsigned) * 2 * T, hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(n_contrib, is.n_contrib, sizeof(unsigned) * c.W * c.H, hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(max_contrib, is.max_contrib, sizeof(unsigned) * T, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ref_backward(void* vc, const float* dL_dpix, float lambda_erank, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                 float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_ddc, float* dL_dsh, float* dL_dscale, float* dL_drot)
+{
+    Ctx& c = *(Ctx*)vc;
+    const size_t P = c.P;
+    float* d_pix = c.dev(dL_dpix, (size_t)3 * c.W * c.H + (size_t)c.W * 64);
+    float *g2 = c.dev<float>(nullptr, 3 * P), *gc = c.dev<float>(nullptr, 4 * P), *go = c.dev<float>(nullptr, P), *gcol = c.dev<float>(nullptr, 3 * P);
+    float *g3 = c.dev<float>(nullptr, 3 * P), *gcov = c.dev<float>(nullptr, 6 * P), *gdc = c.dev<float>(nullptr, 3 * P);
+    float *gsh = c.dev<float>(nullptr, 3 * (size_t)c.M * P + 4), *gs = c.dev<float>(nullptr, 3 * P), *gr = c.dev<float>(nullptr, 4 * P);
+    CudaRasterizer::Rasterizer::backward(c.P, c.D, c.M, c.R, c.B, c.bg, c.W, c.H, c.means, c.dc, c.shs, nullptr, c.scales, 1.0f, c.rots,
+                                         nullptr, c.view, c.proj, c.campos, c.tanfovx, c.tanfovy, c.lxn, c.lxp, c.lyn, c.lyp, c.radii, c.geom,
+                                         c.binning, c.img, c.sample, d_pix, g2, gc, go, gcol, g3, gcov, gdc, gsh, gs, gr, lambda_erank, false);
+    HCHK(hipDeviceSynchronize());
+#define OUT(h, d, n) HCHK(hipMemcpy(h, d, sizeof(float) * (n), hipMemcpyDeviceToHost))
+    OUT(dL_dmean2D, g2, 3 * P); OUT(dL_dconic, gc, 4 * P); OUT(dL_dopacity, go, P); OUT(dL_dcolor, gcol, 3 * P); OUT(dL_dmean3D, g3, 3 * P);
+    OUT(dL_dcov3D, gcov, 6 * P); OUT(dL_ddc, gdc, 3 * P);
+    if (c.M > 0) OUT(dL_dsh, gsh, 3 * (size_t)c.M * P);
+    OUT(dL_dscale, gs, 3 * P); OUT(dL_drot, gr, 4 * P);
+#undef OUT
+    return 0;
+}
+
+int ref_adam(float* param, const float* grad, float* m, float* v, const unsigned char* visible, float lr, float b1, float b2, float eps,
+             unsigned N, unsigned M)
+{
+    Ctx c;
+    const size_t n = (size_t)N * M;
+    float *dp = c.dev(param, n), *dg = c.dev(grad, n), *dm = c.dev(m, n), *dv = c.dev(v, n);
+    bool* dvis = (bool*)c.dev(visible, N);
+    ADAM::adamUpdate(dp, dg, dm, dv, dvis, lr, b1, b2, eps, N, M);
+    HCHK(hipDeviceSynchronize());
+    HCHK(hipMemcpy(param, dp, sizeof(float) * n, hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(m, dm, sizeof(float) * n, hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(v, dv, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

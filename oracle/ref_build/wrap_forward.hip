@@ -1,0 +1,6 @@
+// translation unit = the reference's forward.cu, unmodified, with the CUDA shift semantics of ref_warp_size.h
+#include "forward.h"
+#include "ref_warp_size.h"
+#undef WARP_SIZE
+#define WARP_SIZE (RefWarpSize{})
+#include "forward.cu"
