@@ -1,0 +1,69 @@
+"""CPU, world_size 2, gloo: the one exchange step of the N-GPU path — SUM of the gradient slab and
+MAX (= OR) of the visibility mask — and the view sharding rule of bench.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import trainer
+    P = 257
+    g = torch.Generator().manual_seed(100 + rank)
+    shapes = [(P, 3), (P, 1, 3), (P, 15, 3), (P, 1), (P, 3), (P, 4)]   # the six groups of gaussian.cpp:399-418
+    grads = [torch.randn(*s, generator=g) for s in shapes]
+    vis = torch.rand(P, generator=g) < 0.3
+    red, rvis = trainer.allreduce_gradients(grads, vis)
+    q.put((rank, [r.clone().numpy() for r in red], rvis.numpy(), [x.numpy() for x in grads], vis.numpy()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_gradient_allreduce_two_ranks_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, red0, vis0, g0, v0), (_, red1, vis1, g1, v1) = res
+    for a, b, x, y in zip(red0, red1, g0, g1):
+        np.testing.assert_array_equal(a, b)                 # every rank holds the identical reduced slab
+        np.testing.assert_allclose(a, x + y, rtol=0, atol=0)  # = sum of the per-view gradients (2 addends: exact)
+        assert a.shape == x.shape
+    np.testing.assert_array_equal(vis0, vis1)
+    np.testing.assert_array_equal(vis0, v0 | v1)              # mask = OR of the views
+
+
+def test_view_sharding_rule():
+    """bench.py: rank k of an N-rank job renders synthetic view k % 8; a single rank renders the identity pose."""
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd.camera import synthetic_camera
+    c0 = synthetic_camera(64, 48, None)
+    assert np.allclose(c0.world_view_transform, np.eye(4))
+    views = [synthetic_camera(64, 48, k) for k in range(8)]
+    cens = np.array([v.camera_center for v in views])
+    assert np.allclose(cens[:, 0], (np.arange(8) - 3.5) * 0.25, atol=1e-6) and np.allclose(cens[:, 1:], 0, atol=1e-6)
+    for v in views:   # full_proj = view x proj, stored transposed (camera.h:60,86,109)
+        assert np.allclose(v.full_proj_transform, v.world_view_transform @ v.projection_matrix, atol=1e-6)
