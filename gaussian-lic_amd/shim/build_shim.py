@@ -1,0 +1,66 @@
+"""Builds libgslic_torch_shim.so: plain g++ against LibTorch headers, linked to libgslic_hip.so by C-ABI only
+(no hipcc, no hipify, no torch.utils.cpp_extension JIT: the .so stays in-tree and travels to the GPU box)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT = os.path.join(PKG, "libgslic_torch_shim.so")
+
+
+def build(force=False):
+    import torch
+    from torch.utils import cpp_extension
+    src = os.path.join(HERE, "gslic_torch_shim.cpp")
+    deps = [src, os.path.join(PKG, "..", "include", "gslic_hip.h")] + [os.path.join(HERE, "include", p) for p in
+                                                                       ("rasterizer/rasterize_points.h", "fused-ssim/ssim.h", "simple-knn/spatial.h")]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(d) for d in deps):
+        return OUT
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    for inc in cpp_extension.include_paths():
+        cmd += ["-isystem", inc]
+    cmd += ["-I", os.path.join(HERE, "include"), src, "-o", OUT, "-L", PKG, "-lgslic_hip", f"-Wl,-rpath,$ORIGIN", "-L", tlib,
+            "-ltorch", "-ltorch_cpu", "-lc10", f"-Wl,-rpath,{tlib}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout[-3000:] + r.stderr[-6000:])
+        raise RuntimeError("shim build failed")
+    return OUT
+
+
+REF_SRC = "/root/reference/src"
+CHECK = os.path.join(PKG, "dropin_check")
+
+
+def build_dropin_check(force=False):
+    """Compiles the REFERENCE's own host code (rasterizer/rasterizer.cpp + headers, read in place) together with
+    dropin_check.cpp and links it against the shim: the drop-in claim, exercised.  Needs /root/reference; the binary stays
+    in-tree (git-ignored) and travels to the GPU box."""
+    if not os.path.isdir(REF_SRC):
+        return None
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension
+    src = os.path.join(HERE, "dropin_check.cpp")
+    if not force and os.path.exists(CHECK) and os.path.getmtime(CHECK) > max(os.path.getmtime(src), os.path.getmtime(OUT)):
+        return CHECK
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ["g++", "-O1", "-std=c++17", "-w", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    for inc in cpp_extension.include_paths():
+        cmd += ["-isystem", inc]
+    cmd += ["-isystem", sysconfig.get_paths()["include"], "-I", REF_SRC, src, os.path.join(REF_SRC, "rasterizer", "rasterizer.cpp"),
+            "-o", CHECK, "-L", PKG, "-lgslic_torch_shim", "-lgslic_hip", "-Wl,-rpath,$ORIGIN", "-L", tlib, "-ltorch", "-ltorch_cpu",
+            "-ltorch_hip", "-lc10", "-lc10_hip", f"-Wl,-rpath,{tlib}", "-Wl,--no-as-needed", "-ltorch_hip", "-Wl,--as-needed",
+            "-L", os.path.join(sysconfig.get_config_var("LIBDIR") or "/usr/lib"), f"-lpython{sysconfig.get_python_version()}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout[-3000:] + r.stderr[-6000:])
+        raise RuntimeError("dropin_check build failed")
+    return CHECK
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))
+    print(build_dropin_check(force="--force" in sys.argv))

@@ -1,0 +1,90 @@
+// dropin_check.cpp — drives the REFERENCE's own host code (rasterizer/rasterizer.{h,cpp}, loss_utils.h, optim_utils.h,
+// compiled in place from /root/reference, unmodified) on top of libgslic_torch_shim.so / libgslic_hip.so: a few
+// iterations of the optimize() loop body (gaussian.cpp:674-716) on tensors read from raw fp32 files.
+//   dropin_check <dir> <P> <W> <H> <deg> <iters>
+// reads  <dir>/{xyz,scaling,rotation,opacity,dc,rest,view,proj,campos,gt}.f32 and scalars.f32 (tanfovx, tanfovy, 4 lims),
+// writes <dir>/out_{image,xyz,scaling,rotation,opacity,dc,rest}.f32 after <iters> steps (image = last render).
+#include "rasterizer/rasterizer.h"  // reference
+#include "loss_utils.h"             // reference
+#include "optim_utils.h"            // reference
+
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+static torch::Tensor load(const std::string& path, std::vector<int64_t> shape)
+{
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    std::vector<float> buf(n);
+    std::ifstream f(path, std::ios::binary);
+    TORCH_CHECK(f.good(), "cannot open ", path);
+    f.read(reinterpret_cast<char*>(buf.data()), n * sizeof(float));
+    return torch::from_blob(buf.data(), shape, torch::kFloat32).clone().to(torch::kCUDA);
+}
+static void save(const std::string& path, const torch::Tensor& t)
+{
+    torch::Tensor c = t.detach().to(torch::kCPU).contiguous();
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char*>(c.data_ptr<float>()), c.numel() * sizeof(float));
+}
+
+int main(int argc, char** argv)
+{
+    TORCH_CHECK(argc == 7, "usage: dropin_check <dir> <P> <W> <H> <deg> <iters>");
+    const std::string d = argv[1];
+    const int64_t P = std::stoll(argv[2]), W = std::stoll(argv[3]), H = std::stoll(argv[4]);
+    const int deg = std::stoi(argv[5]), iters = std::stoi(argv[6]);
+    const int64_t M = deg > 0 ? 15 : 0;
+    auto leaf = [](torch::Tensor t) { return t.requires_grad_(true); };
+    torch::Tensor xyz = leaf(load(d + "/xyz.f32", {P, 3})), scaling = leaf(load(d + "/scaling.f32", {P, 3}));
+    torch::Tensor rotation = leaf(load(d + "/rotation.f32", {P, 4})), opacity = leaf(load(d + "/opacity.f32", {P, 1}));
+    torch::Tensor dc = leaf(load(d + "/dc.f32", {P, 1, 3}));
+    torch::Tensor rest = M > 0 ? leaf(load(d + "/rest.f32", {P, M, 3})) : leaf(torch::zeros({P, 0, 3}, torch::kCUDA));
+    torch::Tensor view = load(d + "/view.f32", {4, 4}), proj = load(d + "/proj.f32", {4, 4}), campos = load(d + "/campos.f32", {3});
+    torch::Tensor gt = load(d + "/gt.f32", {3, H, W});
+    torch::Tensor sc = load(d + "/scalars.f32", {6}).to(torch::kCPU);
+    const float* s = sc.data_ptr<float>();
+    torch::Tensor bg = torch::zeros({3}, torch::kFloat32).cuda();
+
+    // trainingSetup (gaussian.cpp:399-418) with config/fastlivo.yaml learning rates
+    std::vector<torch::Tensor> g0{xyz}, g1{dc}, g2{rest}, g3{opacity}, g4{scaling}, g5{rotation};
+    SparseGaussianAdam opt(g0, 0.0, 1e-15);
+    opt.param_groups()[0].options().set_lr(1.6e-4);
+    opt.add_param_group(g1); opt.param_groups()[1].options().set_lr(2.5e-3);
+    opt.add_param_group(g2); opt.param_groups()[2].options().set_lr(2.5e-3 / 20.0);
+    opt.add_param_group(g3); opt.param_groups()[3].options().set_lr(5e-2);
+    opt.add_param_group(g4); opt.param_groups()[4].options().set_lr(5e-3);
+    opt.add_param_group(g5); opt.param_groups()[5].options().set_lr(1e-3);
+
+    torch::Tensor image;
+    for (int it = 0; it < iters; it++) {
+        // render() (renderer.cpp:21-88) without the Camera/GaussianModel wrappers (those need Eigen/OpenCV/PCL)
+        GaussianRasterizationSettings rs((int)H, (int)W, s[0], s[1], s[2], s[3], s[4], s[5], bg, 1.0f, view, proj, deg, campos, false, false,
+                                         false, 0.0f);
+        GaussianRasterizer rasterizer(rs);
+        auto screenspace = torch::zeros_like(xyz, torch::TensorOptions().requires_grad(true));
+        torch::Tensor colors_precomp, cov3D_precomp;
+        auto res = rasterizer.forward(xyz, screenspace, torch::sigmoid(opacity), dc, rest, colors_precomp, torch::exp(scaling),
+                                      torch::nn::functional::normalize(rotation), cov3D_precomp);
+        image = std::get<0>(res);
+        torch::Tensor radii = std::get<1>(res);
+        // optimize() body (gaussian.cpp:685-707)
+        auto Ll1 = loss_utils::l1_loss(image, gt);
+        torch::Tensor iu = image.unsqueeze(0), gu = gt.unsqueeze(0);
+        auto ssim_value = loss_utils::fused_ssim(iu, gu);
+        auto loss = (1.0 - 0.2) * Ll1 + 0.2 * (1.0 - ssim_value);
+        loss.backward();
+        auto visible = radii > 0;
+        opt.set_visibility_and_N(visible, xyz.size(0));
+        opt.step();
+        opt.zero_grad(true);
+        std::cout << "iter " << it << " loss " << loss.item<float>() << " visible " << visible.sum().item<int>() << std::endl;
+    }
+    save(d + "/out_image.f32", image);
+    save(d + "/out_xyz.f32", xyz); save(d + "/out_scaling.f32", scaling); save(d + "/out_rotation.f32", rotation);
+    save(d + "/out_opacity.f32", opacity); save(d + "/out_dc.f32", dc);
+    if (M > 0) save(d + "/out_rest.f32", rest);
+    return 0;
+}
