@@ -9,9 +9,10 @@
 //
 // render_bwd_kernel  replaces PerGaussianRenderCUDA<3> (backward.cu:379-597)
 //   ONE WAVE PER BUCKET of 64 list entries: lane = Gaussian, the tile's 256 pixels stream through the lanes as a
-//   64-deep systolic pipeline; the per-pixel state {T, ar[3], n_contrib, dL/dpixel[3]} moves lane -> lane+1 with
-//   one v_mov_b32 DPP wave_shr:1 per value (no ds_bpermute, no LDS), lane 0 is fed from a 64-pixel register
-//   chunk via v_readlane.  Each lane accumulates its Gaussian's nine 2D gradients in registers and writes them
+//   64-deep systolic pipeline; the per-pixel state {T, ar[3], dL/dpixel[3], n_contrib|index} moves lane -> lane+1 with
+//   one v_mov_b32 DPP wave_shr:1 per value (no ds_bpermute, no LDS), lane 0 is fed from a 64-pixel register chunk via
+//   v_readlane + the DPP's bound-lane `old` operand.  Only pixels whose n_contrib reaches this bucket are injected (a 64-bit ballot per chunk,
+//   walked with s_ff1): pixels that terminated earlier cost no pipeline step at all.  Each lane accumulates its Gaussian's nine 2D gradients in registers and writes them
 //   ONCE to its emission slot (plain 48-byte store): no atomics — the sum over a Gaussian's tiles is a
 //   contiguous segmented reduction in preprocess_bwd_kernel, deterministic run to run.
 #include "gslic_common.h"
@@ -123,6 +124,54 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
     }
 }
 
+// Whole-wave shift by one lane with injection: lane l >= 1 receives v[l-1]; lane 0 has no source lane, so with
+// bound_ctrl = 0 it keeps the DPP "old" operand — which we set to the (wave-uniform) value to inject.  2 VALU ops.
+__device__ __forceinline__ float shift_in_f(float inject, float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(inject), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint32_t shift_in_u(uint32_t inject, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)inject, (int)v, 0x138, 0xf, 0xf, false);
+}
+
+// One pipeline step: hand every pixel state to the next lane (DPP wave_shr:1), put a new pixel (or an empty slot) into
+// lane 0 (the DPP's `old` operand), then let every lane whose Gaussian can have been blended into its current pixel accumulate.
+// State per pixel: T, ar[3] (= accumulated colour - final colour), dL/dpixel[3], and `tag` = n_contrib << 8 | pixel index.
+#define GS_BWD_STEP(iT, ia0, ia1, ia2, ig0, ig1, ig2, itag)                                                          \
+    do {                                                                                                             \
+        T = shift_in_f(iT, T); ar0 = shift_in_f(ia0, ar0); ar1 = shift_in_f(ia1, ar1); ar2 = shift_in_f(ia2, ar2);   \
+        g0 = shift_in_f(ig0, g0); g1 = shift_in_f(ig1, g1); g2 = shift_in_f(ig2, g2); tag = shift_in_u(itag, tag);   \
+        if (kcmp < tag) { /* kit < n_contrib of this pixel (backward.cu:538) */                                     \
+            const float dx = dx0 - (float)(tag & 15u);                                                               \
+            const float dy = dy0 - (float)((tag >> 4) & 15u);                                                        \
+            float p2 = (hA * dx) * dx;                                                                               \
+            p2 = __builtin_fmaf(hC * dy, dy, p2);                                                                    \
+            p2 = __builtin_fmaf(nB * dx, dy, p2); /* = log2(e) * power */                                            \
+            const float G = __builtin_amdgcn_exp2f(p2);                                                              \
+            const float alpha = fminf(0.99f, op * G);                                                                \
+            if (!(p2 > 0.0f) && !(alpha < (1.0f / 255.0f))) {                                                        \
+                const float om = 1.0f - alpha;                                                                       \
+                const float rinv = __builtin_amdgcn_rcpf(om);                                                        \
+                const float Ta = T * alpha;                                                                          \
+                ar0 = __builtin_fmaf(Ta, colr, ar0); ar1 = __builtin_fmaf(Ta, colg, ar1); ar2 = __builtin_fmaf(Ta, colb, ar2); \
+                acc_r = __builtin_fmaf(Ta, g0, acc_r); acc_g = __builtin_fmaf(Ta, g1, acc_g); acc_b = __builtin_fmaf(Ta, g2, acc_b); \
+                float dLda = __builtin_fmaf(rinv, ar0, colr * T) * g0;                                               \
+                dLda = __builtin_fmaf(__builtin_fmaf(rinv, ar1, colg * T), g1, dLda);                                \
+                dLda = __builtin_fmaf(__builtin_fmaf(rinv, ar2, colb * T), g2, dLda);                                \
+                T *= om;                                                                                             \
+                const float q = op * dLda; /* dL/dG */                                                               \
+                const float gdx = G * dx, gdy = G * dy;                                                              \
+                acc_mx = __builtin_fmaf(q, __builtin_fmaf(gdx, cA, gdy * cB), acc_mx); /* sign and 0.5*W applied at the end */ \
+                acc_my = __builtin_fmaf(q, __builtin_fmaf(gdy, cC, gdx * cB), acc_my);                               \
+                acc_cx = __builtin_fmaf(gdx * dx, q, acc_cx); /* -0.5 applied at the end */                          \
+                acc_cy = __builtin_fmaf(gdx * dy, q, acc_cy);                                                        \
+                acc_cw = __builtin_fmaf(gdy * dy, q, acc_cw);                                                        \
+                acc_op = __builtin_fmaf(G, dLda, acc_op);                                                            \
+            }                                                                                                        \
+        }                                                                                                            \
+    } while (0)
+
 __global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -133,12 +182,13 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a)
     const uint32_t n = range.y - range.x;
     const uint32_t bbm = (tile == 0) ? 0u : a.bucket_offsets[tile - 1];
     const uint32_t bit = bucket - bbm;
-    const uint32_t kit = bit * GS_BUCKET + (uint32_t)lane;  // splat index in tile
+    const uint32_t bstart = bit * GS_BUCKET;
+    const uint32_t kit = bstart + (uint32_t)lane;  // splat index in tile
     const bool valid = kit < n;
     const uint32_t slot = valid ? a.inst_slot[range.x + kit] : 0u;
 
     // bucket entirely behind every pixel's last contributor (backward.cu:428): gradients are exactly zero
-    if (bit * GS_BUCKET >= a.max_contrib[tile]) {
+    if (bstart >= a.max_contrib[tile]) {
         if (valid) {
             float4* o = a.partials + 3 * (size_t)slot;
             o[0] = o[1] = o[2] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -146,87 +196,68 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a)
         return;
     }
 
-    float gmx = 0, gmy = 0, cA = 0, cB = 0, cC = 0, op = 0, colr = 0, colg = 0, colb = 0;
+    const int tx0 = (int)(tile % (uint32_t)a.gx) * GS_TILE, ty0 = (int)(tile / (uint32_t)a.gx) * GS_TILE;
+    float dx0 = 0, dy0 = 0, cA = 0, cB = 0, cC = 0, op = 0, colr = 0, colg = 0, colb = 0;
     if (valid) {
         const uint32_t g = a.point_list[range.x + kit];
         const float4* rp = a.rec + 3 * (size_t)g;
         const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-        gmx = r0.x; gmy = r0.y; cA = r0.z; cB = r0.w; cC = r1.x; op = r1.y; colr = r1.z; colg = r1.w; colb = r2.x;
+        dx0 = r0.x - (float)tx0; dy0 = r0.y - (float)ty0;
+        cA = r0.z; cB = r0.w; cC = r1.x; op = r1.y; colr = r1.z; colg = r1.w; colb = r2.x;
     }
+    const float LOG2E = 1.4426950408889634f;
+    const float hA = -0.5f * LOG2E * cA, hC = -0.5f * LOG2E * cC, nB = -LOG2E * cB;
+    const uint32_t kcmp = (kit << 8) | 0xffu;  // kcmp < (n_contrib << 8 | idx)  <=>  kit < n_contrib
     float acc_mx = 0, acc_my = 0, acc_cx = 0, acc_cy = 0, acc_cw = 0, acc_op = 0, acc_r = 0, acc_g = 0, acc_b = 0;
-
-    const int tx0 = (int)(tile % (uint32_t)a.gx) * GS_TILE, ty0 = (int)(tile / (uint32_t)a.gx) * GS_TILE;
-    const float ddelx_dx = 0.5f * (float)a.W, ddely_dy = 0.5f * (float)a.H;
     const size_t plane = (size_t)a.H * a.W;
 
-    // pipeline state (pixel currently at this lane) and the 64-pixel feed chunk
+    // pixel state travelling through the lanes
     float T = 0, ar0 = 0, ar1 = 0, ar2 = 0, g0 = 0, g1 = 0, g2 = 0;
-    uint32_t nc = 0;
-    float fT = 0, fa0 = 0, fa1 = 0, fa2 = 0, fg0 = 0, fg1 = 0, fg2 = 0;
-    uint32_t fnc = 0;
+    uint32_t tag = 0;
 
-    for (int i = 0; i < GS_TILE_PIX + 63; i++) {
-        if ((i & 63) == 0 && i < GS_TILE_PIX) {
-            const int pidx = i + lane;
-            const float4 ck = a.ckpt[(size_t)bucket * GS_TILE_PIX + pidx];
-            const float4 pf = a.pix_final[(size_t)tile * GS_TILE_PIX + pidx];
-            const int px = tx0 + (pidx & 15), py = ty0 + (pidx >> 4);
-            const bool inside = px < a.W && py < a.H;
-            fnc = inside ? __float_as_uint(pf.w) : 0u;
-            fT = ck.x;
-            fa0 = ck.y - pf.x; fa1 = ck.z - pf.y; fa2 = ck.w - pf.z;
-            fg0 = fg1 = fg2 = 0.f;
-            if (inside) {
-                const size_t pid = (size_t)py * a.W + px;
-                fg0 = a.dL_dpix[pid]; fg1 = a.dL_dpix[plane + pid]; fg2 = a.dL_dpix[2 * plane + pid];
-            }
+    // 64-pixel feed chunk (register double buffer: chunk c+1 is in flight while chunk c streams through)
+    float4 ck, pf;
+    float fg0, fg1, fg2;
+    bool inside;
+    auto load_chunk = [&](int c) {
+        const int pidx = c * 64 + lane;
+        ck = a.ckpt[(size_t)bucket * GS_TILE_PIX + pidx];
+        pf = a.pix_final[(size_t)tile * GS_TILE_PIX + pidx];
+        const int px = tx0 + (pidx & 15), py = ty0 + (pidx >> 4);
+        inside = px < a.W && py < a.H;
+        fg0 = fg1 = fg2 = 0.f;
+        if (inside) {
+            const size_t pid = (size_t)py * a.W + px;
+            fg0 = a.dL_dpix[pid]; fg1 = a.dL_dpix[plane + pid]; fg2 = a.dL_dpix[2 * plane + pid];
         }
-        // hand the pixel state to the next lane
-        T = wave_shr1_f(T); ar0 = wave_shr1_f(ar0); ar1 = wave_shr1_f(ar1); ar2 = wave_shr1_f(ar2);
-        g0 = wave_shr1_f(g0); g1 = wave_shr1_f(g1); g2 = wave_shr1_f(g2);
-        nc = wave_shr1_u(nc);
-        // lane 0 takes pixel i from the feed chunk (or an empty slot once the tile is exhausted)
-        {
-            const int sl = i & 63;
-            const float iT = readlane_f(fT, sl), ia0 = readlane_f(fa0, sl), ia1 = readlane_f(fa1, sl), ia2 = readlane_f(fa2, sl);
-            const float ig0 = readlane_f(fg0, sl), ig1 = readlane_f(fg1, sl), ig2 = readlane_f(fg2, sl);
-            const uint32_t inc = (i < GS_TILE_PIX) ? readlane_u(fnc, sl) : 0u;
-            if (lane == 0) { T = iT; ar0 = ia0; ar1 = ia1; ar2 = ia2; g0 = ig0; g1 = ig1; g2 = ig2; nc = inc; }
-        }
-        if (kit < nc) {  // this Gaussian was (possibly) blended into this pixel (backward.cu:538)
-            const int idx = i - lane;
-            const float dx = gmx - (float)(tx0 + (idx & 15));
-            const float dy = gmy - (float)(ty0 + (idx >> 4));
-            const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
-            const float G = __expf(power);
-            const float alpha = fminf(0.99f, op * G);
-            if (!(power > 0.0f) && !(alpha < (1.0f / 255.0f))) {
-                const float dchannel_dcolor = alpha * T;
-                const float alpha_inv = 1.0f / (1.0f - alpha);
-                const float Ta = T * alpha;
-                ar0 += Ta * colr; ar1 += Ta * colg; ar2 += Ta * colb;
-                acc_r += dchannel_dcolor * g0; acc_g += dchannel_dcolor * g1; acc_b += dchannel_dcolor * g2;
-                float dL_dalpha = ((colr * T) + alpha_inv * ar0) * g0;
-                dL_dalpha += ((colg * T) + alpha_inv * ar1) * g1;
-                dL_dalpha += ((colb * T) + alpha_inv * ar2) * g2;
-                T *= (1.0f - alpha);
-                const float dL_dG = op * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * cA - gdy * cB;
-                const float dG_ddely = -gdy * cC - gdx * cB;
-                acc_mx += dL_dG * dG_ddelx * ddelx_dx;
-                acc_my += dL_dG * dG_ddely * ddely_dy;
-                acc_cx += -0.5f * gdx * dx * dL_dG;
-                acc_cy += -0.5f * gdx * dy * dL_dG;
-                acc_cw += -0.5f * gdy * dy * dL_dG;
-                acc_op += G * dL_dalpha;
-            }
+    };
+    load_chunk(0);
+#pragma unroll 1
+    for (int c = 0; c < 4; c++) {
+        // derive this chunk's feed values, then start the next chunk's loads
+        const uint32_t ncp = inside ? __float_as_uint(pf.w) : 0u;
+        const float fT = ck.x, fa0 = ck.y - pf.x, fa1 = ck.z - pf.y, fa2 = ck.w - pf.z;
+        const float cg0 = fg0, cg1 = fg1, cg2 = fg2;
+        const uint32_t ftag = (ncp << 8) | (uint32_t)(c * 64 + lane);
+        uint64_t active = __ballot(ncp > bstart);  // pixels that reach this bucket; the others contribute nothing here
+        if (c < 3) load_chunk(c + 1);
+        while (active) {
+            const int sl = __builtin_ctzll(active);
+            active &= active - 1;
+            GS_BWD_STEP(readlane_f(fT, sl), readlane_f(fa0, sl), readlane_f(fa1, sl), readlane_f(fa2, sl), readlane_f(cg0, sl),
+                        readlane_f(cg1, sl), readlane_f(cg2, sl), readlane_u(ftag, sl));
         }
     }
+    // drain: the last injected pixel still has to pass the bucket's remaining (valid) lanes
+    const int nvalid = (n - bstart) < (uint32_t)GS_BUCKET ? (int)(n - bstart) : GS_BUCKET;
+#pragma unroll 1
+    for (int d = 1; d < nvalid; d++) GS_BWD_STEP(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u);
+
     if (valid) {
+        const float sx = -0.5f * (float)a.W, sy = -0.5f * (float)a.H;  // -(...) * ddelx_dx, ddelx_dx = 0.5 W (backward.cu:464-465)
         float4* o = a.partials + 3 * (size_t)slot;
-        o[0] = make_float4(acc_mx, acc_my, acc_cx, acc_cy);
-        o[1] = make_float4(acc_cw, acc_op, acc_r, acc_g);
+        o[0] = make_float4(acc_mx * sx, acc_my * sy, -0.5f * acc_cx, -0.5f * acc_cy);
+        o[1] = make_float4(-0.5f * acc_cw, acc_op, acc_r, acc_g);
         o[2] = make_float4(acc_b, 0.f, 0.f, 0.f);
     }
 }
