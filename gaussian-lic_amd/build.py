@@ -23,7 +23,7 @@ SOURCES = {
     "scan.hip": [],
     "radix_sort.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],
-    "render.hip": [],
+    "render.hip": ["-fno-slp-vectorize"],
     "preprocess_bwd.hip": [],
     "adam.hip": [],
     "ssim.hip": [],

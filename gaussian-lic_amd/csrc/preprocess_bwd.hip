@@ -20,12 +20,93 @@ __constant__ float b_SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31
 __constant__ float b_SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                                  -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
 
+// Direction-only SH coefficients (the factors multiplying sh[k] in forward.cu:37-66), k = 0..14.
+__device__ __forceinline__ void sh_coefs(int D, float x, float y, float z, float (&c)[15])
+{
+#pragma unroll
+    for (int k = 0; k < 15; k++) c[k] = 0.f;
+    if (D > 0) {
+        c[0] = -SHC1 * y; c[1] = SHC1 * z; c[2] = -SHC1 * x;
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            c[3] = b_SH_C2[0] * xy; c[4] = b_SH_C2[1] * yz; c[5] = b_SH_C2[2] * (2.f * zz - xx - yy);
+            c[6] = b_SH_C2[3] * xz; c[7] = b_SH_C2[4] * (xx - yy);
+            if (D > 2) {
+                c[8] = b_SH_C3[0] * y * (3.f * xx - yy); c[9] = b_SH_C3[1] * xy * z; c[10] = b_SH_C3[2] * y * (4.f * zz - xx - yy);
+                c[11] = b_SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); c[12] = b_SH_C3[4] * x * (4.f * zz - xx - yy);
+                c[13] = b_SH_C3[5] * z * (xx - yy); c[14] = b_SH_C3[6] * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+
+struct ShOut {  // what phase B needs to write a Gaussian's dL_dsh row
+    float x, y, z, dR, dG, dB;
+    bool on;
+};
+
+template <bool LDS_SH>
+__device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so);
+
+// LDS_SH (M == 15): the block's 256 x 45 SH floats (contiguous in memory) are staged through LDS with coalesced float4
+// accesses and read row-wise by the owning thread (row stride 45 floats: odd, bank-conflict free); the block's dL_dsh rows go
+// back the same way — instead of 45 strided 4-byte accesses per thread in each direction (measured 2.6x write amplification).
+template <bool LDS_SH>
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreprocessBwdArgs a)
 {
+    __shared__ float lds_sh[LDS_SH ? 256 * 45 : 4];
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
-    const bool visible = a.radii[idx] > 0;
     const int M = a.M;
+    const int row0 = blockIdx.x * 256;
+    const int rows = (a.P - row0) < 256 ? (a.P - row0) : 256;
+    if constexpr (LDS_SH) {
+        const float* src = a.shs + (size_t)row0 * 45;
+        if (rows == 256) {
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            float4* d4 = reinterpret_cast<float4*>(lds_sh);
+            for (int i = threadIdx.x; i < 256 * 45 / 4; i += 256) d4[i] = s4[i];
+        } else {
+            for (int i = threadIdx.x; i < rows * 45; i += 256) lds_sh[i] = src[i];
+        }
+        __syncthreads();
+    }
+    ShOut so;
+    so.x = so.y = so.z = so.dR = so.dG = so.dB = 0.f;
+    so.on = false;
+    const float* sh_row = LDS_SH ? (lds_sh + threadIdx.x * 45) : (a.shs ? a.shs + (size_t)3 * M * idx : nullptr);
+    if (idx < a.P) bwd_phase_a<LDS_SH>(a, idx, M, sh_row, so);
+    if constexpr (LDS_SH) __syncthreads();  // every SH row has been consumed: the buffer now takes the dL_dsh rows
+
+    // ---- phase B: this Gaussian's dL_dsh row (zeros when invisible, when shs == NULL, and above the active degree)
+    if (idx < a.P && (LDS_SH || a.dL_dsh)) {
+        float* drow = LDS_SH ? (lds_sh + threadIdx.x * 45) : (a.dL_dsh + (size_t)3 * M * idx);
+        if (so.on) {
+            float c[15];
+            sh_coefs(a.D, so.x, so.y, so.z, c);
+            const int nk = M < 15 ? M : 15;
+            for (int k = 0; k < nk; k++) { drow[3 * k] = c[k] * so.dR; drow[3 * k + 1] = c[k] * so.dG; drow[3 * k + 2] = c[k] * so.dB; }
+            for (int k = 3 * nk; k < 3 * M; k++) drow[k] = 0.f;
+        } else {
+            for (int k = 0; k < 3 * M; k++) drow[k] = 0.f;
+        }
+    }
+    if constexpr (LDS_SH) {
+        __syncthreads();
+        float* dst = a.dL_dsh + (size_t)row0 * 45;
+        if (rows == 256) {
+            float4* d4 = reinterpret_cast<float4*>(dst);
+            const float4* s4 = reinterpret_cast<const float4*>(lds_sh);
+            for (int i = threadIdx.x; i < 256 * 45 / 4; i += 256) d4[i] = s4[i];
+        } else {
+            for (int i = threadIdx.x; i < rows * 45; i += 256) dst[i] = lds_sh[i];
+        }
+    }
+}
+
+template <bool LDS_SH>
+__device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so)
+{
+    const bool visible = a.radii[idx] > 0;
 
     if (!visible) {
         if (a.dL_dmean2D) { a.dL_dmean2D[3 * idx] = 0; a.dL_dmean2D[3 * idx + 1] = 0; a.dL_dmean2D[3 * idx + 2] = 0; }
@@ -36,8 +117,6 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreprocessBwdArgs a
         if (a.dL_dcov3D)
             for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * idx + k] = 0;
         a.dL_ddc[3 * idx] = 0; a.dL_ddc[3 * idx + 1] = 0; a.dL_ddc[3 * idx + 2] = 0;
-        if (a.dL_dsh)
-            for (int k = 0; k < 3 * M; k++) a.dL_dsh[(size_t)3 * M * idx + k] = 0;
         a.dL_dscale[3 * idx] = 0; a.dL_dscale[3 * idx + 1] = 0; a.dL_dscale[3 * idx + 2] = 0;
         reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0, 0, 0, 0);
         return;
@@ -164,11 +243,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreprocessBwdArgs a
         const float dox = mx3 - a.campos[0], doy = my3 - a.campos[1], doz = mz3 - a.campos[2];
         const float len = sqrtf(dox * dox + doy * doy + doz * doz);
         const float x = dox / len, y = doy / len, z = doz / len;
-        const float* __restrict__ sh = a.shs + (size_t)3 * M * idx;
-        float* __restrict__ dsh = a.dL_dsh + (size_t)3 * M * idx;
-        if (a.D < 3 || M != 15)  // coefficients above the active degree keep the reference's zero-fill
-            for (int k = 0; k < 3 * M; k++) dsh[k] = 0.f;
+        const float* __restrict__ sh = sh_row;
         const float dRGB[3] = {(clamp_bits & 1u) ? 0.f : s_r, (clamp_bits & 2u) ? 0.f : s_g, (clamp_bits & 4u) ? 0.f : s_b};
+        so.x = x; so.y = y; so.z = z; so.dR = dRGB[0]; so.dG = dRGB[1]; so.dB = dRGB[2]; so.on = true;
         float ddir[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
@@ -176,23 +253,14 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreprocessBwdArgs a
             a.dL_ddc[3 * idx + ch] = SHC0 * g;
             float ddx = 0.f, ddy = 0.f, ddz = 0.f;
 #define S(k) sh[3 * (k) + ch]
-#define SET(k, coef) dsh[3 * (k) + ch] = (coef) * g
             if (a.D > 0) {
-                SET(0, -SHC1 * y); SET(1, SHC1 * z); SET(2, -SHC1 * x);
                 ddx = -SHC1 * S(2); ddy = -SHC1 * S(0); ddz = SHC1 * S(1);
                 if (a.D > 1) {
-                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    SET(3, b_SH_C2[0] * xy); SET(4, b_SH_C2[1] * yz); SET(5, b_SH_C2[2] * (2.f * zz - xx - yy));
-                    SET(6, b_SH_C2[3] * xz); SET(7, b_SH_C2[4] * (xx - yy));
                     ddx += b_SH_C2[0] * y * S(3) + b_SH_C2[2] * 2.f * -x * S(5) + b_SH_C2[3] * z * S(6) + b_SH_C2[4] * 2.f * x * S(7);
                     ddy += b_SH_C2[0] * x * S(3) + b_SH_C2[1] * z * S(4) + b_SH_C2[2] * 2.f * -y * S(5) + b_SH_C2[4] * 2.f * -y * S(7);
                     ddz += b_SH_C2[1] * y * S(4) + b_SH_C2[2] * 2.f * 2.f * z * S(5) + b_SH_C2[3] * x * S(6);
                     if (a.D > 2) {
-                        SET(8, b_SH_C3[0] * y * (3.f * xx - yy)); SET(9, b_SH_C3[1] * xy * z);
-                        SET(10, b_SH_C3[2] * y * (4.f * zz - xx - yy));
-                        SET(11, b_SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
-                        SET(12, b_SH_C3[4] * x * (4.f * zz - xx - yy)); SET(13, b_SH_C3[5] * z * (xx - yy));
-                        SET(14, b_SH_C3[6] * x * (xx - 3.f * yy));
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
                         ddx += (b_SH_C3[0] * S(8) * 3.f * 2.f * xy + b_SH_C3[1] * S(9) * yz + b_SH_C3[2] * S(10) * -2.f * xy +
                                 b_SH_C3[3] * S(11) * -3.f * 2.f * xz + b_SH_C3[4] * S(12) * (-3.f * xx + 4.f * zz - yy) +
                                 b_SH_C3[5] * S(13) * 2.f * xz + b_SH_C3[6] * S(14) * 3.f * (xx - yy));
@@ -206,7 +274,6 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreprocessBwdArgs a
                 }
             }
 #undef S
-#undef SET
             ddir[0] += ddx * g; ddir[1] += ddy * g; ddir[2] += ddz * g;
         }
         // dnormvdv (auxiliary.h:119-129)
@@ -265,7 +332,11 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreprocessBwdArgs a
 
 int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
 {
-    GS_LAUNCH(K_PREPROCESS_BWD, preprocess_bwd_kernel, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+    if (a.M == 15 && a.shs && a.dL_dsh) {
+        GS_LAUNCH(K_PREPROCESS_BWD, preprocess_bwd_kernel<true>, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+    } else {
+        GS_LAUNCH(K_PREPROCESS_BWD, preprocess_bwd_kernel<false>, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+    }
     return GSLIC_OK;
 }
 
