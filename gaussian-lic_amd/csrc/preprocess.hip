@@ -28,10 +28,27 @@ __constant__ float c_SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.45
 __device__ __forceinline__ float fmin_c(float a, float b) { return (b < a) ? b : a; }
 __device__ __forceinline__ float fmax_c(float a, float b) { return (b > a) ? b : a; }
 
+// LDS_SH (M == 15, colour mode): the block's 256 x 45 SH floats are contiguous in memory; they are staged through LDS with
+// coalesced float4 loads issued first (their latency hides under the projection / tile counting) and read row-wise by the
+// owning thread (row stride 45 floats: odd, bank-conflict free) instead of 45 strided 4-byte loads per visible Gaussian.
+template <bool LDS_SH>
 __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a)
 {
+    __shared__ float lds_sh[LDS_SH ? 256 * 45 : 4];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    if constexpr (LDS_SH) {
+        const int row0 = blockIdx.x * 256;
+        const int rows = (a.P - row0) < 256 ? (a.P - row0) : 256;
+        const float* src = a.shs + (size_t)row0 * 45;
+        if (rows == 256) {
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            float4* d4 = reinterpret_cast<float4*>(lds_sh);
+            for (int i = threadIdx.x; i < 256 * 45 / 4; i += 256) d4[i] = s4[i];
+        } else {
+            for (int i = threadIdx.x; i < rows * 45; i += 256) lds_sh[i] = src[i];
+        }
+    }
     bool active = idx < a.P;
     const float* __restrict__ V = a.view;
     const float* __restrict__ Pm = a.proj;
@@ -156,6 +173,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a)
         a.radii[idx] = visible ? radius : 0;
         a.tiles_touched[idx] = visible ? cnt : 0u;
     }
+    if constexpr (LDS_SH) __syncthreads();  // SH rows have landed in LDS (block-uniform: no thread has returned yet)
     if (!visible) return;
 
     // ---- SH -> RGB (forward.cu:29-77) ----
@@ -166,7 +184,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a)
         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
         const float x = dx / len, y = dy / len, z = dz / len;
         const float* __restrict__ d0 = a.dc + 3 * (size_t)idx;
-        const float* __restrict__ sh = a.shs ? a.shs + (size_t)3 * a.M * idx : nullptr;
+        const float* __restrict__ sh = LDS_SH ? (lds_sh + threadIdx.x * 45) : (a.shs ? a.shs + (size_t)3 * a.M * idx : nullptr);
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
             float res = c_SH_C0 * d0[ch];
@@ -290,7 +308,11 @@ __global__ __launch_bounds__(256) void bucket_count_kernel(int T, const uint2* _
 
 int launch_preprocess(const PreprocessArgs& a, hipStream_t s)
 {
-    GS_LAUNCH(K_PREPROCESS, preprocess_kernel, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+    if (a.M == 15 && a.D > 0 && a.shs && !a.no_color) {
+        GS_LAUNCH(K_PREPROCESS, preprocess_kernel<true>, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+    } else {
+        GS_LAUNCH(K_PREPROCESS, preprocess_kernel<false>, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+    }
     return GSLIC_OK;
 }
 int launch_keybuild(const KeybuildArgs& a, hipStream_t s)
