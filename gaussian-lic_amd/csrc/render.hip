@@ -9,9 +9,9 @@
 //
 // render_bwd_kernel  replaces PerGaussianRenderCUDA<3> (backward.cu:379-597)
 //   ONE WAVE PER BUCKET of 64 list entries: lane = Gaussian, the tile's 256 pixels stream through the lanes as a
-//   64-deep systolic pipeline; the per-pixel state {T, ar[3], dL/dpixel[3], n_contrib|index} moves lane -> lane+1 with
-//   one v_mov_b32 DPP wave_shr:1 per value (no ds_bpermute, no LDS), lane 0 is fed from a 64-pixel register chunk via
-//   v_readlane + the DPP's bound-lane `old` operand.  Only pixels whose n_contrib reaches this bucket are injected (a 64-bit ballot per chunk,
+//   64-deep systolic pipeline; the evolving per-pixel state {T, ar[3], n_contrib|index} moves lane -> lane+1 with one
+//   v_mov_b32 DPP wave_shr:1 per value (no ds_bpermute), injected through the DPP's bound-lane `old` operand; the per-pixel
+//   constants (dL/dpixel) are parked in LDS per chunk and fetched with one ds_read_b128 per step.  Only pixels whose n_contrib reaches this bucket are injected (a 64-bit ballot per chunk,
 //   walked with s_ff1): pixels that terminated earlier cost no pipeline step at all.  Each lane accumulates its Gaussian's nine 2D gradients in registers and writes them
 //   ONCE to its emission slot (plain 48-byte store): no atomics — the sum over a Gaussian's tiles is a
 //   contiguous segmented reduction in preprocess_bwd_kernel, deterministic run to run.
@@ -135,14 +135,17 @@ __device__ __forceinline__ uint32_t shift_in_u(uint32_t inject, uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)inject, (int)v, 0x138, 0xf, 0xf, false);
 }
 
-// One pipeline step: hand every pixel state to the next lane (DPP wave_shr:1), put a new pixel (or an empty slot) into
-// lane 0 (the DPP's `old` operand), then let every lane whose Gaussian can have been blended into its current pixel accumulate.
-// State per pixel: T, ar[3] (= accumulated colour - final colour), dL/dpixel[3], and `tag` = n_contrib << 8 | pixel index.
-#define GS_BWD_STEP(iT, ia0, ia1, ia2, ig0, ig1, ig2, itag)                                                          \
+// One pipeline step.  The evolving part of a pixel's state {T, ar[3]} and its tag (n_contrib << 8 | pixel index) move
+// lane -> lane+1 with one DPP each; the injected values enter through the DPP's `old` operand (lane 0 has no source lane).
+// The per-pixel CONSTANTS (dL/dpixel) do not travel: the wave parks every 64-pixel chunk in LDS once (coalesced
+// ds_write_b128) and a lane fetches its current pixel's record with one ds_read_b128.  VALU is the bound of this kernel
+// (profiles/r01_sq_counters_render.md), so every value taken off the conveyor is three VALU ops saved per step.
+#define GS_BWD_STEP(inj /*float4 {T, ar0..2}*/, itag)                                                                \
     do {                                                                                                             \
-        T = shift_in_f(iT, T); ar0 = shift_in_f(ia0, ar0); ar1 = shift_in_f(ia1, ar1); ar2 = shift_in_f(ia2, ar2);   \
-        g0 = shift_in_f(ig0, g0); g1 = shift_in_f(ig1, g1); g2 = shift_in_f(ig2, g2); tag = shift_in_u(itag, tag);   \
+        T = shift_in_f((inj).x, T); ar0 = shift_in_f((inj).y, ar0); ar1 = shift_in_f((inj).z, ar1);                  \
+        ar2 = shift_in_f((inj).w, ar2); tag = shift_in_u(itag, tag);                                                 \
         if (kcmp < tag) { /* kit < n_contrib of this pixel (backward.cu:538) */                                     \
+            const float4 gr = grec[tag & 255u];                                                                      \
             const float dx = dx0 - (float)(tag & 15u);                                                               \
             const float dy = dy0 - (float)((tag >> 4) & 15u);                                                        \
             float p2 = (hA * dx) * dx;                                                                               \
@@ -155,10 +158,10 @@ __device__ __forceinline__ uint32_t shift_in_u(uint32_t inject, uint32_t v)
                 const float rinv = __builtin_amdgcn_rcpf(om);                                                        \
                 const float Ta = T * alpha;                                                                          \
                 ar0 = __builtin_fmaf(Ta, colr, ar0); ar1 = __builtin_fmaf(Ta, colg, ar1); ar2 = __builtin_fmaf(Ta, colb, ar2); \
-                acc_r = __builtin_fmaf(Ta, g0, acc_r); acc_g = __builtin_fmaf(Ta, g1, acc_g); acc_b = __builtin_fmaf(Ta, g2, acc_b); \
-                float dLda = __builtin_fmaf(rinv, ar0, colr * T) * g0;                                               \
-                dLda = __builtin_fmaf(__builtin_fmaf(rinv, ar1, colg * T), g1, dLda);                                \
-                dLda = __builtin_fmaf(__builtin_fmaf(rinv, ar2, colb * T), g2, dLda);                                \
+                acc_r = __builtin_fmaf(Ta, gr.x, acc_r); acc_g = __builtin_fmaf(Ta, gr.y, acc_g); acc_b = __builtin_fmaf(Ta, gr.z, acc_b); \
+                float dLda = __builtin_fmaf(rinv, ar0, colr * T) * gr.x;                                             \
+                dLda = __builtin_fmaf(__builtin_fmaf(rinv, ar1, colg * T), gr.y, dLda);                              \
+                dLda = __builtin_fmaf(__builtin_fmaf(rinv, ar2, colb * T), gr.z, dLda);                              \
                 T *= om;                                                                                             \
                 const float q = op * dLda; /* dL/dG */                                                               \
                 const float gdx = G * dx, gdy = G * dy;                                                              \
@@ -174,8 +177,14 @@ __device__ __forceinline__ uint32_t shift_in_u(uint32_t inject, uint32_t v)
 
 __global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a)
 {
+    // per-wave LDS: the pixel records of the whole tile (dL/dpixel, by pixel index) and the current chunk's start states
+    __shared__ float4 s_grec[4][GS_TILE_PIX];
+    __shared__ float4 s_init[4][64];
     const int lane = threadIdx.x & 63;
-    const uint32_t bucket = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int wave = threadIdx.x >> 6;
+    float4* const grec = s_grec[wave];
+    float4* const init = s_init[wave];
+    const uint32_t bucket = blockIdx.x * 4u + (uint32_t)wave;
     if (bucket >= (uint32_t)a.B) return;
     const uint32_t tile = a.bucket_to_tile[bucket];
     const uint2 range = a.ranges[tile];
@@ -211,8 +220,8 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a)
     float acc_mx = 0, acc_my = 0, acc_cx = 0, acc_cy = 0, acc_cw = 0, acc_op = 0, acc_r = 0, acc_g = 0, acc_b = 0;
     const size_t plane = (size_t)a.H * a.W;
 
-    // pixel state travelling through the lanes
-    float T = 0, ar0 = 0, ar1 = 0, ar2 = 0, g0 = 0, g1 = 0, g2 = 0;
+    // evolving pixel state travelling through the lanes
+    float T = 0, ar0 = 0, ar1 = 0, ar2 = 0;
     uint32_t tag = 0;
 
     // 64-pixel feed chunk (register double buffer: chunk c+1 is in flight while chunk c streams through)
@@ -234,24 +243,29 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a)
     load_chunk(0);
 #pragma unroll 1
     for (int c = 0; c < 4; c++) {
-        // derive this chunk's feed values, then start the next chunk's loads
+        // park this chunk in LDS, then start the next chunk's global loads
         const uint32_t ncp = inside ? __float_as_uint(pf.w) : 0u;
-        const float fT = ck.x, fa0 = ck.y - pf.x, fa1 = ck.z - pf.y, fa2 = ck.w - pf.z;
-        const float cg0 = fg0, cg1 = fg1, cg2 = fg2;
         const uint32_t ftag = (ncp << 8) | (uint32_t)(c * 64 + lane);
+        grec[c * 64 + lane] = make_float4(fg0, fg1, fg2, 0.f);
+        init[lane] = make_float4(ck.x, ck.y - pf.x, ck.z - pf.y, ck.w - pf.z);  // T, ar = checkpoint colour - final colour
         uint64_t active = __ballot(ncp > bstart);  // pixels that reach this bucket; the others contribute nothing here
         if (c < 3) load_chunk(c + 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         while (active) {
             const int sl = __builtin_ctzll(active);
             active &= active - 1;
-            GS_BWD_STEP(readlane_f(fT, sl), readlane_f(fa0, sl), readlane_f(fa1, sl), readlane_f(fa2, sl), readlane_f(cg0, sl),
-                        readlane_f(cg1, sl), readlane_f(cg2, sl), readlane_u(ftag, sl));
+            const float4 inj = init[sl];  // wave-uniform address: LDS broadcast
+            const uint32_t itag = readlane_u(ftag, sl);
+            GS_BWD_STEP(inj, itag);
         }
+        __builtin_amdgcn_wave_barrier();  // init[] is rewritten by the next chunk only after its last read above
     }
     // drain: the last injected pixel still has to pass the bucket's remaining (valid) lanes
     const int nvalid = (n - bstart) < (uint32_t)GS_BUCKET ? (int)(n - bstart) : GS_BUCKET;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
-    for (int d = 1; d < nvalid; d++) GS_BWD_STEP(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u);
+    for (int d = 1; d < nvalid; d++) GS_BWD_STEP(zero4, 0u);
 
     if (valid) {
         const float sx = -0.5f * (float)a.W, sy = -0.5f * (float)a.H;  // -(...) * ddelx_dx, ddelx_dx = 0.5 W (backward.cu:464-465)
