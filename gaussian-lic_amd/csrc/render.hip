@@ -38,58 +38,64 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
 
     const int px = tx0 + (lane & 15);
     const int pyb = ty0 + (lane >> 4);
-    const float pxf = (float)px;
-    float pyf[4], T[4], Cr[4], Cg[4], Cb[4];
+    // The sign of T carries the `done` flag (forward.cu:352,439-443): T > 0 = still blending, T < 0 = finished with
+    // transmittance |T| (T never reaches 0: blending stops below 1e-4).  One register and no flag bookkeeping per pixel.
+    float T[4], Cr[4], Cg[4], Cb[4];
     uint32_t last[4];
-    bool done[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int py = pyb + 4 * q;
-        pyf[q] = (float)py;
-        T[q] = 1.0f; Cr[q] = Cg[q] = Cb[q] = 0.0f;
+        T[q] = (px < a.W && py < a.H) ? 1.0f : -1.0f;
+        Cr[q] = Cg[q] = Cb[q] = 0.0f;
         last[q] = 0;
-        done[q] = !(px < a.W && py < a.H);
     }
+    const float LOG2E = 1.4426950408889634f;
 
     for (int base = 0; base < n; base += GS_BUCKET) {
-        if (__all(done[0] && done[1] && done[2] && done[3])) break;
+        if (__all(T[0] < 0.f && T[1] < 0.f && T[2] < 0.f && T[3] < 0.f)) break;
         if (color) {
             float4* ck = a.ckpt + ((size_t)(bbm + (uint32_t)(base / GS_BUCKET)) * GS_TILE_PIX) + lane;
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (!done[q]) ck[q * 64] = make_float4(T[q], Cr[q], Cg[q], Cb[q]);
+                if (T[q] > 0.f) ck[q * 64] = make_float4(T[q], Cr[q], Cg[q], Cb[q]);
         }
         const int m = (n - base) < GS_BUCKET ? (n - base) : GS_BUCKET;
-        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+        // each lane fetches one record and pre-scales its conic: exponent in base 2, relative to this lane-independent tile origin
+        float fdx = 0, fdy = 0, fhA = 0, fhC = 0, fnB = 0, fop = 0, fr = 0, fg = 0, fb = 0;
         if (lane < m) {
             const uint32_t g = a.point_list[range.x + (uint32_t)(base + lane)];
             const float4* rp = a.rec + 3 * (size_t)g;
-            r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
+            const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+            fdx = r0.x - (float)tx0; fdy = r0.y - (float)ty0;
+            fhA = -0.5f * LOG2E * r0.z; fnB = -LOG2E * r0.w; fhC = -0.5f * LOG2E * r1.x;
+            fop = r1.y; fr = r1.z; fg = r1.w; fb = r2.x;
         }
+        const float lx = (float)(lane & 15), ly = (float)(lane >> 4);
         for (int j = 0; j < m; j++) {
-            const float gmx = readlane_f(r0.x, j), gmy = readlane_f(r0.y, j);
-            const float cA = readlane_f(r0.z, j), cB = readlane_f(r0.w, j), cC = readlane_f(r1.x, j);
-            const float op = readlane_f(r1.y, j);
-            const float colr = readlane_f(r1.z, j), colg = readlane_f(r1.w, j), colb = readlane_f(r2.x, j);
+            const float gdx = readlane_f(fdx, j), gdy = readlane_f(fdy, j);
+            const float hA = readlane_f(fhA, j), nB = readlane_f(fnB, j), hC = readlane_f(fhC, j);
+            const float op = readlane_f(fop, j);
+            const float colr = readlane_f(fr, j), colg = readlane_f(fg, j), colb = readlane_f(fb, j);
             const uint32_t contributor = (uint32_t)(base + j + 1);
-            const float dx = gmx - pxf;
-            const float adx2 = cA * dx * dx;
-            const float bdx = cB * dx;
+            const float dx = gdx - lx;
+            const float pA = (hA * dx) * dx;   // log2(e) * (-1/2 A dx^2)
+            const float pB = nB * dx;          // log2(e) * (-B dx)
+            const float dy0 = gdy - ly;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const float dy = gmy - pyf[q];
-                const float power = -0.5f * (adx2 + cC * dy * dy) - bdx * dy;
-                const float alpha = fminf(0.99f, op * __expf(power));
-                bool ok = !done[q] && !(power > 0.0f) && !(alpha < (1.0f / 255.0f));
-                const float test_T = T[q] * (1.0f - alpha);
-                const bool stop = ok && (test_T < 0.0001f);
-                done[q] = done[q] || stop;
-                ok = ok && !stop;
-                if (ok) {
-                    const float w = alpha * T[q];
-                    Cr[q] += colr * w; Cg[q] += colg * w; Cb[q] += colb * w;
-                    T[q] = test_T;
-                    last[q] = contributor;
+                const float dy = dy0 - (float)(4 * q);
+                const float p2 = __builtin_fmaf(pB, dy, __builtin_fmaf(hC * dy, dy, pA));  // log2(e) * power
+                const float alpha = fminf(0.99f, op * __builtin_amdgcn_exp2f(p2));
+                const float test_T = T[q] * (1.0f - alpha);  // negative (so < 1e-4) once the pixel is done
+                if (!(p2 > 0.0f) && !(alpha < (1.0f / 255.0f)) && T[q] > 0.f) {
+                    if (test_T < 0.0001f) {
+                        T[q] = -T[q];  // done; this entry is NOT applied (forward.cu:438-443)
+                    } else {
+                        const float w = alpha * T[q];
+                        Cr[q] = __builtin_fmaf(colr, w, Cr[q]); Cg[q] = __builtin_fmaf(colg, w, Cg[q]); Cb[q] = __builtin_fmaf(colb, w, Cb[q]);
+                        T[q] = test_T;
+                        last[q] = contributor;
+                    }
                 }
             }
         }
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
         const int py = pyb + 4 * q;
         if (px < a.W && py < a.H) {
             const size_t pid = (size_t)py * a.W + px;
-            a.out_final_T[pid] = T[q];
+            a.out_final_T[pid] = fabsf(T[q]);
             if (color) {
                 a.out_color[pid] = Cr[q];
                 a.out_color[plane + pid] = Cg[q];
