@@ -33,7 +33,7 @@ EXPORTS = [
     "gslic_fusedssim_forward", "gslic_fusedssim_backward", "gslic_knn_mean_dist2", "gslic_abi_version",
     "gslic_last_error", "gslic_geom_bytes", "gslic_img_bytes", "gslic_binning_bytes", "gslic_sample_bytes",
     "gslic_profile_enable", "gslic_profile_reset", "gslic_profile_collect", "gslic_profile_num_kernels",
-    "gslic_profile_kernel_name", "gslic_profile_get", "gslic_debug_export",
+    "gslic_profile_kernel_name", "gslic_profile_get", "gslic_debug_export", "gslic_extend_select", "gslic_extend_emit",
 ]
 
 _lib = None
@@ -73,6 +73,9 @@ def lib():
     L.gslic_fusedssim_forward.argtypes = [i32, i32, i32, i32, f32, f32] + [vp] * 6 + [vp]
     L.gslic_fusedssim_backward.argtypes = [i32, i32, i32, i32, f32, f32] + [vp] * 7 + [vp]
     L.gslic_knn_mean_dist2.argtypes = [i32, vp, vp, ALLOC_FN, vp, vp]
+    L.gslic_extend_select.argtypes = [i32, vp, vp, vp, vp, f32, f32, f32, f32, i32, i32, vp, ALLOC_FN, vp,
+                                      ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i32), vp]
+    L.gslic_extend_emit.argtypes = [i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.gslic_debug_export.argtypes = [ctypes.POINTER(RasterParams), i32, i32] + [vp] * 4 + [vp] * 10 + [vp]
     if L.gslic_abi_version() != 1:
         raise GslicError("libgslic_hip.so ABI version mismatch")

@@ -28,6 +28,7 @@ SOURCES = {
     "adam.hip": [],
     "ssim.hip": [],
     "knn.hip": [],
+    "extend.hip": ["-ffp-contract=off"],  # pixel assignment decides integers: canonical order like preprocess.hip
 }
 COMMON = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]

@@ -29,7 +29,7 @@ static bool g_prof_cur_on = false;
 static const char* const k_names[K_COUNT] = {
     "preprocess", "scan_reduce", "scan_spine", "scan_apply", "keybuild", "sort_hist", "sort_scatter", "finalize_lists",
     "bucket_count", "render_fwd", "render_bwd", "preprocess_bwd", "adam", "ssim_fwd", "ssim_bwd", "knn_minmax", "knn_morton",
-    "knn_boxes", "knn_search", "debug_export"};
+    "knn_boxes", "knn_search", "debug_export", "extend"};
 struct ProfRec { int id; hipEvent_t a, b; };
 static std::vector<ProfRec> g_pending;
 static std::vector<hipEvent_t> g_pool;
@@ -127,6 +127,10 @@ int ssim_forward(int, int, int, int, float, float, const float*, const float*, f
 int ssim_backward(int, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*, float*,
                   hipStream_t);
 int knn_mean_dist2(int, const float*, float*, gslic_alloc_fn, void*, hipStream_t);
+int extend_select(int, const float*, const float*, const float*, const float*, float, float, float, float, int, int, const float*,
+                  gslic_alloc_fn, void*, uint32_t**, uint32_t**, int32_t*, hipStream_t);
+int extend_emit(int, const uint32_t*, const uint32_t*, const float*, const float*, const float*, float, float, int, float*, float*, float*,
+                float*, float*, float*, hipStream_t);
 
 static int check_params(const gslic_raster_params* p)
 {
@@ -377,6 +381,30 @@ int gslic_knn_mean_dist2(int32_t P, const float* points, float* mean_dists, gsli
     if (P == 0) return GSLIC_OK;
     if (!points || !mean_dists || !scratch_alloc) return set_error(GSLIC_ERR_INVALID_ARG, "knn: NULL pointer");
     return knn_mean_dist2(P, points, mean_dists, scratch_alloc, scratch_ctx, (hipStream_t)stream);
+}
+
+int gslic_extend_select(int32_t n, const float* points, const float* depths_rsp, const float* R_cw, const float* t_cw, float fx, float fy,
+                        float cx, float cy, int32_t width, int32_t height, const float* final_T, gslic_alloc_fn scratch_alloc,
+                        void* scratch_ctx, uint32_t** keep_flags, uint32_t** keep_pos, int32_t* count, void* stream)
+{
+    if (!count || !keep_flags || !keep_pos) return set_error(GSLIC_ERR_INVALID_ARG, "extend: NULL output pointer");
+    *count = 0; *keep_flags = nullptr; *keep_pos = nullptr;
+    if (n < 0 || width <= 0 || height <= 0) return set_error(GSLIC_ERR_INVALID_ARG, "extend: bad sizes");
+    if (n == 0) return GSLIC_OK;
+    if (!points || !depths_rsp || !R_cw || !t_cw || !final_T || !scratch_alloc) return set_error(GSLIC_ERR_INVALID_ARG, "extend: NULL pointer");
+    return extend_select(n, points, depths_rsp, R_cw, t_cw, fx, fy, cx, cy, width, height, final_T, scratch_alloc, scratch_ctx, keep_flags,
+                         keep_pos, count, (hipStream_t)stream);
+}
+
+int gslic_extend_emit(int32_t n, const uint32_t* keep_flags, const uint32_t* keep_pos, const float* points, const float* colors,
+                      const float* depths_rsp, float scaling_scale, float focal, int32_t M, float* xyz, float* dc, float* rest,
+                      float* opacity, float* scaling, float* rotation, void* stream)
+{
+    if (n <= 0) return GSLIC_OK;
+    if (!keep_flags || !keep_pos || !points || !colors || !depths_rsp || !xyz || !dc || !opacity || !scaling || !rotation || (M > 0 && !rest))
+        return set_error(GSLIC_ERR_INVALID_ARG, "extend emit: NULL pointer");
+    return extend_emit(n, keep_flags, keep_pos, points, colors, depths_rsp, scaling_scale, focal, M, xyz, dc, rest, opacity, scaling,
+                       rotation, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------

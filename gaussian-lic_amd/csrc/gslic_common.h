@@ -51,6 +51,7 @@ enum KernelId {
     K_KNN_BOXES,
     K_KNN_SEARCH,
     K_DEBUG_EXPORT,
+    K_EXTEND,
     K_COUNT
 };
 void prof_begin(int id, hipStream_t s);

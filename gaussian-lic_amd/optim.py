@@ -32,6 +32,15 @@ class SparseGaussianAdam:
         self.state = [None] * len(self.params)
         self.visibility, self.N = None, 0
 
+    def rebind(self, params, exp_avgs=None, exp_avg_sqs=None):
+        """Point the groups at new parameter tensors (after densificationPostfix, gaussian.cpp:426-497, re-keys the state
+        map).  Moments given by the caller replace the stored ones (they already hold the old rows + zeros for the new)."""
+        self.params = list(params)
+        for i in range(len(self.params)):
+            if exp_avgs is not None:
+                step = self.state[i]["step"] if self.state[i] else 0
+                self.state[i] = dict(step=step, exp_avg=exp_avgs[i], exp_avg_sq=exp_avg_sqs[i])
+
     def set_visibility_and_N(self, visibility, N):
         self.visibility, self.N = visibility, int(N)
 

@@ -18,14 +18,50 @@ LAMBDA_DSSIM = 0.2
 
 
 class GaussianModel:
-    """Parameters + activations of src/gaussian.{h,cpp} that the hot path touches (no map management)."""
+    """Parameters + activations of src/gaussian.{h,cpp} that the hot path touches, with capacity-doubling storage so that
+    extend() appends rows in place instead of six torch::cat reallocations of every parameter and Adam moment per keyframe
+    (densificationPostfix, gaussian.cpp:426-497)."""
 
-    def __init__(self, raw, device, lambda_erank=0.0):
+    NAMES = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")   # group order of gaussian.cpp:399-418
+
+    def __init__(self, raw, device, lambda_erank=0.0, capacity=None, scaling_scale=1.0):
         self.sh_degree = int(raw["sh_degree"])
         self.lambda_erank = float(lambda_erank)
-        mk = lambda t: t.to(device).contiguous().requires_grad_(True)
-        self.xyz, self.features_dc, self.features_rest = mk(raw["xyz"]), mk(raw["features_dc"]), mk(raw["features_rest"])
-        self.opacity, self.scaling, self.rotation = mk(raw["opacity"]), mk(raw["scaling"]), mk(raw["rotation"])
+        self.scaling_scale = float(scaling_scale)
+        self.device = device
+        self.P = int(raw["xyz"].shape[0])
+        cap = max(int(capacity or self.P), self.P)
+        self._buf, self._m, self._v = {}, {}, {}
+        for n in self.NAMES:
+            src = raw[n].to(device).float()
+            self._buf[n] = torch.empty((cap,) + tuple(src.shape[1:]), device=device)
+            self._buf[n][:self.P].copy_(src)
+            self._m[n] = torch.zeros_like(self._buf[n])
+            self._v[n] = torch.zeros_like(self._buf[n])
+        self.optimizer = None
+        self._rebind()
+
+    @property
+    def capacity(self):
+        return self._buf["xyz"].shape[0]
+
+    def _rebind(self):
+        for n in self.NAMES:
+            setattr(self, n, self._buf[n][:self.P].detach().requires_grad_(True))
+        if self.optimizer is not None:
+            self.optimizer.rebind(self.parameters(), [self._m[n][:self.P] for n in self.NAMES], [self._v[n][:self.P] for n in self.NAMES])
+
+    def _reserve(self, newP):
+        if newP <= self.capacity:
+            return
+        cap = max(2 * self.capacity, newP)
+        for d in (self._buf, self._m, self._v):
+            for n in self.NAMES:
+                old = d[n]
+                new = torch.zeros((cap,) + tuple(old.shape[1:]), device=self.device) if d is not self._buf else \
+                    torch.empty((cap,) + tuple(old.shape[1:]), device=self.device)
+                new[:self.P].copy_(old[:self.P])
+                d[n] = new
 
     # gaussian.cpp:147-175
     def get_xyz(self): return self.xyz
@@ -37,14 +73,57 @@ class GaussianModel:
 
     def parameters(self):
         """Group order of trainingSetup (gaussian.cpp:399-418)."""
-        return [self.xyz, self.features_dc, self.features_rest, self.opacity, self.scaling, self.rotation]
+        return [getattr(self, n) for n in self.NAMES]
 
     def training_setup(self, lrs=None):
         c = dict(DEFAULT_LRS)
         c.update(lrs or {})
         group_lrs = [c["position_lr"], c["feature_lr"], c["feature_lr"] / 20.0, c["opacity_lr"], c["scaling_lr"], c["rotation_lr"]]
         self.optimizer = SparseGaussianAdam(self.parameters(), group_lrs, eps=1e-15)
+        self._rebind()
         return self.optimizer
+
+    @torch.no_grad()
+    def extend(self, camera, points, colors, depths_rsp, R_cw, t_cw, intrinsics, bg=None):
+        """extend() of gaussian.cpp:499-638 for one new frame: transmittance-only render of the latest camera, GPU selection of
+        the LiDAR points that land on not-yet-opaque pixels (nearest per pixel), append of the new Gaussians (+ zero Adam moments)
+        in place.  points/colors [n,3], depths_rsp [n] on the device; R_cw [3,3], t_cw [3]; intrinsics = (fx, fy, cx, cy).
+        Returns the number of Gaussians inserted."""
+        import ctypes
+        from . import _lib
+        from .rasterizer import render
+        L = _lib.lib()
+        dev = self.device
+        bg = torch.zeros(3, device=dev) if bg is None else bg
+        _img, final_T, _pts, _vis, _radii = render(camera, self, bg, no_color=True)
+        n = int(points.shape[0])
+        fx, fy, cx, cy = (float(v) for v in intrinsics)
+        points, colors, depths_rsp = points.contiguous().float(), colors.contiguous().float(), depths_rsp.contiguous().float()
+        Rc, tc = R_cw.to(dev).float().contiguous(), t_cw.to(dev).float().contiguous()
+        scratch = _lib.TensorAllocator(dev)
+        flags, pos, count = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int32(0)
+        p = _lib.ptr
+        _lib.check(L.gslic_extend_select(n, p(points), p(depths_rsp), p(Rc), p(tc), fx, fy, cx, cy, camera.image_width, camera.image_height,
+                                         p(final_T.contiguous()), scratch.cb, None, ctypes.byref(flags), ctypes.byref(pos),
+                                         ctypes.byref(count), _lib.current_stream_ptr()))
+        k = count.value
+        if k == 0:
+            return 0
+        P0 = self.P
+        self._reserve(P0 + k)
+        M = self._buf["features_rest"].shape[1]
+        row = lambda name: ctypes.c_void_p(self._buf[name][P0:].data_ptr()) if self._buf[name][P0:].numel() else None
+        focal = (fx + fy) / 2.0
+        _lib.check(L.gslic_extend_emit(n, flags, pos, p(points), p(colors), p(depths_rsp), self.scaling_scale, focal, M, row("xyz"),
+                                       row("features_dc"), row("features_rest"), row("opacity"), row("scaling"), row("rotation"),
+                                       _lib.current_stream_ptr()))
+        for d in (self._m, self._v):       # new rows start with zero moments (gaussian.cpp:458-459)
+            for name in self.NAMES:
+                d[name][P0:P0 + k].zero_()
+        self.P = P0 + k
+        self._rebind()
+        torch.cuda.current_stream().synchronize()  # scratch (flags/pos) is released on return
+        return k
 
 
 def _dist_on():

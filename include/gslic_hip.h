@@ -209,6 +209,31 @@ int gslic_knn_mean_dist2(
     gslic_alloc_fn scratch_alloc, void* scratch_ctx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * gslic_extend_select / gslic_extend_emit — SURVEY.md §8f row 1: the device-side replacement of the point selection inside
+ * extend() (src/gaussian.cpp:536-603; CPU unordered_map<string,...> dedupe at :557-572) and of the construction of the new
+ * Gaussians' parameter rows (:605-626).  The caller renders the latest camera with no_color = 1 first (final_T, :501-507).
+ *
+ *  select: points [n,3] world, depths_rsp [n] (sensor range, :534), R_cw [9] row-major and t_cw [3] (DEVICE), intrinsics,
+ *          final_T [H,W].  A point survives iff it is the nearest (smallest camera z, lowest index on ties) of the points
+ *          falling into its pixel, the pixel is inside the image, depths_rsp > 0 and 1 - final_T < 0.99.
+ *          Returns *count (host; the call synchronises the stream once) and two device arrays inside the scratch buffer:
+ *          keep_flags [n] (0/1) and keep_pos [n] (exclusive rank among survivors, ascending point index — the reference's
+ *          order is unordered_map iteration order, i.e. unspecified).
+ *  emit:   writes `count` rows at the given row pointers (= the model's tensors offset to row P): xyz = point,
+ *          dc = (colour - 0.5)/C0, rest = 0 [M,3], opacity = inverse_sigmoid(0.1), scaling = log(scaling_scale*range/focal) x3,
+ *          rotation = (1,0,0,0).  Growing the tensors (densificationPostfix, :426-497) stays with the host.
+ */
+int gslic_extend_select(
+    int32_t n, const float* points, const float* depths_rsp, const float* R_cw, const float* t_cw,
+    float fx, float fy, float cx, float cy, int32_t width, int32_t height, const float* final_T,
+    gslic_alloc_fn scratch_alloc, void* scratch_ctx,
+    uint32_t** keep_flags, uint32_t** keep_pos, int32_t* count, void* stream);
+int gslic_extend_emit(
+    int32_t n, const uint32_t* keep_flags, const uint32_t* keep_pos, const float* points, const float* colors,
+    const float* depths_rsp, float scaling_scale, float focal, int32_t M,
+    float* xyz, float* dc, float* rest, float* opacity, float* scaling, float* rotation, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Introspection / measurement (no reference counterpart; used by bench.py and the tests).
  */
 int gslic_abi_version(void);

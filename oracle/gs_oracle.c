@@ -922,3 +922,62 @@ int orc_max_threads(void) { return omp_get_max_threads(); }
 void orc_set_threads(int n) { (void)n; }
 int orc_max_threads(void) { return 1; }
 #endif
+
+/* ================================================================================================
+ * extend() point selection (gaussian.cpp:499-617): camera-frame projection of the new LiDAR points, nearest point per
+ * pixel (the CPU unordered_map<string,...> at :557-572: smaller camera-z wins, the earlier index wins ties), then the
+ * filter of :585-603 (in image, sensor range > 0, rendered alpha = 1 - final_T < 0.99).  keep[i] = 1 for survivors.
+ * The reference appends survivors in unordered_map iteration order (unspecified); survivors are reported here by flag, and
+ * every consumer in this repository uses ascending point index.  Points whose pixel is outside the image can never pass the
+ * filter, so they are not entered into the per-pixel map (same survivors).
+ */
+void orc_extend_select(int n, const real* points, const real* depths_rsp, const real* R_cw /*[9] row-major*/, const real* t_cw,
+                       real fx, real fy, real cx, real cy, int W, int H, const real* final_T, uint8_t* keep)
+{
+    int32_t* best = (int32_t*)malloc(sizeof(int32_t) * (size_t)W * H);
+    real* bestz = (real*)malloc(sizeof(real) * (size_t)W * H);
+    int32_t* pix = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    for (size_t i = 0; i < (size_t)W * H; i++) best[i] = -1;
+    for (int i = 0; i < n; i++) {
+        const real* p = points + 3 * i;
+        real c[3];
+        for (int j = 0; j < 3; j++) c[j] = p[0] * R_cw[3 * j + 0] + p[1] * R_cw[3 * j + 1] + p[2] * R_cw[3 * j + 2] + t_cw[j];
+        const real xf = (c[0] * fx) / c[2] + cx, yf = (c[1] * fy) / c[2] + cy;
+        pix[i] = -1; keep[i] = 0;
+        const real xfl = (real)floor((double)xf), yfl = (real)floor((double)yf);
+        if (!(xfl >= 0 && xfl < (real)W && yfl >= 0 && yfl < (real)H)) continue; /* NaN / inf / outside */
+        const int id = (int)yfl * W + (int)xfl;
+        pix[i] = id;
+        if (best[id] < 0 || c[2] < bestz[id]) { best[id] = i; bestz[id] = c[2]; }
+    }
+    for (int i = 0; i < n; i++) {
+        if (pix[i] < 0 || best[pix[i]] != i) continue;
+        if (!(depths_rsp[i] > 0)) continue;
+        if (!((RC(1.) - final_T[pix[i]]) < RC(0.99))) continue;
+        keep[i] = 1;
+    }
+    free(best); free(bestz); free(pix);
+}
+
+/* New-Gaussian rows of extend() (gaussian.cpp:605-626) for the kept points, ascending index:
+ * xyz = point, dc = RGB2SH(colour) = (c - 0.5)/C0, rest = 0, scaling = log(scaling_scale * range / focal) x3,
+ * rotation = (1,0,0,0), opacity = inverse_sigmoid(0.1).  Returns the number of rows written. */
+int orc_extend_emit(int n, const uint8_t* keep, const real* points, const real* colors, const real* depths_rsp, real scaling_scale,
+                    real focal, int M, real* xyz, real* dc, real* rest, real* opacity, real* scaling, real* rotation)
+{
+    int k = 0;
+    const real op = r_log(RC(0.1) / (RC(1.) - RC(0.1)));
+    for (int i = 0; i < n; i++) {
+        if (!keep[i]) continue;
+        for (int j = 0; j < 3; j++) {
+            xyz[3 * k + j] = points[3 * i + j];
+            dc[3 * k + j] = (colors[3 * i + j] - RC(0.5)) / (real)0.28209479177387814;
+            scaling[3 * k + j] = r_log(scaling_scale * depths_rsp[i] / focal);
+        }
+        for (int j = 0; j < 3 * M; j++) rest[(size_t)3 * M * k + j] = 0;
+        opacity[k] = op;
+        rotation[4 * k] = 1; rotation[4 * k + 1] = rotation[4 * k + 2] = rotation[4 * k + 3] = 0;
+        k++;
+    }
+    return k;
+}

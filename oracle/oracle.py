@@ -188,3 +188,24 @@ class Oracle:
         out = np.zeros(pts.shape[0], self.dtype)
         self.lib.orc_knn(ctypes.c_int(pts.shape[0]), _ptr(pts), _ptr(out))
         return out
+
+    def extend_select(self, points, depths_rsp, R_cw, t_cw, fx, fy, cx, cy, W, H, final_T):
+        pts, d = self.a(points, (-1, 3)), self.a(depths_rsp).reshape(-1)
+        n = pts.shape[0]
+        keep = np.zeros(n, np.uint8)
+        r = self.real
+        self.lib.orc_extend_select(ctypes.c_int(n), _ptr(pts), _ptr(d), _ptr(self.a(R_cw).reshape(-1)), _ptr(self.a(t_cw).reshape(-1)),
+                                   r(fx), r(fy), r(cx), r(cy), ctypes.c_int(W), ctypes.c_int(H), _ptr(self.a(final_T).reshape(-1)), _ptr(keep))
+        return keep.astype(bool)
+
+    def extend_emit(self, keep, points, colors, depths_rsp, scaling_scale, focal, M):
+        pts, col, d = self.a(points, (-1, 3)), self.a(colors, (-1, 3)), self.a(depths_rsp).reshape(-1)
+        k = int(keep.sum())
+        z = lambda *s: np.zeros(s, self.dtype)
+        out = dict(xyz=z(k, 3), dc=z(k, 1, 3), rest=z(k, M, 3), opacity=z(k, 1), scaling=z(k, 3), rotation=z(k, 4))
+        r = self.real
+        kk = self.lib.orc_extend_emit(ctypes.c_int(pts.shape[0]), _ptr(np.ascontiguousarray(keep.astype(np.uint8))), _ptr(pts), _ptr(col),
+                                      _ptr(d), r(scaling_scale), r(focal), ctypes.c_int(M), _ptr(out["xyz"]), _ptr(out["dc"]),
+                                      _ptr(out["rest"]) if M > 0 else None, _ptr(out["opacity"]), _ptr(out["scaling"]), _ptr(out["rotation"]))
+        assert kk == k
+        return out

@@ -1,0 +1,98 @@
+"""extend() point selection + in-place append: oracle properties on CPU, HIP parity on GPU."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_scene, rel_err
+
+
+def _lidar_frame(n, W, H, seed, fx, fy, cx, cy):
+    """n synthetic LiDAR returns in the camera frame of the identity pose, several per pixel on purpose, a few behind/outside."""
+    rng = np.random.default_rng(seed)
+    u, v = rng.uniform(-0.1 * W, 1.1 * W, n), rng.uniform(-0.1 * H, 1.1 * H, n)
+    u[: n // 4] = np.floor(u[: n // 4] / 8) * 8 + 0.5      # pile points onto shared pixels
+    v[: n // 4] = np.floor(v[: n // 4] / 8) * 8 + 0.5
+    z = rng.uniform(1.0, 40.0, n)
+    z[rng.random(n) < 0.01] *= -1.0
+    pts = np.stack([(u - cx) * z / fx, (v - cy) * z / fy, z], 1).astype(np.float32)
+    rsp = np.where(rng.random(n) < 0.02, -1.0, np.abs(z)).astype(np.float32)
+    col = rng.random((n, 3)).astype(np.float32)
+    return pts, col, rsp
+
+
+def test_oracle_extend_select_properties(oracle32):
+    W, H, n = 96, 64, 5000
+    fx = fy = 0.675 * W
+    cx, cy = 0.4857 * W, 0.5215 * H
+    pts, col, rsp = _lidar_frame(n, W, H, 0, fx, fy, cx, cy)
+    T = np.random.default_rng(1).random((H, W)).astype(np.float32)
+    T[:, : W // 2] = 0.001                                  # left half already opaque: alpha = 0.999 >= 0.99
+    keep = oracle32.extend_select(pts, rsp, np.eye(3, dtype=np.float32), np.zeros(3, np.float32), fx, fy, cx, cy, W, H, T)
+    # brute-force restatement with a python dict, like the reference's unordered_map
+    best = {}
+    for i in range(n):
+        x, y, z = pts[i]
+        xf = np.floor(np.float32(np.float32(x * np.float32(fx)) / z) + np.float32(cx))
+        yf = np.floor(np.float32(np.float32(y * np.float32(fy)) / z) + np.float32(cy))
+        key = (float(xf), float(yf))
+        if key not in best or z < best[key][1]:
+            best[key] = (i, z)
+    want = np.zeros(n, bool)
+    for (xf, yf), (i, z) in best.items():
+        if 0 <= xf < W and 0 <= yf < H and rsp[i] > 0 and (np.float32(1.0) - T[int(yf), int(xf)]) < np.float32(0.99):
+            want[i] = True
+    np.testing.assert_array_equal(keep, want)
+    assert keep.sum() > 100
+    xs = np.floor((pts[keep, 0] * fx) / pts[keep, 2] + cx)
+    assert xs.min() >= W // 2                               # nothing lands on the opaque half
+    rows = oracle32.extend_emit(keep, pts, col, rsp, 1.0, 0.5 * (fx + fy), 15)
+    assert rows["xyz"].shape[0] == keep.sum() and np.allclose(rows["rotation"], [1, 0, 0, 0])
+    assert np.allclose(rows["opacity"], np.log(0.1 / 0.9)) and float(np.abs(rows["rest"]).max()) == 0.0
+    assert np.allclose(rows["dc"][:, 0], (col[keep] - 0.5) / 0.28209479177387814, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_extend_matches_oracle_and_appends_in_place(oracle32):
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import trainer
+    from gaussian_lic_amd.rasterizer import render
+    from gaussian_lic_amd.synthetic import gt_image
+    W, H, P, n = 320, 240, 2000, 30000   # sparse model: most pixels are still transparent
+    raw, sc, camd, cam = make_scene("random", P, W, H, 3, 51)
+    dev = torch.device("cuda:0")
+    cam.to_device(dev)
+    model = trainer.GaussianModel(raw, dev)              # capacity == P: the append must grow the storage
+    model.training_setup()
+    bg = torch.zeros(3, device=dev)
+    gt = gt_image(H, W).to(dev)
+    for _ in range(2):
+        trainer.training_step(model, cam, gt, bg)        # non-trivial Adam moments before the append
+    before = {k: getattr(model, k).detach().clone() for k in model.NAMES}
+    m_before = [s["exp_avg"].clone() for s in model.optimizer.state]
+    fx, fy, cx, cy = float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy)
+    pts, col, rsp = _lidar_frame(n, W, H, 3, fx, fy, cx, cy)
+    with torch.no_grad():
+        final_T = render(cam, model, bg, no_color=True)[1].cpu().numpy()
+    k = model.extend(cam, torch.from_numpy(pts).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(rsp).to(dev),
+                     torch.eye(3), torch.zeros(3), (fx, fy, cx, cy))
+    keep = oracle32.extend_select(pts, rsp, np.eye(3, dtype=np.float32), np.zeros(3, np.float32), fx, fy, cx, cy, W, H, final_T)
+    assert k == int(keep.sum()) and k > 1000
+    rows = oracle32.extend_emit(keep, pts, col, rsp, 1.0, 0.5 * (fx + fy), 15)
+    assert model.P == P + k and model.capacity >= P + k
+    for name, key in (("xyz", "xyz"), ("features_dc", "dc"), ("features_rest", "rest"), ("opacity", "opacity"), ("scaling", "scaling"),
+                      ("rotation", "rotation")):
+        t = getattr(model, name).detach()
+        assert torch.equal(t[:P], before[name]), name                              # old rows untouched
+        got = t[P:].cpu().numpy()
+        if name in ("xyz", "features_rest", "rotation"):
+            np.testing.assert_array_equal(got, rows[key].reshape(got.shape))       # exact: copies / constants, ascending order
+        else:
+            assert rel_err(got, rows[key].reshape(got.shape)) < 1e-6, name
+    for s, mb in zip(model.optimizer.state, m_before):                             # moments: old rows kept, new rows zero
+        assert torch.equal(s["exp_avg"][:P], mb) and float(s["exp_avg"][P:].abs().max()) == 0.0
+        assert s["exp_avg"].shape[0] == P + k and float(s["exp_avg_sq"][P:].abs().max()) == 0.0
+    loss, vis = trainer.training_step(model, cam, gt, bg)                          # the grown model trains
+    assert vis.shape[0] == P + k and torch.isfinite(loss)
+    k2 = model.extend(cam, torch.from_numpy(pts).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(rsp).to(dev),
+                      torch.eye(3), torch.zeros(3), (fx, fy, cx, cy))
+    assert 0 <= k2 < k                                                              # pixels covered by the new Gaussians reject more points
