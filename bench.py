@@ -65,7 +65,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="random", choices=["random", "lidar"])
-    ap.add_argument("--mode", default="train", choices=["train", "render"], help="train = fwd+loss+bwd+Adam; render = bare fwd+bwd")
+    ap.add_argument("--mode", default="train", choices=["train", "render", "slam"],
+                    help="train = fwd+loss+bwd+Adam; render = bare fwd+bwd; slam = train with extend() appends every 20 steps "
+                         "(SURVEY config 3 instance: starts at 75 %% of --gaussians, +5 %% LiDAR points per append)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every kernel inside the timed region (adds overhead)")
     args = ap.parse_args()
@@ -88,7 +90,10 @@ def main():
 
     W, H, P = args.width, args.height, args.gaussians
     raw = (random_scene if args.scene == "random" else lidar_scene)(P, W, H, sh_degree=3, seed=0)
-    model = trainer.GaussianModel(raw, dev)
+    if args.mode == "slam":   # start at 75 % and let extend() grow the map
+        P0 = (3 * P) // 4
+        raw = {k: (v[:P0].contiguous() if torch.is_tensor(v) else v) for k, v in raw.items()}
+    model = trainer.GaussianModel(raw, dev, capacity=P if args.mode == "slam" else None)
     model.training_setup()
     cam = synthetic_camera(W, H, None if world == 1 else rank % 8).to_device(dev)
     gt = gt_image(H, W, seed=2 + rank).to(dev)
@@ -100,8 +105,25 @@ def main():
     slab = torch.empty(int(min(24, 6 + 10 * P / 2e6)) << 30, dtype=torch.uint8, device=dev)
     del slab
 
+    slam = dict(it=0, inserted=0, ms=0.0, calls=0)
+    if args.mode == "slam":
+        frame = lidar_scene(P // 20, W, H, sh_degree=3, seed=100)   # one LiDAR frame in the camera's view: 5 % of the map size
+        f_pts = frame["xyz"].to(dev)
+        f_col = (frame["features_dc"].reshape(-1, 3) * 0.28209479177387814 + 0.5).to(dev)
+        f_rsp = frame["xyz"][:, 2].contiguous().to(dev)
+        Rcw = torch.from_numpy(cam.world_view_transform[:3, :3].T.copy())
+        tcw = torch.from_numpy(cam.world_view_transform[3, :3].copy())
+
     def step():
-        if args.mode == "train":
+        if args.mode == "slam":
+            slam["it"] += 1
+            if slam["it"] % 20 == 0:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                slam["inserted"] += model.extend(cam, f_pts, f_col, f_rsp, Rcw, tcw, (float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy)))
+                e1.record(); e1.synchronize()
+                slam["ms"] += e0.elapsed_time(e1); slam["calls"] += 1
+        if args.mode in ("train", "slam"):
             return trainer.training_step(model, cam, gt, bg)[1]
         return trainer.render_fwd_bwd(model, cam, dL, bg)
 
@@ -156,6 +178,7 @@ def main():
                                         rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, rs.limx_neg, rs.limx_pos,
                                         rs.limy_neg, rs.limy_pos, model.get_features_dc(), model.get_features_rest(), 3, rs.campos,
                                         False, False, False)[:2]
+    P = model.P
     stats = dict(P=P, V=int(visible.sum().item()), R=int(Rn), B=int(Bn), N=W * H, T=((W + 15) // 16) * ((H + 15) // 16), K=16)
 
     if rank != 0:
@@ -203,12 +226,15 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE config 3: {P} Gaussians ({args.scene} scene, seed 0), {W}x{H}, SH degree 3, "
                                + ("render fwd + 0.8*L1+0.2*(1-fused-SSIM) + bwd + sparse Adam per view"
-                                  if args.mode == "train" else "bare render fwd+bwd per view")
+                                  if args.mode in ("train", "slam") else "bare render fwd+bwd per view")
+                               + ("; extend() append of a LiDAR frame every 20 steps, timed" if args.mode == "slam" else "")
                                + ("" if world == 1 else f"; {world} views/step, one gradient all-reduce per step"),
                    "mode": args.mode, "parallelism": f"dp{world}" if world > 1 else "single",
                    "visible": stats["V"], "instances_R": stats["R"], "buckets_B": stats["B"]},
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "extend": None if args.mode != "slam" else {"calls": slam["calls"], "inserted": slam["inserted"], "final_gaussians": model.P,
+                                                    "ms_per_call": round(slam["ms"] / max(slam["calls"], 1), 3)},
         "kernel_ms_per_step": {k: round(v[0] / max(nprof, 1), 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
     }
     print(json.dumps(out), flush=True)

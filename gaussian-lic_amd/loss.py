@@ -65,3 +65,42 @@ def psnr(img1, img2):
     """loss_utils.h:35-39."""
     mse = torch.pow(img1 - img2, 2).mean()
     return 10.0 * torch.log10(1.0 / mse)
+
+
+def _gaussian_window(window_size, sigma, channel, like):
+    """gaussian() + create_window() of loss_utils.h:41-74 (float math like the reference)."""
+    import math
+    g = torch.tensor([math.exp(-((x - window_size // 2) ** 2) / (2.0 * sigma * sigma)) for x in range(window_size)], dtype=torch.float32)
+    g = (g / g.sum()).unsqueeze(1)
+    w2 = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
+    return w2.expand(channel, 1, window_size, window_size).contiguous().to(like.device).type_as(like)
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """Evaluation SSIM — loss_utils.h:80-128 (conv2d with an 11x11 Gaussian window, zero padding); used by
+    evaluateVisualQuality (gaussian.cpp:721-831).  LibTorch conv2d stays the host's op, exactly as in the reference."""
+    channel = img1.size(-3)
+    window = _gaussian_window(window_size, 1.5, channel, img1)
+    pad = window_size // 2
+    conv = lambda x: torch.nn.functional.conv2d(x, window, padding=pad, groups=channel)
+    mu1, mu2 = conv(img1), conv(img2)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = conv(img1 * img1) - mu1_sq
+    sigma2_sq = conv(img2 * img2) - mu2_sq
+    sigma12 = conv(img1 * img2) - mu1_mu2
+    c1, c2 = 0.01 * 0.01, 0.03 * 0.03
+    ssim_map = ((2 * mu1_mu2 + c1) * (2 * sigma12 + c2)) / ((mu1_sq + mu2_sq + c1) * (sigma1_sq + sigma2_sq + c2))
+    return ssim_map.mean() if size_average else ssim_map.mean(1).mean(1).mean(1)
+
+
+def evaluate_visual_quality(model, cameras, gt_images, bg):
+    """PSNR / SSIM over a set of views — the metric part of evaluateVisualQuality (gaussian.cpp:751-789): render, clamp to [0,1],
+    psnr + conv-SSIM per image, averaged.  (LPIPS needs the TorchScript AlexNet blob the reference does not ship.)"""
+    from .rasterizer import render
+    ps, ss = [], []
+    with torch.no_grad():
+        for cam, gt in zip(cameras, gt_images):
+            img = torch.clamp(render(cam, model, bg)[0], 0.0, 1.0)
+            ps.append(psnr(img, gt))
+            ss.append(ssim(img.unsqueeze(0), gt.unsqueeze(0)))
+    return torch.stack(ps).mean(), torch.stack(ss).mean()

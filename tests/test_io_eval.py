@@ -1,0 +1,51 @@
+"""CPU: PLY wire format of saveMap and the evaluation metrics of loss_utils.h (row 4)."""
+import numpy as np
+import torch
+
+from conftest import rel_err
+
+
+class _M:
+    pass
+
+
+def test_ply_roundtrip_and_layout(tmp_path):
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import io_ply
+    from gaussian_lic_amd.synthetic import random_scene
+    raw = random_scene(257, 64, 48, 3, 7)
+    m = _M()
+    for k in ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation"):
+        setattr(m, k, raw[k])
+    path = str(tmp_path / "point_cloud.ply")
+    n = io_ply.save_map(m, path, skybox_points_num=7)
+    assert n == 250
+    blob = open(path, "rb").read()
+    head, body = blob.split(b"end_header\n", 1)
+    lines = head.decode().strip().split("\n")
+    assert lines[:3] == ["ply", "format binary_little_endian 1.0", "element vertex 250"]
+    props = [l.split()[2] for l in lines[3:]]
+    assert props == ["x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{i}" for i in range(45)] + ["opacity", "scale_0", "scale_1",
+                                                                                                          "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+    assert len(body) == 250 * 59 * 4
+    row0 = np.frombuffer(body[:59 * 4], "<f4")
+    np.testing.assert_array_equal(row0[:3], raw["xyz"][7].numpy())
+    # f_rest is channel-major: f_rest_0..14 = all 15 coefficients of channel 0 (gaussian.cpp:312-313)
+    np.testing.assert_array_equal(row0[6:6 + 15], raw["features_rest"][7, :, 0].numpy())
+    np.testing.assert_array_equal(row0[6 + 15:6 + 30], raw["features_rest"][7, :, 1].numpy())
+    back = io_ply.load_map(path)
+    for k in ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation"):
+        assert torch.equal(back[k], raw[k][7:]), k
+    assert back["sh_degree"] == 3
+
+
+def test_eval_ssim_and_psnr_match_oracle(oracle32):
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import loss
+    rng = np.random.default_rng(0)
+    a, b = rng.random((1, 3, 40, 56)).astype(np.float32), rng.random((1, 3, 40, 56)).astype(np.float32)
+    s = loss.ssim(torch.from_numpy(a), torch.from_numpy(b))
+    m = oracle32.ssim_forward(a, b, train=False)[0]
+    assert abs(float(s) - float(m.mean())) < 2e-5
+    p = loss.psnr(torch.from_numpy(a), torch.from_numpy(b))
+    assert abs(float(p) - 10 * np.log10(1.0 / ((a - b) ** 2).mean())) < 1e-4
