@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "render", "slam"],
                     help="train = fwd+loss+bwd+Adam; render = bare fwd+bwd; slam = train with extend() appends every 20 steps "
                          "(SURVEY config 3 instance: starts at 75 %% of --gaussians, +5 %% LiDAR points per append)")
+    ap.add_argument("--host", default="fused", choices=["fused", "dropin"],
+                    help="fused = the framework's own step on the fused entry points (activations + loss inside the kernels, no autograd "
+                         "graph); dropin = the reference's operator API + LibTorch autograd, i.e. what an unmodified reference host runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every kernel inside the timed region (adds overhead)")
     args = ap.parse_args()
@@ -105,6 +108,7 @@ def main():
     slab = torch.empty(int(min(24, 6 + 10 * P / 2e6)) << 30, dtype=torch.uint8, device=dev)
     del slab
 
+    host = dict(mode=args.host)
     slam = dict(it=0, inserted=0, ms=0.0, calls=0)
     if args.mode == "slam":
         frame = lidar_scene(P // 20, W, H, sh_degree=3, seed=100)   # one LiDAR frame in the camera's view: 5 % of the map size
@@ -124,6 +128,8 @@ def main():
                 e1.record(); e1.synchronize()
                 slam["ms"] += e0.elapsed_time(e1); slam["calls"] += 1
         if args.mode in ("train", "slam"):
+            if host["mode"] == "fused":
+                return trainer.training_step_fused(model, cam, gt, bg)[1]
             return trainer.training_step(model, cam, gt, bg)[1]
         return trainer.render_fwd_bwd(model, cam, dL, bg)
 
@@ -161,6 +167,24 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(dt.item())
+
+    # ---- the same K steps through the other host path (reported next to `value`, not part of it)
+    other = None
+    if args.mode == "train":
+        host["mode"] = "dropin" if args.host == "fused" else "fused"
+        for _ in range(3):
+            step()
+        sync_all()
+        o0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync_all()
+        odt = torch.tensor([time.perf_counter() - o0], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(odt, op=torch.distributed.ReduceOp.MAX)
+        other = {"host": host["mode"], "value": round(args.steps * world / float(odt.item()), 3), "unit": "views/s",
+                 "ms_per_step": round(1e3 * float(odt.item()) / args.steps, 3)}
+        host["mode"] = args.host
 
     # ---- unit counts of this workload (one extra forward, untimed)
     with torch.no_grad():
@@ -227,12 +251,15 @@ def main():
         "config": {"workload": f"BASELINE config 3: {P} Gaussians ({args.scene} scene, seed 0), {W}x{H}, SH degree 3, "
                                + ("render fwd + 0.8*L1+0.2*(1-fused-SSIM) + bwd + sparse Adam per view"
                                   if args.mode in ("train", "slam") else "bare render fwd+bwd per view")
+                               + (" (fused entry points: activations and loss inside the kernels)" if args.host == "fused" and args.mode != "render"
+                                  else " (reference operator API + LibTorch autograd)")
                                + ("; extend() append of a LiDAR frame every 20 steps, timed" if args.mode == "slam" else "")
                                + ("" if world == 1 else f"; {world} views/step, one gradient all-reduce per step"),
-                   "mode": args.mode, "parallelism": f"dp{world}" if world > 1 else "single",
+                   "mode": args.mode, "host": args.host if args.mode != "render" else "dropin", "parallelism": f"dp{world}" if world > 1 else "single",
                    "visible": stats["V"], "instances_R": stats["R"], "buckets_B": stats["B"]},
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "other_host_path": other,
         "extend": None if args.mode != "slam" else {"calls": slam["calls"], "inserted": slam["inserted"], "final_gaussians": model.P,
                                                     "ms_per_call": round(slam["ms"] / max(slam["calls"], 1), 3)},
         "kernel_ms_per_step": {k: round(v[0] / max(nprof, 1), 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},

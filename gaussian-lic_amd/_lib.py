@@ -20,7 +20,7 @@ class RasterParams(ctypes.Structure):
                 ("height", ctypes.c_int32), ("tan_fovx", ctypes.c_float), ("tan_fovy", ctypes.c_float),
                 ("limx_neg", ctypes.c_float), ("limx_pos", ctypes.c_float), ("limy_neg", ctypes.c_float),
                 ("limy_pos", ctypes.c_float), ("scale_modifier", ctypes.c_float), ("prefiltered", ctypes.c_int32),
-                ("debug", ctypes.c_int32), ("no_color", ctypes.c_int32)]
+                ("debug", ctypes.c_int32), ("no_color", ctypes.c_int32), ("raw_params", ctypes.c_int32)]
 
 
 class AdamGroup(ctypes.Structure):
@@ -33,7 +33,8 @@ EXPORTS = [
     "gslic_fusedssim_forward", "gslic_fusedssim_backward", "gslic_knn_mean_dist2", "gslic_abi_version",
     "gslic_last_error", "gslic_geom_bytes", "gslic_img_bytes", "gslic_binning_bytes", "gslic_sample_bytes",
     "gslic_profile_enable", "gslic_profile_reset", "gslic_profile_collect", "gslic_profile_num_kernels",
-    "gslic_profile_kernel_name", "gslic_profile_get", "gslic_debug_export", "gslic_extend_select", "gslic_extend_emit",
+    "gslic_profile_kernel_name", "gslic_profile_get", "gslic_debug_export", "gslic_extend_select", "gslic_extend_emit", "gslic_loss_partials_count", "gslic_l1_ssim_loss_forward",
+    "gslic_l1_ssim_loss_backward",
 ]
 
 _lib = None
@@ -77,7 +78,11 @@ def lib():
                                       ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i32), vp]
     L.gslic_extend_emit.argtypes = [i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.gslic_debug_export.argtypes = [ctypes.POINTER(RasterParams), i32, i32] + [vp] * 4 + [vp] * 10 + [vp]
-    if L.gslic_abi_version() != 1:
+    L.gslic_loss_partials_count.restype = ctypes.c_int64
+    L.gslic_loss_partials_count.argtypes = [i32, i32, i32, i32]
+    L.gslic_l1_ssim_loss_forward.argtypes = [i32, i32, i32, i32, f32, f32] + [vp] * 7 + [vp]
+    L.gslic_l1_ssim_loss_backward.argtypes = [i32, i32, i32, i32, f32] + [vp] * 6 + [vp]
+    if L.gslic_abi_version() != 2:
         raise GslicError("libgslic_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -127,6 +127,9 @@ int ssim_forward(int, int, int, int, float, float, const float*, const float*, f
 int ssim_backward(int, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*, float*,
                   hipStream_t);
 int knn_mean_dist2(int, const float*, float*, gslic_alloc_fn, void*, hipStream_t);
+int loss_forward(int, int, int, int, float, float, const float*, const float*, float*, float*, float*, float*, float*, hipStream_t);
+int loss_backward(int, int, int, int, float, const float*, const float*, const float*, const float*, const float*, float*, hipStream_t);
+int64_t loss_partials_count(int, int, int, int);
 int extend_select(int, const float*, const float*, const float*, const float*, float, float, float, float, int, int, const float*,
                   gslic_alloc_fn, void*, uint32_t**, uint32_t**, int32_t*, hipStream_t);
 int extend_emit(int, const uint32_t*, const uint32_t*, const float*, const float*, const float*, float, float, int, float*, float*, float*,
@@ -214,7 +217,7 @@ int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_
     pa.focal_y = prm->height / (2.0f * prm->tan_fovy);  // rasterizer_impl.cu:348-349
     pa.focal_x = prm->width / (2.0f * prm->tan_fovx);
     pa.limx_neg = prm->limx_neg; pa.limx_pos = prm->limx_pos; pa.limy_neg = prm->limy_neg; pa.limy_pos = prm->limy_pos;
-    pa.scale_modifier = prm->scale_modifier; pa.prefiltered = prm->prefiltered; pa.no_color = prm->no_color;
+    pa.scale_modifier = prm->scale_modifier; pa.prefiltered = prm->prefiltered; pa.no_color = prm->no_color; pa.raw = prm->raw_params;
     pa.means = means3D; pa.scales = scales; pa.rots = rotations; pa.opac = opacities; pa.dc = dc; pa.shs = shs;
     pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = cam_pos;
     pa.radii = radii; pa.rec = geom.rec; pa.tiles_touched = geom.tiles_touched; pa.flags = geom.flags;
@@ -317,7 +320,7 @@ int gslic_rasterize_backward(const gslic_raster_params* prm, int32_t R, int32_t 
     DEBUG_SYNC(prm, s);
 
     PreprocessBwdArgs pb;
-    pb.P = P; pb.D = prm->D; pb.M = prm->M; pb.W = prm->width; pb.H = prm->height;
+    pb.P = P; pb.D = prm->D; pb.M = prm->M; pb.W = prm->width; pb.H = prm->height; pb.raw = prm->raw_params;
     pb.focal_y = prm->height / (2.0f * prm->tan_fovy);
     pb.focal_x = prm->width / (2.0f * prm->tan_fovx);
     pb.limx_neg = prm->limx_neg; pb.limx_pos = prm->limx_pos; pb.limy_neg = prm->limy_neg; pb.limy_pos = prm->limy_pos;
@@ -372,6 +375,28 @@ int gslic_fusedssim_backward(int32_t B, int32_t CH, int32_t H, int32_t W, float 
     if (!img1 || !img2 || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1)
         return set_error(GSLIC_ERR_INVALID_ARG, "ssim backward: NULL tensor pointer");
     return ssim_backward(B, CH, H, W, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1, (hipStream_t)stream);
+}
+
+int64_t gslic_loss_partials_count(int32_t B, int32_t CH, int32_t H, int32_t W)
+{
+    return (B <= 0 || CH <= 0 || H <= 0 || W <= 0) ? 8 : loss_partials_count(B, CH, H, W);
+}
+
+int gslic_l1_ssim_loss_forward(int32_t B, int32_t CH, int32_t H, int32_t W, float C1, float C2, const float* img, const float* gt,
+                               float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, float* partials, float* terms, void* stream)
+{
+    if (B <= 0 || CH <= 0 || H <= 0 || W <= 0) return set_error(GSLIC_ERR_INVALID_ARG, "loss: empty image");
+    if (!img || !gt || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !partials || !terms)
+        return set_error(GSLIC_ERR_INVALID_ARG, "loss forward: NULL pointer");
+    return loss_forward(B, CH, H, W, C1, C2, img, gt, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, partials, terms, (hipStream_t)stream);
+}
+
+int gslic_l1_ssim_loss_backward(int32_t B, int32_t CH, int32_t H, int32_t W, float lambda_dssim, const float* img, const float* gt,
+                                const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg, void* stream)
+{
+    if (B <= 0 || CH <= 0 || H <= 0 || W <= 0) return set_error(GSLIC_ERR_INVALID_ARG, "loss: empty image");
+    if (!img || !gt || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg) return set_error(GSLIC_ERR_INVALID_ARG, "loss backward: NULL pointer");
+    return loss_backward(B, CH, H, W, lambda_dssim, img, gt, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg, (hipStream_t)stream);
 }
 
 int gslic_knn_mean_dist2(int32_t P, const float* points, float* mean_dists, gslic_alloc_fn scratch_alloc, void* scratch_ctx,

@@ -8,7 +8,7 @@ struct PreprocessArgs {
     int P, D, M, W, H, gx, gy;
     float focal_x, focal_y;
     float limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier;
-    int prefiltered, no_color;
+    int prefiltered, no_color, raw;
     const float *means, *scales, *rots, *opac, *dc, *shs, *view, *proj, *campos;
     int32_t* radii;
     float4* rec;
@@ -63,7 +63,7 @@ struct RenderBwdArgs {
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
 
 struct PreprocessBwdArgs {
-    int P, D, M, W, H;
+    int P, D, M, W, H, raw;
     float focal_x, focal_y;
     float limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier, lambda_erank;
     const float *means, *scales, *rots, *dc, *shs, *view, *proj, *campos;

@@ -75,13 +75,18 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a)
         const float projx = hx * pw, projy = hy * pw;
 
         // computeCov3D (forward.cu:120-149)
-        const float qr = a.rots[4 * idx], qx = a.rots[4 * idx + 1], qy = a.rots[4 * idx + 2], qz = a.rots[4 * idx + 3];
+        float qr = a.rots[4 * idx], qx = a.rots[4 * idx + 1], qy = a.rots[4 * idx + 2], qz = a.rots[4 * idx + 3];
+        float sc0 = a.scales[3 * idx], sc1 = a.scales[3 * idx + 1], sc2 = a.scales[3 * idx + 2];
+        if (a.raw) {  // activations of gaussian.cpp:147-175: exp(scaling_), normalize(rotation_) (eps 1e-12)
+            sc0 = expf(sc0); sc1 = expf(sc1); sc2 = expf(sc2);
+            const float nrm = fmax_c(sqrtf(qr * qr + qx * qx + qy * qy + qz * qz), 1e-12f);
+            qr = qr / nrm; qx = qx / nrm; qy = qy / nrm; qz = qz / nrm;
+        }
         float Rm[3][3];
         Rm[0][0] = 1.f - 2.f * (qy * qy + qz * qz); Rm[0][1] = 2.f * (qx * qy - qr * qz); Rm[0][2] = 2.f * (qx * qz + qr * qy);
         Rm[1][0] = 2.f * (qx * qy + qr * qz); Rm[1][1] = 1.f - 2.f * (qx * qx + qz * qz); Rm[1][2] = 2.f * (qy * qz - qr * qx);
         Rm[2][0] = 2.f * (qx * qz - qr * qy); Rm[2][1] = 2.f * (qy * qz + qr * qx); Rm[2][2] = 1.f - 2.f * (qx * qx + qy * qy);
-        const float s[3] = {a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
-                            a.scale_modifier * a.scales[3 * idx + 2]};
+        const float s[3] = {a.scale_modifier * sc0, a.scale_modifier * sc1, a.scale_modifier * sc2};
         float Mk[3][3];
 #pragma unroll
         for (int k = 0; k < 3; k++)
@@ -121,6 +126,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a)
 
         const float det = cov0 * cov2 - cov1 * cov1;
         op = a.opac[idx];
+        if (a.raw) op = 1.0f / (1.0f + expf(-op));  // sigmoid(opacity_)
         if (det == 0.0f || op < (1.0f / 255.0f)) {
             active = false;
         } else {

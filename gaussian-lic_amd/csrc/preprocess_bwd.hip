@@ -145,12 +145,18 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
     const float mx3 = a.means[3 * idx], my3 = a.means[3 * idx + 1], mz3 = a.means[3 * idx + 2];
 
     // ---- Sigma_3D from scale / rotation (forward.cu:120-149) ----
-    const float qr = a.rots[4 * idx], qx = a.rots[4 * idx + 1], qy = a.rots[4 * idx + 2], qz = a.rots[4 * idx + 3];
+    float qr = a.rots[4 * idx], qx = a.rots[4 * idx + 1], qy = a.rots[4 * idx + 2], qz = a.rots[4 * idx + 3];
+    const float4 qraw = make_float4(qr, qx, qy, qz);
+    if (a.raw) {
+        const float nrm = fmaxf(sqrtf(qr * qr + qx * qx + qy * qy + qz * qz), 1e-12f);
+        qr = qr / nrm; qx = qx / nrm; qy = qy / nrm; qz = qz / nrm;
+    }
     float Rm[3][3];
     Rm[0][0] = 1.f - 2.f * (qy * qy + qz * qz); Rm[0][1] = 2.f * (qx * qy - qr * qz); Rm[0][2] = 2.f * (qx * qz + qr * qy);
     Rm[1][0] = 2.f * (qx * qy + qr * qz); Rm[1][1] = 1.f - 2.f * (qx * qx + qz * qz); Rm[1][2] = 2.f * (qy * qz - qr * qx);
     Rm[2][0] = 2.f * (qx * qz - qr * qy); Rm[2][1] = 2.f * (qy * qz + qr * qx); Rm[2][2] = 1.f - 2.f * (qx * qx + qy * qy);
-    const float sc[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+    float sc[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+    if (a.raw) { sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]); }
     const float s[3] = {a.scale_modifier * sc[0], a.scale_modifier * sc[1], a.scale_modifier * sc[2]};
     float Mk[3][3];  // Mk[k][c] = s_k * Rm[c][k]  (= glm M[c][k])
 #pragma unroll
@@ -325,6 +331,23 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
             dscale[2] += le * sc[2] * (-d1 * s1s1 - d2 * s2s2 + d3 * (s1s1 + s2s2));
         }
         dscale[2] += 1;
+    }
+    if (a.raw) {
+        // chain through the activations, as LibTorch autograd does outside the reference's kernels (gaussian.cpp:147-175):
+        // d exp = s; d sigmoid = o (1 - o); d normalize = dnormvdv (auxiliary.h:131-143)
+        dscale[0] *= sc[0]; dscale[1] *= sc[1]; dscale[2] *= sc[2];
+        const float o = a.rec[3 * (size_t)idx + 1].y;
+        a.dL_dopacity[idx] = s_op * o * (1.0f - o);
+        const float sum2 = qraw.x * qraw.x + qraw.y * qraw.y + qraw.z * qraw.z + qraw.w * qraw.w;
+        const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        const float vd0 = qraw.x * dq.x, vd1 = qraw.y * dq.y, vd2 = qraw.z * dq.z, vd3 = qraw.w * dq.w;
+        const float vds = vd0 + vd1 + vd2 + vd3;
+        float4 dr;
+        dr.x = ((sum2 - qraw.x * qraw.x) * dq.x - qraw.x * (vds - vd0)) * invsum32;
+        dr.y = ((sum2 - qraw.y * qraw.y) * dq.y - qraw.y * (vds - vd1)) * invsum32;
+        dr.z = ((sum2 - qraw.z * qraw.z) * dq.z - qraw.z * (vds - vd2)) * invsum32;
+        dr.w = ((sum2 - qraw.w * qraw.w) * dq.w - qraw.w * (vds - vd3)) * invsum32;
+        dq = dr;
     }
     a.dL_dscale[3 * idx] = dscale[0]; a.dL_dscale[3 * idx + 1] = dscale[1]; a.dL_dscale[3 * idx + 2] = dscale[2];
     reinterpret_cast<float4*>(a.dL_drot)[idx] = dq;

@@ -143,6 +143,179 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Loss of optimize() (gaussian.cpp:685-691) with l1_loss (loss_utils.h:30-33) folded into the SSIM passes.
+// loss_fwd_kernel = ssim_fwd_kernel without the ssim_map store, plus per-block sums of |a-b| and of the SSIM values;
+// loss_reduce_kernel adds the per-block partials in a fixed order (bit-reproducible, no float atomics).
+__device__ __forceinline__ float block256_sum(float v, float* red /*[4]*/)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void loss_fwd_kernel(int H, int W, float C1, float C2, const float* __restrict__ img1,
+                                                       const float* __restrict__ img2, float* __restrict__ dm_dmu1,
+                                                       float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12,
+                                                       float* __restrict__ partials)
+{
+    __shared__ float sa[SH_][SH_];
+    __shared__ float sb[SH_][SH_];
+    __shared__ float hs[5][SH_][ST];
+    __shared__ float red[4];
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const float* a = img1 + plane;
+    const float* b = img2 + plane;
+    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < SH_ * SH_; t += 256) {
+        const int ly = t / SH_, lx = t % SH_;
+        sa[ly][lx] = pix_or_zero(a, H, W, y0 + ly - 5, x0 + lx - 5);
+        sb[ly][lx] = pix_or_zero(b, H, W, y0 + ly - 5, x0 + lx - 5);
+    }
+    __syncthreads();
+    for (int t = tid; t < SH_ * ST; t += 256) {
+        const int ly = t / ST, lx = t % ST;
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+            const float pa = sa[ly][lx + i], pb = sb[ly][lx + i];
+            const float g = c_G[i];
+            r0 += g * pa; r1 += g * (pa * pa); r2 += g * pb; r3 += g * (pb * pb); r4 += g * (pa * pb);
+        }
+        hs[0][ly][lx] = r0; hs[1][ly][lx] = r1; hs[2][ly][lx] = r2; hs[3][ly][lx] = r3; hs[4][ly][lx] = r4;
+    }
+    __syncthreads();
+    const int lx = tid & 31;
+    float sum_l1 = 0.f, sum_ssim = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int ly = (tid >> 5) + 8 * q;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 11; j++) {
+            const float g = c_G[j];
+            v0 += g * hs[0][ly + j][lx]; v1 += g * hs[1][ly + j][lx]; v2 += g * hs[2][ly + j][lx];
+            v3 += g * hs[3][ly + j][lx]; v4 += g * hs[4][ly + j][lx];
+        }
+        const int px = x0 + lx, py = y0 + ly;
+        if (px < W && py < H) {
+            const float mu1 = v0, mu2 = v2;
+            const float sigma1_sq = v1 - mu1 * mu1;
+            const float sigma2_sq = v3 - mu2 * mu2;
+            const float sigma12 = v4 - mu1 * mu2;
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu1_mu2 = mu1 * mu2;
+            const float C = (2.0f * mu1_mu2 + C1);
+            const float D = (2.0f * sigma12 + C2);
+            const float A = (mu1_sq + mu2_sq + C1);
+            const float B = (sigma1_sq + sigma2_sq + C2);
+            const size_t o = plane + (size_t)py * W + px;
+            sum_ssim += (C * D) / (A * B);
+            sum_l1 += fabsf(sa[ly + 5][lx + 5] - sb[ly + 5][lx + 5]);
+            dm_dmu1[o] = ((mu2 * 2.0f * D) / (A * B) - (mu2 * 2.0f * C) / (A * B) - (mu1 * 2.0f * C * D) / (A * A * B) +
+                          (mu1 * 2.0f * C * D) / (A * B * B));
+            dm_dsigma1_sq[o] = ((-C * D) / (A * B * B));
+            dm_dsigma12[o] = ((2 * C) / (A * B));
+        }
+    }
+    const float bl1 = block256_sum(sum_l1, red);
+    const float bss = block256_sum(sum_ssim, red);
+    if (tid == 0) {
+        const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partials[2 * blk] = bl1;
+        partials[2 * blk + 1] = bss;
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_reduce_kernel(size_t nblk, const float* __restrict__ partials, float inv_n, float* __restrict__ terms)
+{
+    __shared__ float red[4];
+    float s0 = 0.f, s1 = 0.f;
+    for (size_t i = threadIdx.x; i < nblk; i += 256) { s0 += partials[2 * i]; s1 += partials[2 * i + 1]; }
+    const float t0 = block256_sum(s0, red);
+    const float t1 = block256_sum(s1, red);
+    if (threadIdx.x == 0) { terms[0] = t0 * inv_n; terms[1] = t1 * inv_n; }
+}
+
+// dL/dimg for dL/dloss = 1: the SSIM branch is ssim_bwd_kernel with the uniform upstream gradient -lambda/N pulled out of the
+// convolutions (zero padding commutes with a constant factor), plus the L1 branch (1-lambda)/N * sign(img - gt).
+__global__ __launch_bounds__(256) void loss_bwd_kernel(int H, int W, float w_l1, float w_ssim, const float* __restrict__ img1,
+                                                       const float* __restrict__ img2, const float* __restrict__ dm_dmu1,
+                                                       const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12,
+                                                       float* __restrict__ dL_dimg1)
+{
+    __shared__ float s1[SH_][SH_];
+    __shared__ float s2[SH_][SH_];
+    __shared__ float s3[SH_][SH_];
+    __shared__ float hs[3][SH_][ST];
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < SH_ * SH_; t += 256) {
+        const int ly = t / SH_, lx = t % SH_;
+        const int y = y0 + ly - 5, x = x0 + lx - 5;
+        s1[ly][lx] = pix_or_zero(dm_dmu1 + plane, H, W, y, x);
+        s2[ly][lx] = pix_or_zero(dm_dsigma1_sq + plane, H, W, y, x);
+        s3[ly][lx] = pix_or_zero(dm_dsigma12 + plane, H, W, y, x);
+    }
+    __syncthreads();
+    for (int t = tid; t < SH_ * ST; t += 256) {
+        const int ly = t / ST, lx = t % ST;
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+            const float g = c_G[i];
+            r0 += g * s1[ly][lx + i]; r1 += g * s2[ly][lx + i]; r2 += g * s3[ly][lx + i];
+        }
+        hs[0][ly][lx] = r0; hs[1][ly][lx] = r1; hs[2][ly][lx] = r2;
+    }
+    __syncthreads();
+    const int lx = tid & 31;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int ly = (tid >> 5) + 8 * q;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 11; j++) {
+            const float g = c_G[j];
+            v0 += g * hs[0][ly + j][lx]; v1 += g * hs[1][ly + j][lx]; v2 += g * hs[2][ly + j][lx];
+        }
+        const int px = x0 + lx, py = y0 + ly;
+        if (px < W && py < H) {
+            const size_t o = plane + (size_t)py * W + px;
+            const float pix1 = img1[o], pix2 = img2[o];
+            const float d = pix1 - pix2;
+            const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);  // torch.sign (abs backward)
+            dL_dimg1[o] = w_ssim * (v0 + pix1 * 2.0f * v1 + pix2 * v2) + w_l1 * sgn;
+        }
+    }
+}
+
+int loss_forward(int B, int CH, int H, int W, float C1, float C2, const float* img, const float* gt, float* d1, float* d2, float* d3,
+                 float* partials, float* terms, hipStream_t s)
+{
+    dim3 grid(div_up(W, ST), div_up(H, ST), B * CH);
+    GS_LAUNCH(K_SSIM_FWD, loss_fwd_kernel, grid, dim3(256), 0, s, H, W, C1, C2, img, gt, d1, d2, d3, partials);
+    const size_t nblk = (size_t)grid.x * grid.y * grid.z;
+    GS_LAUNCH(K_SSIM_FWD, loss_reduce_kernel, dim3(1), dim3(256), 0, s, nblk, (const float*)partials,
+              1.0f / (float)((size_t)B * CH * H * W), terms);
+    return GSLIC_OK;
+}
+int loss_backward(int B, int CH, int H, int W, float lambda_dssim, const float* img, const float* gt, const float* d1, const float* d2,
+                  const float* d3, float* dL_dimg, hipStream_t s)
+{
+    dim3 grid(div_up(W, ST), div_up(H, ST), B * CH);
+    const float n = (float)((size_t)B * CH * H * W);
+    GS_LAUNCH(K_SSIM_BWD, loss_bwd_kernel, grid, dim3(256), 0, s, H, W, (1.0f - lambda_dssim) / n, -lambda_dssim / n, img, gt, d1, d2,
+              d3, dL_dimg);
+    return GSLIC_OK;
+}
+int64_t loss_partials_count(int B, int CH, int H, int W) { return 2 * (int64_t)div_up(W, ST) * div_up(H, ST) * B * CH + 8; }
+
 int ssim_forward(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2, float* ssim_map,
                  float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, hipStream_t s)
 {

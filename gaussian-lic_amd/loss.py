@@ -104,3 +104,34 @@ def evaluate_visual_quality(model, cameras, gt_images, bg):
             ps.append(psnr(img, gt))
             ss.append(ssim(img.unsqueeze(0), gt.unsqueeze(0)))
     return torch.stack(ps).mean(), torch.stack(ss).mean()
+
+
+class FusedLoss:
+    """loss = (1-lambda) * L1 + lambda * (1 - SSIM) of optimize() (gaussian.cpp:685-691) computed by two kernels
+    (gslic_l1_ssim_loss_forward / _backward) with no LibTorch elementwise ops and no autograd graph."""
+
+    def __init__(self, lambda_dssim=0.2):
+        self.lambda_dssim = float(lambda_dssim)
+        self._shape, self._buf = None, None
+
+    def _scratch(self, img):
+        if self._shape != tuple(img.shape) or self._buf[0].device != img.device:
+            n = int(_lib.lib().gslic_loss_partials_count(1, img.shape[0], img.shape[1], img.shape[2]))
+            self._buf = [torch.empty_like(img) for _ in range(4)] + [torch.empty(n, device=img.device), torch.empty(2, device=img.device)]
+            self._shape = tuple(img.shape)
+        return self._buf
+
+    def forward_backward(self, image, gt):
+        """image, gt: [3,H,W].  Returns (dL/dimage, terms) with terms = device tensor [mean|img-gt|, mean ssim]."""
+        image, gt = image.contiguous(), gt.contiguous()
+        CH, H, W = image.shape
+        d1, d2, d3, dL, partials, terms = self._scratch(image)
+        p, L = _lib.ptr, _lib.lib()
+        _lib.check(L.gslic_l1_ssim_loss_forward(1, CH, H, W, C1, C2, p(image), p(gt), p(d1), p(d2), p(d3), p(partials), p(terms),
+                                                _lib.current_stream_ptr()))
+        _lib.check(L.gslic_l1_ssim_loss_backward(1, CH, H, W, self.lambda_dssim, p(image), p(gt), p(d1), p(d2), p(d3), p(dL),
+                                                 _lib.current_stream_ptr()))
+        return dL, terms
+
+    def value(self, terms):
+        return (1.0 - self.lambda_dssim) * terms[0] + self.lambda_dssim * (1.0 - terms[1])

@@ -38,10 +38,10 @@ class GaussianRasterizationSettings:
     lambda_erank: float = 0.0
 
 
-def _params(P, D, M, H, W, tanfovx, tanfovy, lxn, lxp, lyn, lyp, scale_modifier, prefiltered, debug, no_color):
+def _params(P, D, M, H, W, tanfovx, tanfovy, lxn, lxp, lyn, lyp, scale_modifier, prefiltered, debug, no_color, raw=False):
     return _lib.RasterParams(int(P), int(D), int(M), int(W), int(H), float(tanfovx), float(tanfovy), float(lxn), float(lxp),
                              float(lyn), float(lyp), float(scale_modifier), int(bool(prefiltered)), int(bool(debug)),
-                             int(bool(no_color)))
+                             int(bool(no_color)), int(bool(raw)))
 
 
 def _f32c(t):
@@ -50,9 +50,10 @@ def _f32c(t):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                         projmatrix, tan_fovx, tan_fovy, image_height, image_width, limx_neg, limx_pos, limy_neg, limy_pos,
-                        dc, sh, degree, campos, prefiltered, debug, no_color=False):
+                        dc, sh, degree, campos, prefiltered, debug, no_color=False, raw_params=False):
     """RasterizeGaussiansCUDA (rasterize_points.cu:50-149): returns
-    (num_rendered, num_buckets, out_color, out_final_T, radii, geomBuffer, binningBuffer, imgBuffer, sampleBuffer)."""
+    (num_rendered, num_buckets, out_color, out_final_T, radii, geomBuffer, binningBuffer, imgBuffer, sampleBuffer).
+    raw_params=True (not in the reference): opacity / scales / rotations are the RAW parameters, activated inside the kernels."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise ValueError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:77-80
     L = _lib.lib()
@@ -70,7 +71,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         sh_c = _f32c(sh) if M > 0 else None
         viewmatrix, projmatrix, campos, background = map(_f32c, (viewmatrix, projmatrix, campos, background))
         prm = _params(P, degree, M, H, W, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier,
-                      prefiltered, debug, no_color)
+                      prefiltered, debug, no_color, raw_params)
         p = _lib.ptr
         _lib.check(L.gslic_rasterize_forward(
             ctypes.byref(prm), allocs[0].cb, None, allocs[1].cb, None, allocs[2].cb, None, allocs[3].cb, None,
@@ -82,9 +83,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                                  projmatrix, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, dL_dout_color, dc, sh,
-                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, B, sampleBuffer, lambda_erank, debug):
+                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, B, sampleBuffer, lambda_erank, debug,
+                                 raw_params=False):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:151-246): returns (dL_dmeans2D, dL_dcolors_precomp,
-    dL_dopacities, dL_dmeans3D, dL_dcov3Ds_precomp, dL_ddc, dL_dsh, dL_dscales, dL_drotations)."""
+    dL_dopacities, dL_dmeans3D, dL_dcov3Ds_precomp, dL_ddc, dL_dsh, dL_dscales, dL_drotations).
+    raw_params=True: scales / rotations are raw and dL_dopacities / dL_dscales / dL_drotations are w.r.t. the raw parameters."""
     L = _lib.lib()
     dev = means3D.device
     P, H, W = means3D.size(0), dL_dout_color.size(1), dL_dout_color.size(2)
@@ -99,7 +102,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         sh_c = _f32c(sh) if M > 0 else None
         viewmatrix, projmatrix, campos, background = map(_f32c, (viewmatrix, projmatrix, campos, background))
         prm = _params(P, degree, M, H, W, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier,
-                      False, debug, False)
+                      False, debug, False, raw_params)
         p = _lib.ptr
         _lib.check(L.gslic_rasterize_backward(
             ctypes.byref(prm), int(R), int(B), p(background), p(means3D), p(dc), p(sh_c), p(colors), p(scales), p(rotations),

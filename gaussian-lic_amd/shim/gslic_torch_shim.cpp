@@ -65,7 +65,7 @@ RasterizeGaussiansCUDA(const torch::Tensor& background, const torch::Tensor& mea
     int rendered = 0, num_buckets = 0;
     if (P != 0) {
         gslic_raster_params prm{P, degree, M, W, H, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier,
-                                prefiltered ? 1 : 0, debug ? 1 : 0, no_color ? 1 : 0};
+                                prefiltered ? 1 : 0, debug ? 1 : 0, no_color ? 1 : 0, /*raw_params=*/0};
         at::Tensor bg = f32c(background), m3 = f32c(means3D), col = f32c(colors), op = f32c(opacity), sc = f32c(scales),
                    rot = f32c(rotations), cov = f32c(cov3D_precomp), vm = f32c(viewmatrix), pm = f32c(projmatrix), dcc = f32c(dc),
                    shc = f32c(sh), cp = f32c(campos);
@@ -101,7 +101,7 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
     at::Tensor dL_dscales = mk({P, 3}), dL_drotations = mk({P, 4});
     if (P != 0) {
         gslic_raster_params prm{P, degree, M, W, H, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier, 0,
-                                debug ? 1 : 0, 0};
+                                debug ? 1 : 0, 0, /*raw_params=*/0};
         at::Tensor bg = f32c(background), m3 = f32c(means3D), col = f32c(colors), sc = f32c(scales), rot = f32c(rotations),
                    cov = f32c(cov3D_precomp), vm = f32c(viewmatrix), pm = f32c(projmatrix), dcc = f32c(dc), shc = f32c(sh),
                    cp = f32c(campos), dl = f32c(dL_dout_color), rad = radii.contiguous();

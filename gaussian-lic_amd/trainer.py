@@ -164,6 +164,48 @@ def training_step(model, camera, gt_image, bg, lambda_dssim=LAMBDA_DSSIM, do_ste
     return loss.detach(), visible
 
 
+def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=True):
+    """The same iteration as training_step — identical arithmetic up to fp32 rounding — on the fused entry points
+    (SURVEY.md §8f row 2): sigmoid / exp / normalize and their backward run inside preprocess / preprocess_bwd (raw_params),
+    the loss and dL/dimage come from two loss kernels, and there is no autograd graph: 0 LibTorch elementwise launches per step
+    (the drop-in path issues ~35).  Returns (terms [mean L1, mean SSIM] device tensor, visible mask)."""
+    from . import rasterizer as rz
+    fl = fused_loss or _default_fused_loss()
+    dev = model.device
+    e = torch.empty(0, device=dev)
+    with torch.no_grad():
+        xyz, dc, rest = model.xyz.detach(), model.features_dc.detach(), model.features_rest.detach()
+        op, sc, rot = model.opacity.detach(), model.scaling.detach(), model.rotation.detach()
+        cam = camera
+        (R, B, image, _final_T, radii, geom, binning, img, sample) = rz.rasterize_gaussians(
+            bg, xyz, e, op, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
+            cam.image_height, cam.image_width, float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dc, rest,
+            model.sh_degree, cam.d_camera_center, False, False, False, raw_params=True)
+        dL_dimage, terms = fl.forward_backward(image, gt_image)
+        (_g2, _gc, g_op, g_xyz, _gcov, g_dc, g_sh, g_sc, g_rot) = rz.rasterize_gaussians_backward(
+            bg, xyz, radii, e, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
+            float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dL_dimage, dc, rest, model.sh_degree,
+            cam.d_camera_center, geom, R, binning, img, B, sample, model.lambda_erank, False, raw_params=True)
+        visible = radii > 0
+        if do_step:
+            grads = [g_xyz, g_dc, g_sh, g_op, g_sc, g_rot]       # group order of gaussian.cpp:399-418
+            if _dist_on():
+                grads, visible = allreduce_gradients(grads, visible)
+            model.optimizer.set_visibility_and_N(visible, model.P)
+            model.optimizer.step(grads)
+    return terms, visible
+
+
+_FUSED_LOSS = None
+
+
+def _default_fused_loss():
+    global _FUSED_LOSS
+    if _FUSED_LOSS is None:
+        _FUSED_LOSS = loss_utils.FusedLoss(LAMBDA_DSSIM)
+    return _FUSED_LOSS
+
+
 def render_fwd_bwd(model, camera, dL_dimage, bg):
     """Bare rendered view forward + backward (the metric's "(fwd+bwd)"), no loss kernels, no optimiser."""
     image, _final_T, _pts, visible, _radii = render(camera, model, bg)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSLIC_ABI_VERSION 1
+#define GSLIC_ABI_VERSION 2
 
 typedef enum gslic_status {
     GSLIC_OK = 0,
@@ -62,6 +62,10 @@ typedef struct gslic_raster_params {
     int32_t prefiltered;    /* bool                                                                    */
     int32_t debug;          /* bool: synchronise + check after every stage (CHECK_CUDA, auxiliary.h:173-180) */
     int32_t no_color;       /* bool: transmittance-only render (forward.cu:338,362,412,446,470)         */
+    int32_t raw_params;     /* bool, 0 for the drop-in shim.  1: `opacities`, `scales`, `rotations` are the
+                               RAW parameters (logit, log, unnormalised quaternion); sigmoid / exp / normalize of
+                               renderer.cpp:57-63 + gaussian.cpp:147-175 run inside the kernels, and the backward returns
+                               dL/d(raw) in dL_dopacity / dL_dscale / dL_drot (the chain LibTorch autograd would apply). */
 } gslic_raster_params;
 
 /* ------------------------------------------------------------------------------------------------
@@ -197,6 +201,22 @@ int gslic_fusedssim_backward(
     const float* img1, const float* img2, const float* dL_dmap,
     const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
     float* dL_dimg1, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * gslic_l1_ssim_loss_forward / _backward — SURVEY.md §8f row 2: the loss of optimize() (src/gaussian.cpp:685-691),
+ *   loss = (1 - lambda) * mean|img - gt| + lambda * (1 - mean(ssim_map(img, gt))),
+ * with l1_loss (loss_utils.h:30-33) folded into the fused-SSIM kernels.  Forward writes the three derivative maps (as
+ * gslic_fusedssim_forward with train = 1) and terms[0] = mean|img - gt|, terms[1] = mean ssim (DEVICE floats, reduced in a fixed
+ * order: bit-reproducible); `partials` is DEVICE scratch of gslic_loss_partials_count(B,CH,H,W) floats.  Backward writes
+ * dL/dimg for dL/dloss = 1: (1-lambda)/N sign(img-gt) - lambda/N (conv(dm_dmu1) + 2 img conv(dm_dsigma1_sq) + gt conv(dm_dsigma12)).
+ */
+int64_t gslic_loss_partials_count(int32_t B, int32_t CH, int32_t H, int32_t W);
+int gslic_l1_ssim_loss_forward(
+    int32_t B, int32_t CH, int32_t H, int32_t W, float C1, float C2, const float* img, const float* gt,
+    float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, float* partials, float* terms /*[2] device*/, void* stream);
+int gslic_l1_ssim_loss_backward(
+    int32_t B, int32_t CH, int32_t H, int32_t W, float lambda_dssim, const float* img, const float* gt,
+    const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * gslic_knn_mean_dist2 — replaces SimpleKNN::knn (src/simple-knn/simple_knn.cu:185-221) behind distCUDA2

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in gslic_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names
-    assert _lib.lib().gslic_abi_version() == 1
+    assert _lib.lib().gslic_abi_version() == 2
 
 
 def test_scratch_sizes_and_errors_without_gpu():
@@ -39,7 +39,7 @@ def test_scratch_sizes_and_errors_without_gpu():
     assert L.gslic_binning_bytes(1000, 1) < L.gslic_binning_bytes(1000, 0)
     assert L.gslic_sample_bytes(10) >= 10 * 4096
     # argument validation happens before any device work
-    prm = _lib.RasterParams(10, 5, 15, 64, 48, 1.0, 1.0, -1, 1, -1, 1, 1.0, 0, 0, 0)
+    prm = _lib.RasterParams(10, 5, 15, 64, 48, 1.0, 1.0, -1, 1, -1, 1, 1.0, 0, 0, 0, 0)
     R, B = ctypes.c_int32(7), ctypes.c_int32(7)
     rc = L.gslic_rasterize_forward(ctypes.byref(prm), *([_lib.ALLOC_FN(lambda c, n: 0), None] * 4), *([None] * 15),
                                    ctypes.byref(R), ctypes.byref(B), None)
