@@ -113,6 +113,9 @@ SortPlan sort_plan(size_t n, int end_bit);
 // buffer pairs starting from index 0; the result is in buffers [plan.passes & 1].
 int radix_sort_pairs(uint64_t* keys[2], uint32_t* vals[2], const SortPlan& plan, uint32_t* hist,
                      uint32_t* scan_temp, hipStream_t s);
+// Onesweep variant (single pass per digit, decoupled look-back); `state` = onesweep_state_bytes(plan) bytes of device scratch.
+size_t onesweep_state_bytes(const SortPlan& plan);
+int radix_sort_pairs_onesweep(uint64_t* keys[2], uint32_t* vals[2], const SortPlan& plan, void* state, hipStream_t s);
 
 // opaque scratch layouts ----------------------------------------------------------------------------------
 struct GeomState {
@@ -138,6 +141,7 @@ struct BinningState {
     uint32_t* point_list;     // [R] sorted position -> Gaussian id
     uint32_t* hist;           // [256 * nblk]
     uint32_t* scan_temp;
+    void* onesweep_state;     // look-back status words + global digit histograms
     float4* partials;         // [3R] per emission slot: 9 partial gradients (+3 pad), only when !no_color
     SortPlan plan;
     static BinningState carve(const void* base, size_t R, int end_bit, bool no_color, size_t* bytes);

@@ -146,3 +146,30 @@ def test_large_scene_properties():
     ncb = npy(d["n_contrib"]).astype(np.int64)
     assert ncb.max() <= cnt.max()
     assert int(npy(d["max_contrib"]).max()) == int(ncb.max())
+
+
+def test_onesweep_sort_variant_is_bit_identical():
+    """GSLIC_SORT_ONESWEEP=1 (single pass per digit with decoupled look-back) must give exactly the default sort's lists."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+from conftest import make_scene
+from gpu_helpers import hip_forward, npy
+raw, sc, camd, cam = make_scene('random', 150000, 960, 540, 3, 71)
+f = hip_forward(raw, cam, export=('sorted_keys', 'point_list', 'ranges'))
+np.savez(sys.argv[1], keys=npy(f['dbg']['sorted_keys']), pl=npy(f['dbg']['point_list']), rg=npy(f['dbg']['ranges']), img=npy(f['color']))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for name, env in (("a", {}), ("b", {"GSLIC_SORT_ONESWEEP": "1"})):
+        path = os.path.join(root, "gpurun_out", f"_sortcmp_{name}.npz") if os.path.isdir(os.path.join(root, "gpurun_out")) else f"/tmp/_sortcmp_{name}.npz"
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", code, path], cwd=root, env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+        os.remove(path)
+    for k in ("keys", "pl", "rg", "img"):
+        np.testing.assert_array_equal(outs[0][k], outs[1][k])
