@@ -173,3 +173,21 @@ np.savez(sys.argv[1], keys=npy(f['dbg']['sorted_keys']), pl=npy(f['dbg']['point_
         os.remove(path)
     for k in ("keys", "pl", "rg", "img"):
         np.testing.assert_array_equal(outs[0][k], outs[1][k])
+
+
+def test_non_default_stream_and_debug_flag(oracle32):
+    """The C-ABI launches on the stream it is given (here a non-default torch stream) and `debug` (sync after every stage,
+    CHECK_CUDA in the reference) changes nothing."""
+    from gpu_helpers import hip_backward, hip_forward, npy
+    from gaussian_lic_amd.synthetic import pixel_grad
+    raw, sc, camd, cam = make_scene("random", 8000, 200, 150, 3, 81)
+    base = hip_forward(raw, cam)
+    gbase = hip_backward(base, pixel_grad(150, 200))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        f = hip_forward(raw, cam, debug=True)
+        g = hip_backward(f, pixel_grad(150, 200))
+    s.synchronize()
+    assert f["R"] == base["R"] and torch.equal(f["color"], base["color"]) and torch.equal(f["final_T"], base["final_T"])
+    for k in g:
+        np.testing.assert_array_equal(g[k], gbase[k])
