@@ -84,7 +84,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                                  projmatrix, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, dL_dout_color, dc, sh,
                                  degree, campos, geomBuffer, R, binningBuffer, imageBuffer, B, sampleBuffer, lambda_erank, debug,
-                                 raw_params=False):
+                                 raw_params=False, out=None):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:151-246): returns (dL_dmeans2D, dL_dcolors_precomp,
     dL_dopacities, dL_dmeans3D, dL_dcov3Ds_precomp, dL_ddc, dL_dsh, dL_dscales, dL_drotations).
     raw_params=True: scales / rotations are raw and dL_dopacities / dL_dscales / dL_drotations are w.r.t. the raw parameters."""
@@ -94,9 +94,16 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     M = sh.size(1) if sh is not None and sh.size(0) != 0 else 0
     mk = (lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)) if P != 0 else \
         (lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev))
-    dL_dmeans3D, dL_dmeans2D, dL_dcolors = mk(P, 3), mk(P, 3), mk(P, 3)
-    dL_dconic, dL_dopacities, dL_dcov3D = mk(P, 2, 2), mk(P, 1), mk(P, 6)
-    dL_ddc, dL_dsh, dL_dscales, dL_drotations = mk(P, 1, 3), mk(P, M, 3), mk(P, 3), mk(P, 4)
+    if out is not None:
+        # caller-provided gradient storage (e.g. views of one flat slab for a zero-copy all-reduce); the tensors the host
+        # discards (means2D, conic, colors_precomp, cov3D: rasterizer.cpp:171-182) are not materialised at all
+        dL_dmeans3D, dL_ddc, dL_dsh = out["xyz"], out["features_dc"], out["features_rest"]
+        dL_dopacities, dL_dscales, dL_drotations = out["opacity"], out["scaling"], out["rotation"]
+        dL_dmeans2D = dL_dcolors = dL_dconic = dL_dcov3D = None
+    else:
+        dL_dmeans3D, dL_dmeans2D, dL_dcolors = mk(P, 3), mk(P, 3), mk(P, 3)
+        dL_dconic, dL_dopacities, dL_dcov3D = mk(P, 2, 2), mk(P, 1), mk(P, 6)
+        dL_ddc, dL_dsh, dL_dscales, dL_drotations = mk(P, 1, 3), mk(P, M, 3), mk(P, 3), mk(P, 4)
     if P != 0:
         means3D, dc, scales, rotations, dL = map(_f32c, (means3D, dc, scales, rotations, dL_dout_color))
         sh_c = _f32c(sh) if M > 0 else None

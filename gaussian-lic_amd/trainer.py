@@ -130,6 +130,33 @@ def _dist_on():
     return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
 
 
+class GradSlab:
+    """One contiguous fp32 buffer [P x (11+3K)] holding the six gradient tensors back to back (group order of
+    gaussian.cpp:399-418).  The fused backward writes straight into its views, so the per-step exchange is ONE in-place
+    all-reduce of `flat` with no concatenation copy (472 MB at 2M Gaussians, SH degree 3)."""
+
+    def __init__(self, model):
+        self.P = model.P
+        shapes = [tuple(p.shape) for p in model.parameters()]
+        sizes = [int(torch.tensor(s).prod()) for s in shapes]
+        self.flat = torch.empty(sum(sizes), device=model.device)
+        self.views, off = {}, 0
+        for name, shp, n in zip(model.NAMES, shapes, sizes):
+            self.views[name] = self.flat[off:off + n].view(shp)
+            off += n
+
+    def grads(self, model):
+        return [self.views[n] for n in model.NAMES]
+
+
+def allreduce_slab(slab, visible):
+    """The per-step exchange on a GradSlab: SUM all-reduce of the slab in place + MAX (= OR) of the visibility bytes."""
+    vis = visible.to(torch.uint8)
+    torch.distributed.all_reduce(slab.flat, op=torch.distributed.ReduceOp.SUM)
+    torch.distributed.all_reduce(vis, op=torch.distributed.ReduceOp.MAX)
+    return vis.bool()
+
+
 def allreduce_gradients(grads, visible):
     """The per-step exchange: SUM of the concatenated gradient slab [P x (11+3K)] and MAX (= OR) of the visibility
     bytes.  One collective each; returns (list of reduced gradient views, reduced visibility)."""
@@ -182,17 +209,19 @@ def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=Tr
             cam.image_height, cam.image_width, float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dc, rest,
             model.sh_degree, cam.d_camera_center, False, False, False, raw_params=True)
         dL_dimage, terms = fl.forward_backward(image, gt_image)
-        (_g2, _gc, g_op, g_xyz, _gcov, g_dc, g_sh, g_sc, g_rot) = rz.rasterize_gaussians_backward(
+        slab = getattr(model, "_grad_slab", None)
+        if slab is None or slab.P != model.P:
+            slab = model._grad_slab = GradSlab(model)
+        rz.rasterize_gaussians_backward(
             bg, xyz, radii, e, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
             float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dL_dimage, dc, rest, model.sh_degree,
-            cam.d_camera_center, geom, R, binning, img, B, sample, model.lambda_erank, False, raw_params=True)
+            cam.d_camera_center, geom, R, binning, img, B, sample, model.lambda_erank, False, raw_params=True, out=slab.views)
         visible = radii > 0
         if do_step:
-            grads = [g_xyz, g_dc, g_sh, g_op, g_sc, g_rot]       # group order of gaussian.cpp:399-418
             if _dist_on():
-                grads, visible = allreduce_gradients(grads, visible)
+                visible = allreduce_slab(slab, visible)
             model.optimizer.set_visibility_and_N(visible, model.P)
-            model.optimizer.step(grads)
+            model.optimizer.step(slab.grads(model))       # group order of gaussian.cpp:399-418
     return terms, visible
 
 

@@ -31,6 +31,19 @@ def _worker(rank, world, port, q):
     grads = [torch.randn(*s, generator=g) for s in shapes]
     vis = torch.rand(P, generator=g) < 0.3
     red, rvis = trainer.allreduce_gradients(grads, vis)
+    # the zero-copy variant used by the fused step: gradients already live in one slab
+    class _M:
+        NAMES = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")
+        device = torch.device("cpu")
+        P = 257
+        def parameters(self): return [torch.empty(*s) for s in shapes]
+    slab = trainer.GradSlab(_M())
+    for v, x in zip(slab.grads(_M()), grads):
+        v.copy_(x)
+    svis = trainer.allreduce_slab(slab, vis)
+    for a, b in zip(slab.grads(_M()), red):
+        assert torch.equal(a, b)
+    assert torch.equal(svis, rvis)
     q.put((rank, [r.clone().numpy() for r in red], rvis.numpy(), [x.numpy() for x in grads], vis.numpy()))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
