@@ -48,6 +48,9 @@ def algorithmic_bytes(kernel, s):
         "render_bwd": 4096 * B + 104 * R + 16 * Np + 12 * N,
         # partials 48/instance; per P radii 4; per visible in: xyz 12 scale 12 rot 16 SH 12K rec 16 off 8; out: 4*(11+3K)+... grads
         "preprocess_bwd": 48 * R + 4 * P + V * (12 * K + 64) + P * 4 * (3 + 4 + 1 + 3 + 3 + 6 + 3 * K + 3 + 4),
+        # the same kernel with Adam applied in place (fused host path, single GPU): no gradient tensors; per visible Gaussian the
+        # 59 scalars' param/m/v are read and written (24 B/scalar), SH and the record are read once
+        "preprocess_bwd+adam": 48 * R + 12 * P + V * (16 + 24 * (11 + 3 * K)),
         # visible rows: param, grad, m, v in; param, m, v out (28 B/scalar); mask byte per scalar-thread
         "adam": 28 * (11 + 3 * K - 3) * V + (11 + 3 * K - 3) * P,
         "ssim_fwd": 24 * N + 48 * N,
@@ -213,7 +216,8 @@ def main():
     # ---- roofline of the dominant kernel
     dom_ms, dom_n = timed.get(dominant, (0.0, 0))
     avg_ms = dom_ms / max(dom_n, 1)
-    abytes = algorithmic_bytes(dominant, stats)
+    fused_adam = args.mode in ("train", "slam") and args.host == "fused" and world == 1
+    abytes = algorithmic_bytes("preprocess_bwd+adam" if (dominant == "preprocess_bwd" and fused_adam) else dominant, stats)
     achieved = abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")

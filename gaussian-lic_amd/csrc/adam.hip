@@ -16,13 +16,6 @@ struct AdamGroups {
     int n;
 };
 
-__device__ __forceinline__ void adam_scalar(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps)
-{
-    m = b1 * m + (1.0f - b1) * g;
-    v = b2 * v + (1.0f - b2) * g * g;
-    p += -lr * m / (sqrtf(v) + eps);
-}
-
 // rows are M scalars wide; element index e -> row e / M with M a compile-time constant (0 = runtime fallback)
 template <uint32_t M>
 __device__ __forceinline__ uint32_t row_of(uint32_t e, uint32_t m_rt)

@@ -294,13 +294,13 @@ int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_
     return GSLIC_OK;
 }
 
-int gslic_rasterize_backward(const gslic_raster_params* prm, int32_t R, int32_t B, const float* background, const float* means3D,
+static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, int32_t B, const float* background, const float* means3D,
                              const float* dc, const float* shs, const float* colors_precomp, const float* scales,
                              const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                              const float* cam_pos, const int32_t* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
                              char* sample_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                              float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_ddc, float* dL_dsh, float* dL_dscale,
-                             float* dL_drot, float lambda_erank, void* stream)
+                             float* dL_drot, float lambda_erank, const gslic_adam_fused* adam, void* stream)
 {
     (void)background; (void)dc;
     GS_TRY(check_params(prm));
@@ -311,9 +311,19 @@ int gslic_rasterize_backward(const gslic_raster_params* prm, int32_t R, int32_t 
     if (prm->no_color) return set_error(GSLIC_ERR_INVALID_ARG, "backward of a no_color forward is undefined (no checkpoints were stored)");
     if (R < 0 || B < 0) return set_error(GSLIC_ERR_INVALID_ARG, "negative R / B");
     if (!means3D || !scales || !rotations || !viewmatrix || !projmatrix || !cam_pos || !radii || !geom_buffer || !binning_buffer ||
-        !img_buffer || !sample_buffer || !dL_dpix || !dL_dopacity || !dL_dmean3D || !dL_ddc || !dL_dscale || !dL_drot ||
-        (prm->M > 0 && (!shs || !dL_dsh)))
+        !img_buffer || !sample_buffer || !dL_dpix || (prm->M > 0 && !shs))
         return set_error(GSLIC_ERR_INVALID_ARG, "required tensor pointer is NULL");
+    if (!adam && (!dL_dopacity || !dL_dmean3D || !dL_ddc || !dL_dscale || !dL_drot || (prm->M > 0 && !dL_dsh)))
+        return set_error(GSLIC_ERR_INVALID_ARG, "required gradient output pointer is NULL");
+    if (adam) {
+        if (!prm->raw_params) return set_error(GSLIC_ERR_INVALID_ARG, "fused Adam needs raw_params = 1 (it updates the raw parameters)");
+        for (int g = 0; g < 6; g++) {
+            if (g == 2 && prm->M == 0) continue;
+            if (!adam->param[g] || !adam->exp_avg[g] || !adam->exp_avg_sq[g]) return set_error(GSLIC_ERR_INVALID_ARG, "fused Adam: group %d has a NULL pointer", g);
+        }
+        if (adam->param[0] != means3D || adam->param[4] != scales || adam->param[5] != rotations || (prm->M > 0 && adam->param[2] != shs))
+            return set_error(GSLIC_ERR_INVALID_ARG, "fused Adam: param[] must alias the tensors passed as means3D / shs / scales / rotations");
+    }
     hipStream_t s = (hipStream_t)stream;
     int gx, gy;
     const int T = tile_grid(prm->width, prm->height, gx, gy);
@@ -341,9 +351,43 @@ int gslic_rasterize_backward(const gslic_raster_params* prm, int32_t R, int32_t 
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_ddc = dL_ddc; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale;
     pb.dL_drot = dL_drot;
+    memset(&pb.adam, 0, sizeof(pb.adam));
+    if (adam) {
+        for (int g = 0; g < 6; g++) { pb.adam.p[g] = adam->param[g]; pb.adam.m[g] = adam->exp_avg[g]; pb.adam.v[g] = adam->exp_avg_sq[g]; pb.adam.lr[g] = adam->lr[g]; }
+        pb.adam.b1 = adam->b1; pb.adam.b2 = adam->b2; pb.adam.eps = adam->eps; pb.adam.on = 1;
+    }
     GS_TRY(launch_preprocess_bwd(pb, s));
     DEBUG_SYNC(prm, s);
     return GSLIC_OK;
+}
+
+int gslic_rasterize_backward(const gslic_raster_params* prm, int32_t R, int32_t B, const float* background, const float* means3D,
+                             const float* dc, const float* shs, const float* colors_precomp, const float* scales,
+                             const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                             const float* cam_pos, const int32_t* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
+                             char* sample_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                             float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_ddc, float* dL_dsh, float* dL_dscale,
+                             float* dL_drot, float lambda_erank, void* stream)
+{
+    return rasterize_backward_impl(prm, R, B, background, means3D, dc, shs, colors_precomp, scales, rotations, cov3D_precomp, viewmatrix,
+                                   projmatrix, cam_pos, radii, geom_buffer, binning_buffer, img_buffer, sample_buffer, dL_dpix, dL_dmean2D,
+                                   dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_ddc, dL_dsh, dL_dscale, dL_drot,
+                                   lambda_erank, nullptr, stream);
+}
+
+int gslic_rasterize_backward_adam(const gslic_raster_params* prm, int32_t R, int32_t B, const float* background, const float* means3D,
+                                  const float* dc, const float* shs, const float* colors_precomp, const float* scales,
+                                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                  const float* cam_pos, const int32_t* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
+                                  char* sample_buffer, const float* dL_dpix, float* dL_dopacity, float* dL_dmean3D, float* dL_ddc,
+                                  float* dL_dsh, float* dL_dscale, float* dL_drot, float lambda_erank, const gslic_adam_fused* adam,
+                                  void* stream)
+{
+    if (!adam) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_rasterize_backward_adam: adam descriptor is NULL");
+    return rasterize_backward_impl(prm, R, B, background, means3D, dc, shs, colors_precomp, scales, rotations, cov3D_precomp, viewmatrix,
+                                   projmatrix, cam_pos, radii, geom_buffer, binning_buffer, img_buffer, sample_buffer, dL_dpix, nullptr,
+                                   nullptr, dL_dopacity, nullptr, dL_dmean3D, nullptr, dL_ddc, dL_dsh, dL_dscale, dL_drot, lambda_erank,
+                                   adam, stream);
 }
 
 int gslic_adam_update(float* param, const float* param_grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible, float lr,

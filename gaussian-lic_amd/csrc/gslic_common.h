@@ -204,6 +204,16 @@ __device__ __forceinline__ uint32_t wave_shr1_u(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
 }
 
+// The Adam update of adam.cu:26-37, one definition for every kernel that applies it (adam.hip and the fused backward):
+// contraction is pinned off so that the two call sites round identically (their results are compared bit for bit).
+__device__ __forceinline__ void adam_scalar(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps)
+{
+#pragma clang fp contract(off)
+    m = b1 * m + (1.0f - b1) * g;
+    v = b2 * v + (1.0f - b2) * g * g;
+    p += -lr * m / (sqrtf(v) + eps);
+}
+
 // Canonical logf for the culling threshold (forward.cu:302): fixed double polynomial, identical to orc_logf.
 __device__ __forceinline__ float canon_logf(float x)
 {

@@ -62,6 +62,13 @@ struct RenderBwdArgs {
 };
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
 
+struct AdamFusedArgs {
+    float *p[6], *m[6], *v[6];  // xyz, features_dc, features_rest, opacity, scaling, rotation
+    float lr[6];
+    float b1, b2, eps;
+    int on;
+};
+
 struct PreprocessBwdArgs {
     int P, D, M, W, H, raw;
     float focal_x, focal_y;
@@ -72,6 +79,7 @@ struct PreprocessBwdArgs {
     const uint32_t* offsets;
     const float4* partials;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_ddc, *dL_dsh, *dL_dscale, *dL_drot;
+    AdamFusedArgs adam;
 };
 int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
 

@@ -55,8 +55,10 @@ template <bool LDS_SH>
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreprocessBwdArgs a)
 {
     __shared__ float lds_sh[LDS_SH ? 256 * 45 : 4];
+    __shared__ uint8_t lds_vis[256];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int M = a.M;
+    lds_vis[threadIdx.x] = (idx < a.P && a.radii[idx] > 0) ? 1 : 0;
     const int row0 = blockIdx.x * 256;
     const int rows = (a.P - row0) < 256 ? (a.P - row0) : 256;
     if constexpr (LDS_SH) {
@@ -78,27 +80,62 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreprocessBwdArgs a
     if constexpr (LDS_SH) __syncthreads();  // every SH row has been consumed: the buffer now takes the dL_dsh rows
 
     // ---- phase B: this Gaussian's dL_dsh row (zeros when invisible, when shs == NULL, and above the active degree)
-    if (idx < a.P && (LDS_SH || a.dL_dsh)) {
-        float* drow = LDS_SH ? (lds_sh + threadIdx.x * 45) : (a.dL_dsh + (size_t)3 * M * idx);
-        if (so.on) {
-            float c[15];
-            sh_coefs(a.D, so.x, so.y, so.z, c);
-            const int nk = M < 15 ? M : 15;
-            for (int k = 0; k < nk; k++) { drow[3 * k] = c[k] * so.dR; drow[3 * k + 1] = c[k] * so.dG; drow[3 * k + 2] = c[k] * so.dB; }
-            for (int k = 3 * nk; k < 3 * M; k++) drow[k] = 0.f;
-        } else {
-            for (int k = 0; k < 3 * M; k++) drow[k] = 0.f;
-        }
-    }
     if constexpr (LDS_SH) {
+        if (idx < a.P) {
+            float* drow = lds_sh + threadIdx.x * 45;
+            if (so.on) {
+                float c[15];
+                sh_coefs(a.D, so.x, so.y, so.z, c);
+                for (int k = 0; k < 15; k++) { drow[3 * k] = c[k] * so.dR; drow[3 * k + 1] = c[k] * so.dG; drow[3 * k + 2] = c[k] * so.dB; }
+            } else {
+                for (int k = 0; k < 45; k++) drow[k] = 0.f;
+            }
+        }
         __syncthreads();
-        float* dst = a.dL_dsh + (size_t)row0 * 45;
+        // ---- phase C: the block's 256 x 45 gradient rows leave LDS coalesced: to dL_dsh and / or straight into Adam
+        const size_t base = (size_t)row0 * 45;
+        const AdamFusedArgs& A = a.adam;
         if (rows == 256) {
-            float4* d4 = reinterpret_cast<float4*>(dst);
             const float4* s4 = reinterpret_cast<const float4*>(lds_sh);
-            for (int i = threadIdx.x; i < 256 * 45 / 4; i += 256) d4[i] = s4[i];
+            for (int i = threadIdx.x; i < 256 * 45 / 4; i += 256) {
+                const float4 g = s4[i];
+                if (a.dL_dsh) reinterpret_cast<float4*>(a.dL_dsh + base)[i] = g;
+                if (A.on) {
+                    const int e = 4 * i;
+                    const bool v0 = lds_vis[e / 45], v1 = lds_vis[(e + 1) / 45], v2 = lds_vis[(e + 2) / 45], v3 = lds_vis[(e + 3) / 45];
+                    if (v0 | v1 | v2 | v3) {
+                        float4 p = reinterpret_cast<float4*>(A.p[2] + base)[i];
+                        float4 m = reinterpret_cast<float4*>(A.m[2] + base)[i];
+                        float4 v = reinterpret_cast<float4*>(A.v[2] + base)[i];
+                        if (v0) adam_scalar(p.x, g.x, m.x, v.x, A.lr[2], A.b1, A.b2, A.eps);
+                        if (v1) adam_scalar(p.y, g.y, m.y, v.y, A.lr[2], A.b1, A.b2, A.eps);
+                        if (v2) adam_scalar(p.z, g.z, m.z, v.z, A.lr[2], A.b1, A.b2, A.eps);
+                        if (v3) adam_scalar(p.w, g.w, m.w, v.w, A.lr[2], A.b1, A.b2, A.eps);
+                        reinterpret_cast<float4*>(A.p[2] + base)[i] = p;
+                        reinterpret_cast<float4*>(A.m[2] + base)[i] = m;
+                        reinterpret_cast<float4*>(A.v[2] + base)[i] = v;
+                    }
+                }
+            }
         } else {
-            for (int i = threadIdx.x; i < rows * 45; i += 256) dst[i] = lds_sh[i];
+            for (int i = threadIdx.x; i < rows * 45; i += 256) {
+                const float g = lds_sh[i];
+                if (a.dL_dsh) a.dL_dsh[base + i] = g;
+                if (A.on && lds_vis[i / 45]) adam_scalar(A.p[2][base + i], g, A.m[2][base + i], A.v[2][base + i], A.lr[2], A.b1, A.b2, A.eps);
+            }
+        }
+    } else if (idx < a.P && M > 0 && (a.dL_dsh || a.adam.on)) {
+        // generic row width: per-thread strided rows (dL_dsh zeros when invisible, when shs == NULL, above the active degree)
+        const AdamFusedArgs& A = a.adam;
+        float c[15];
+        sh_coefs(a.D, so.x, so.y, so.z, c);
+        const int nk = M < 15 ? M : 15;
+        const float dR[3] = {so.dR, so.dG, so.dB};
+        const size_t rb = (size_t)3 * M * idx;
+        for (int k = 0; k < 3 * M; k++) {
+            const float g = (so.on && k < 3 * nk) ? c[k / 3] * dR[k % 3] : 0.f;
+            if (a.dL_dsh) a.dL_dsh[rb + k] = g;
+            if (A.on && lds_vis[threadIdx.x]) adam_scalar(A.p[2][rb + k], g, A.m[2][rb + k], A.v[2][rb + k], A.lr[2], A.b1, A.b2, A.eps);
         }
     }
 }
@@ -111,14 +148,14 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
     if (!visible) {
         if (a.dL_dmean2D) { a.dL_dmean2D[3 * idx] = 0; a.dL_dmean2D[3 * idx + 1] = 0; a.dL_dmean2D[3 * idx + 2] = 0; }
         if (a.dL_dconic) reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(0, 0, 0, 0);
-        a.dL_dopacity[idx] = 0;
+        if (a.dL_dopacity) a.dL_dopacity[idx] = 0;
         if (a.dL_dcolor) { a.dL_dcolor[3 * idx] = 0; a.dL_dcolor[3 * idx + 1] = 0; a.dL_dcolor[3 * idx + 2] = 0; }
-        a.dL_dmean3D[3 * idx] = 0; a.dL_dmean3D[3 * idx + 1] = 0; a.dL_dmean3D[3 * idx + 2] = 0;
+        if (a.dL_dmean3D) { a.dL_dmean3D[3 * idx] = 0; a.dL_dmean3D[3 * idx + 1] = 0; a.dL_dmean3D[3 * idx + 2] = 0; }
         if (a.dL_dcov3D)
             for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * idx + k] = 0;
-        a.dL_ddc[3 * idx] = 0; a.dL_ddc[3 * idx + 1] = 0; a.dL_ddc[3 * idx + 2] = 0;
-        a.dL_dscale[3 * idx] = 0; a.dL_dscale[3 * idx + 1] = 0; a.dL_dscale[3 * idx + 2] = 0;
-        reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0, 0, 0, 0);
+        if (a.dL_ddc) { a.dL_ddc[3 * idx] = 0; a.dL_ddc[3 * idx + 1] = 0; a.dL_ddc[3 * idx + 2] = 0; }
+        if (a.dL_dscale) { a.dL_dscale[3 * idx] = 0; a.dL_dscale[3 * idx + 1] = 0; a.dL_dscale[3 * idx + 2] = 0; }
+        if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0, 0, 0, 0);
         return;
     }
 
@@ -137,7 +174,6 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
     }
     if (a.dL_dmean2D) { a.dL_dmean2D[3 * idx] = s_mx; a.dL_dmean2D[3 * idx + 1] = s_my; a.dL_dmean2D[3 * idx + 2] = 0; }
     if (a.dL_dconic) reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(s_cx, s_cy, 0.f, s_cw);
-    a.dL_dopacity[idx] = s_op;
     if (a.dL_dcolor) { a.dL_dcolor[3 * idx] = s_r; a.dL_dcolor[3 * idx + 1] = s_g; a.dL_dcolor[3 * idx + 2] = s_b; }
 
     const float* __restrict__ V = a.view;
@@ -244,6 +280,7 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
     }
 
     // ---- SH backward (backward.cu:27-136); skipped entirely when shs == NULL (backward.cu:352) ----
+    float ddc[3] = {0.f, 0.f, 0.f};
     if (a.shs) {
         const uint32_t clamp_bits = __float_as_uint(a.rec[3 * (size_t)idx + 2].z);
         const float dox = mx3 - a.campos[0], doy = my3 - a.campos[1], doz = mz3 - a.campos[2];
@@ -256,7 +293,7 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
             const float g = dRGB[ch];
-            a.dL_ddc[3 * idx + ch] = SHC0 * g;
+            ddc[ch] = SHC0 * g;
             float ddx = 0.f, ddy = 0.f, ddz = 0.f;
 #define S(k) sh[3 * (k) + ch]
             if (a.D > 0) {
@@ -288,10 +325,7 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
         dmean[0] += ((+sum2 - dox * dox) * ddir[0] - doy * dox * ddir[1] - doz * dox * ddir[2]) * invsum32;
         dmean[1] += (-dox * doy * ddir[0] + (sum2 - doy * doy) * ddir[1] - doz * doy * ddir[2]) * invsum32;
         dmean[2] += (-dox * doz * ddir[0] - doy * doz * ddir[1] + (sum2 - doz * doz) * ddir[2]) * invsum32;
-    } else {
-        a.dL_ddc[3 * idx] = 0; a.dL_ddc[3 * idx + 1] = 0; a.dL_ddc[3 * idx + 2] = 0;
     }
-    a.dL_dmean3D[3 * idx] = dmean[0]; a.dL_dmean3D[3 * idx + 1] = dmean[1]; a.dL_dmean3D[3 * idx + 2] = dmean[2];
 
     // ---- Sigma_3D -> scale, quaternion (backward.cu:257-310) ----
     // dL/dSigma symmetrised (1/2 on off-diagonals); dM[c][r] = 2 * sum_k M[k][r] * dS[c][k]  (glm column-major)
@@ -332,12 +366,13 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
         }
         dscale[2] += 1;
     }
+    float g_op = s_op;
     if (a.raw) {
         // chain through the activations, as LibTorch autograd does outside the reference's kernels (gaussian.cpp:147-175):
         // d exp = s; d sigmoid = o (1 - o); d normalize = dnormvdv (auxiliary.h:131-143)
         dscale[0] *= sc[0]; dscale[1] *= sc[1]; dscale[2] *= sc[2];
         const float o = a.rec[3 * (size_t)idx + 1].y;
-        a.dL_dopacity[idx] = s_op * o * (1.0f - o);
+        g_op = s_op * o * (1.0f - o);
         const float sum2 = qraw.x * qraw.x + qraw.y * qraw.y + qraw.z * qraw.z + qraw.w * qraw.w;
         const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
         const float vd0 = qraw.x * dq.x, vd1 = qraw.y * dq.y, vd2 = qraw.z * dq.z, vd3 = qraw.w * dq.w;
@@ -349,13 +384,31 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
         dr.w = ((sum2 - qraw.w * qraw.w) * dq.w - qraw.w * (vds - vd3)) * invsum32;
         dq = dr;
     }
-    a.dL_dscale[3 * idx] = dscale[0]; a.dL_dscale[3 * idx + 1] = dscale[1]; a.dL_dscale[3 * idx + 2] = dscale[2];
-    reinterpret_cast<float4*>(a.dL_drot)[idx] = dq;
+    // ---- sinks: gradient tensors (each optional) and / or the in-place Adam update of this Gaussian's 14 small scalars
+    if (a.dL_dopacity) a.dL_dopacity[idx] = g_op;
+    if (a.dL_dmean3D) { a.dL_dmean3D[3 * idx] = dmean[0]; a.dL_dmean3D[3 * idx + 1] = dmean[1]; a.dL_dmean3D[3 * idx + 2] = dmean[2]; }
+    if (a.dL_ddc) { a.dL_ddc[3 * idx] = ddc[0]; a.dL_ddc[3 * idx + 1] = ddc[1]; a.dL_ddc[3 * idx + 2] = ddc[2]; }
+    if (a.dL_dscale) { a.dL_dscale[3 * idx] = dscale[0]; a.dL_dscale[3 * idx + 1] = dscale[1]; a.dL_dscale[3 * idx + 2] = dscale[2]; }
+    if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = dq;
+    if (a.adam.on) {
+        const AdamFusedArgs& A = a.adam;
+        const float dqv[4] = {dq.x, dq.y, dq.z, dq.w};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            adam_scalar(A.p[0][3 * idx + k], dmean[k], A.m[0][3 * idx + k], A.v[0][3 * idx + k], A.lr[0], A.b1, A.b2, A.eps);
+            adam_scalar(A.p[1][3 * idx + k], ddc[k], A.m[1][3 * idx + k], A.v[1][3 * idx + k], A.lr[1], A.b1, A.b2, A.eps);
+            adam_scalar(A.p[4][3 * idx + k], dscale[k], A.m[4][3 * idx + k], A.v[4][3 * idx + k], A.lr[4], A.b1, A.b2, A.eps);
+        }
+        adam_scalar(A.p[3][idx], g_op, A.m[3][idx], A.v[3][idx], A.lr[3], A.b1, A.b2, A.eps);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            adam_scalar(A.p[5][4 * idx + k], dqv[k], A.m[5][4 * idx + k], A.v[5][4 * idx + k], A.lr[5], A.b1, A.b2, A.eps);
+    }
 }
 
 int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
 {
-    if (a.M == 15 && a.shs && a.dL_dsh) {
+    if (a.M == 15 && a.shs && (a.dL_dsh || a.adam.on)) {
         GS_LAUNCH(K_PREPROCESS_BWD, preprocess_bwd_kernel<true>, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
     } else {
         GS_LAUNCH(K_PREPROCESS_BWD, preprocess_bwd_kernel<false>, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);

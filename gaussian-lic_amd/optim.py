@@ -71,6 +71,23 @@ class SparseGaussianAdam:
         _lib.check(_lib.lib().gslic_adam_update_groups(arr, len(groups), _lib.ptr(vis), self.betas[0], self.betas[1], self.eps,
                                                        self.N, _lib.current_stream_ptr()))
 
+    def fused_descriptor(self):
+        """gslic_adam_fused for gslic_rasterize_backward_adam: the six groups' parameters and moments, learning rates, betas, eps."""
+        d = _lib.AdamFused()
+        for i, prm in enumerate(self.params):
+            st = self._ensure_state(i)
+            d.param[i] = prm.data_ptr() if prm.numel() else None
+            d.exp_avg[i] = st["exp_avg"].data_ptr() if prm.numel() else None
+            d.exp_avg_sq[i] = st["exp_avg_sq"].data_ptr() if prm.numel() else None
+            d.lr[i] = self.lrs[i]
+        d.b1, d.b2, d.eps = self.betas[0], self.betas[1], self.eps
+        return d
+
+    def count_step(self):
+        for st in self.state:
+            if st is not None:
+                st["step"] += 1
+
     def zero_grad(self, set_to_none=True):
         for p in self.params:
             if set_to_none:

@@ -84,7 +84,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                                  projmatrix, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, dL_dout_color, dc, sh,
                                  degree, campos, geomBuffer, R, binningBuffer, imageBuffer, B, sampleBuffer, lambda_erank, debug,
-                                 raw_params=False, out=None):
+                                 raw_params=False, out=None, adam=None):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:151-246): returns (dL_dmeans2D, dL_dcolors_precomp,
     dL_dopacities, dL_dmeans3D, dL_dcov3Ds_precomp, dL_ddc, dL_dsh, dL_dscales, dL_drotations).
     raw_params=True: scales / rotations are raw and dL_dopacities / dL_dscales / dL_drotations are w.r.t. the raw parameters."""
@@ -94,6 +94,20 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     M = sh.size(1) if sh is not None and sh.size(0) != 0 else 0
     mk = (lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)) if P != 0 else \
         (lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev))
+    if adam is not None:
+        # single-GPU fast path: Adam applied inside the backward kernel, no gradient tensors at all (gslic_rasterize_backward_adam)
+        means3D, dc, scales, rotations, dL = map(_f32c, (means3D, dc, scales, rotations, dL_dout_color))
+        sh_c = _f32c(sh) if M > 0 else None
+        viewmatrix, projmatrix, campos, background = map(_f32c, (viewmatrix, projmatrix, campos, background))
+        prm = _params(P, degree, M, H, W, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier, False, debug, False, True)
+        p = _lib.ptr
+        _lib.check(L.gslic_rasterize_backward_adam(
+            ctypes.byref(prm), int(R), int(B), p(background), p(means3D), p(dc), p(sh_c), p(colors), p(scales), p(rotations),
+            p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos), p(radii.contiguous()),
+            ctypes.c_void_p(geomBuffer.data_ptr()), ctypes.c_void_p(binningBuffer.data_ptr()), ctypes.c_void_p(imageBuffer.data_ptr()),
+            ctypes.c_void_p(sampleBuffer.data_ptr()), p(dL), None, None, None, None, None, None, float(lambda_erank), ctypes.byref(adam),
+            _lib.current_stream_ptr()))
+        return None
     if out is not None:
         # caller-provided gradient storage (e.g. views of one flat slab for a zero-copy all-reduce); the tensors the host
         # discards (means2D, conic, colors_precomp, cov3D: rasterizer.cpp:171-182) are not materialised at all

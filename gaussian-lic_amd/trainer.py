@@ -191,7 +191,7 @@ def training_step(model, camera, gt_image, bg, lambda_dssim=LAMBDA_DSSIM, do_ste
     return loss.detach(), visible
 
 
-def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=True):
+def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=True, adam_in_backward=True):
     """The same iteration as training_step — identical arithmetic up to fp32 rounding — on the fused entry points
     (SURVEY.md §8f row 2): sigmoid / exp / normalize and their backward run inside preprocess / preprocess_bwd (raw_params),
     the loss and dL/dimage come from two loss kernels, and there is no autograd graph: 0 LibTorch elementwise launches per step
@@ -209,6 +209,16 @@ def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=Tr
             cam.image_height, cam.image_width, float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dc, rest,
             model.sh_degree, cam.d_camera_center, False, False, False, raw_params=True)
         dL_dimage, terms = fl.forward_backward(image, gt_image)
+        if do_step and adam_in_backward and not _dist_on():
+            # single GPU: nothing to exchange, so the Adam update runs inside the per-Gaussian backward kernel while the
+            # gradients are still in registers / LDS (bit-identical to backward + SparseGaussianAdam.step, ~2 GB less HBM traffic)
+            rz.rasterize_gaussians_backward(
+                bg, xyz, radii, e, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx),
+                float(cam.tanfovy), float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dL_dimage, dc, rest,
+                model.sh_degree, cam.d_camera_center, geom, R, binning, img, B, sample, model.lambda_erank, False, raw_params=True,
+                adam=model.optimizer.fused_descriptor())
+            model.optimizer.count_step()
+            return terms, radii > 0
         slab = getattr(model, "_grad_slab", None)
         if slab is None or slab.P != model.P:
             slab = model._grad_slab = GradSlab(model)

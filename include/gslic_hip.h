@@ -163,6 +163,32 @@ int gslic_rasterize_backward(
     void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * gslic_rasterize_backward_adam — single-GPU fast path (no reference counterpart; SURVEY.md §8f row 2 taken one step further):
+ * exactly gslic_rasterize_backward with raw_params = 1 followed by gslic_adam_update_groups(visible = radii > 0) over the six
+ * parameter groups, but the Adam update is applied inside the per-Gaussian backward kernel while the gradients are still in
+ * registers / LDS, so the 236 B/Gaussian of gradients are neither written nor re-read (and no second launch).  Results are
+ * bit-identical to the two-call sequence.  The six gradient output pointers may be NULL (nothing is written) or non-NULL.
+ * Group order everywhere: xyz, features_dc, features_rest, opacity, scaling, rotation (src/gaussian.cpp:399-418);
+ * param[0] / [1] / [2] / [4] / [5] must be the tensors passed as means3D / dc / shs / scales / rotations.
+ * Not usable when gradients must be exchanged between GPUs before the update.
+ */
+typedef struct gslic_adam_fused {
+    float* param[6];
+    float* exp_avg[6];
+    float* exp_avg_sq[6];
+    float lr[6];
+    float b1, b2, eps;
+} gslic_adam_fused;
+int gslic_rasterize_backward_adam(
+    const gslic_raster_params* prm, int32_t R, int32_t B,
+    const float* background, const float* means3D, const float* dc, const float* shs, const float* colors_precomp,
+    const float* scales, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos, const int32_t* radii,
+    char* geom_buffer, char* binning_buffer, char* img_buffer, char* sample_buffer, const float* dL_dpix,
+    float* dL_dopacity, float* dL_dmean3D, float* dL_ddc, float* dL_dsh, float* dL_dscale, float* dL_drot,
+    float lambda_erank, const gslic_adam_fused* adam, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * gslic_adam_update — replaces ADAM::adamUpdate / adamUpdateCUDA (cuda_rasterizer/adam.cu:9-66), reached
  * from adamUpdate (rasterize_points.cu:248-273) <- SparseGaussianAdam::custom_step (optim_utils.h:102-137).
  * In place on param / exp_avg / exp_avg_sq, all [N,M]; rows with visible[g]==0 are left untouched.

@@ -31,7 +31,7 @@ def test_fused_gradients_match_autograd_path(lambda_erank):
     captured = {}
     orig = b.optimizer.step
     b.optimizer.step = lambda grads=None: captured.setdefault("g", [g.clone() for g in grads])
-    terms, vis2 = trainer.training_step_fused(b, cam, gt, bg)
+    terms, vis2 = trainer.training_step_fused(b, cam, gt, bg, adam_in_backward=False)
     assert torch.equal(vis, vis2)
     fl = trainer._default_fused_loss()
     assert abs(float(fl.value(terms)) - float(loss)) < 2e-6
@@ -47,7 +47,7 @@ def test_fused_training_tracks_dropin_training():
     trainer, a, b, cam, gt, bg = _models(20000, 320, 240, 62)
     for _ in range(5):
         trainer.training_step(a, cam, gt, bg)
-        trainer.training_step_fused(b, cam, gt, bg)
+        trainer.training_step_fused(b, cam, gt, bg)      # default: Adam inside the backward kernel
     # Adam without bias correction and eps = 1e-15 (adam.cu:26-37) moves a parameter by ~lr per step whatever the size of
     # its gradient, so where a gradient is ~0 an ulp-level sign difference between the two paths shifts that one parameter
     # by up to lr per step.  Bar: > 99.8 % of the elements agree to 1e-4 of max-abs, and no element is off by more than the
@@ -75,3 +75,16 @@ def test_fused_loss_kernels_match_separate_ops():
     assert rel_err(dL.cpu().numpy(), img.grad.cpu().numpy()) < 1e-5
     dL2, terms2 = fl.forward_backward(img.detach(), gt)      # fixed-order reduction: bit-reproducible
     assert torch.equal(terms, terms2) and torch.equal(dL, dL2)
+
+
+def test_adam_inside_backward_is_bit_identical():
+    """gslic_rasterize_backward_adam == gslic_rasterize_backward (raw) + gslic_adam_update_groups, bit for bit, over several steps."""
+    trainer, a, b, cam, gt, bg = _models(30000, 320, 240, 63, 0.01)
+    for _ in range(4):
+        trainer.training_step_fused(a, cam, gt, bg, adam_in_backward=False)
+        trainer.training_step_fused(b, cam, gt, bg, adam_in_backward=True)
+    for name in a.NAMES:
+        assert torch.equal(getattr(a, name).detach(), getattr(b, name).detach()), name
+    for sa, sb in zip(a.optimizer.state, b.optimizer.state):
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+        assert sa["step"] == sb["step"] == 4
