@@ -37,11 +37,15 @@ def algorithmic_bytes(kernel, s):
     table = {
         # in: xyz 12 + scale 12 + rot 16 + opacity 4 per P; out: radii 4 + tiles 4 per P; per visible: SH 12K in, 48 B record out
         "preprocess": 52 * P + V * (12 * K + 48),
-        # per visible: record 48 + offset 4 in; per instance: key 8 + slot 4 + gaussian id 4 out
-        "keybuild": 8 * P + 52 * V + 16 * R,
-        "sort_hist": 8 * R,                       # keys once per pass
-        "sort_scatter": 24 * R,                   # key+payload in and out, per pass
-        "finalize_lists": 20 * R + 8 * T,         # keys 8 + slot 4 + gather 4 in, list 4 out, ranges
+        # depth sort of the Gaussians: 4-byte key (+ 4-byte id after the first pass) per pass
+        "dsort_hist": 4 * P,
+        "dsort_scatter": 16 * P,
+        "depth_gather": 12 * P,
+        # per Gaussian: order 4 + radius 4; per visible: record 32 + offset 4 in, start 4 out; per instance: tile 4 + gaussian id 4 out
+        "keybuild": 8 * P + 40 * V + 8 * R,
+        "sort_hist": 4 * R,                       # tile keys once per pass
+        "sort_scatter": 24 * R,                   # key + slot + gaussian id in and out, per pass (the first pass reads no slot: 20)
+        "finalize_lists": 4 * R + 8 * T,          # sorted tile ids in, ranges out
         # list 4 + record 48 per instance; checkpoints 4096 per bucket; pix_final 16/px(padded), image 16/px
         "render_fwd": 52 * R + 4096 * B + 16 * Np + 16 * N,
         # checkpoints 4096/bucket; list 4 + slot 4 + record 48 in, partial 48 out per instance; pixel data once: 16 + 12 per px

@@ -30,7 +30,7 @@ static bool g_prof_cur_on = false;
 static const char* const k_names[K_COUNT] = {
     "preprocess", "scan_reduce", "scan_spine", "scan_apply", "keybuild", "sort_hist", "sort_scatter", "finalize_lists",
     "bucket_count", "render_fwd", "render_bwd", "preprocess_bwd", "adam", "ssim_fwd", "ssim_bwd", "knn_minmax", "knn_morton",
-    "knn_boxes", "knn_search", "debug_export", "extend"};
+    "knn_boxes", "knn_search", "debug_export", "extend", "dsort_hist", "dsort_scatter"};
 struct ProfRec { int id; hipEvent_t a, b; };
 static std::vector<ProfRec> g_pending;
 static std::vector<hipEvent_t> g_pool;
@@ -66,11 +66,19 @@ GeomState GeomState::carve(const void* base, size_t P, size_t* bytes)
 {
     Carver c(base);
     GeomState g;
+    g.plan = sort_plan(P, 32);
     g.rec = c.take<float4>(3 * P);
     g.tiles_touched = c.take<uint32_t>(P);
+    g.depth_keys[0] = c.take<uint32_t>(P);
+    g.depth_keys[1] = c.take<uint32_t>(P);
+    g.order[0] = c.take<uint32_t>(P);
+    g.order[1] = c.take<uint32_t>(P);
     g.point_offsets = c.take<uint32_t>(P);
-    g.scan_temp = c.take<uint32_t>(scan_temp_elems(P));
-    g.flags = c.take<uint32_t>(16);
+    g.gauss_start = c.take<uint32_t>(P);
+    g.sort_scratch = c.take<char>(sort_scratch_bytes(g.plan));
+    g.flags = c.take<uint32_t>(64);  // 256 B, so that scan_state follows directly
+    g.scan_state = c.take<char>(scan_state_bytes(P));
+    g.zero_bytes = 64 * sizeof(uint32_t) + scan_state_bytes(P);
     if (bytes) *bytes = c.used(base) + 256;
     return g;
 }
@@ -82,7 +90,6 @@ ImageState ImageState::carve(const void* base, size_t T, size_t* bytes)
     g.bucket_offsets = c.take<uint32_t>(T);
     g.max_contrib = c.take<uint32_t>(T);
     g.pix_final = c.take<float4>(T * GS_TILE_PIX);
-    g.scan_temp = c.take<uint32_t>(scan_temp_elems(T));
     if (bytes) *bytes = c.used(base) + 256;
     return g;
 }
@@ -90,20 +97,13 @@ BinningState BinningState::carve(const void* base, size_t R, int end_bit, bool n
 {
     Carver c(base);
     BinningState g;
-    g.plan = sort_plan(R, end_bit);
-    g.keys[0] = c.take<uint64_t>(R);
-    g.keys[1] = c.take<uint64_t>(R);
-    g.vals[0] = c.take<uint32_t>(R);
-    g.vals[1] = c.take<uint32_t>(R);
-    g.inst_gauss = c.take<uint32_t>(R);
-    g.point_list = c.take<uint32_t>(R);
-    g.hist = c.take<uint32_t>(g.plan.hist_elems);
-    g.scan_temp = c.take<uint32_t>(scan_temp_elems(g.plan.hist_elems));
-    {
-        SortPlan worst = g.plan;
-        worst.passes = 8;  // the layout must not depend on end_bit (backward re-carves with the same R)
-        g.onesweep_state = c.take<char>(onesweep_state_bytes(worst));
+    g.plan = sort_plan(R, end_bit);  // the pass count only picks which ping-pong side holds the result: the layout depends on R alone
+    for (int i = 0; i < 2; i++) {
+        g.tile_keys[i] = c.take<uint32_t>(R);
+        g.slots[i] = c.take<uint32_t>(R);
+        g.gauss[i] = c.take<uint32_t>(R);
     }
+    g.sort_scratch = c.take<char>(sort_scratch_bytes(g.plan));
     g.partials = no_color ? nullptr : c.take<float4>(3 * R);
     if (bytes) *bytes = c.used(base) + 256;
     return g;
@@ -125,7 +125,9 @@ static inline int tile_grid(int W, int H, int& gx, int& gy)
     gy = (H + GS_TILE - 1) / GS_TILE;
     return gx * gy;
 }
-static inline int sort_end_bit(int T) { return 32 + (int)higher_msb((uint32_t)T); }
+static inline int sort_end_bit(int T) { return (int)higher_msb((uint32_t)T); }  // bits of a tile id (the depth half is sorted per Gaussian)
+// GSLIC_SORT_ONESWEEP: bit 0 = depth sort, bit 1 = tile sort use the decoupled-look-back variant (same result bit for bit)
+static inline int onesweep_mask() { static const int m = getenv("GSLIC_SORT_ONESWEEP") ? atoi(getenv("GSLIC_SORT_ONESWEEP")) : 0; return m; }
 
 int adam_update(float*, const float*, float*, float*, const uint8_t*, float, float, float, float, uint32_t, uint32_t, hipStream_t);
 int adam_update_groups(const gslic_adam_group*, int, const uint8_t*, float, float, float, uint32_t, hipStream_t);
@@ -175,7 +177,7 @@ size_t gslic_img_bytes(int32_t W, int32_t H)
 size_t gslic_binning_bytes(int32_t R, int32_t no_color)
 {
     size_t b;
-    BinningState::carve(nullptr, (size_t)(R > 0 ? R : 0), 64, no_color != 0, &b);  // end_bit only changes the pass count
+    BinningState::carve(nullptr, (size_t)(R > 0 ? R : 0), 16, no_color != 0, &b);  // end_bit only changes the pass count
     return b;
 }
 size_t gslic_sample_bytes(int32_t B) { size_t b; SampleState::carve(nullptr, (size_t)(B > 0 ? B : 0), &b); return b; }
@@ -217,7 +219,7 @@ int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_
     if (!img_base) return set_error(GSLIC_ERR_ALLOC, "image allocator returned NULL for %zu bytes", img_bytes);
     ImageState img = ImageState::carve(align256(img_base), (size_t)T, nullptr);
 
-    GS_HIP(hipMemsetAsync(geom.flags, 0, 16 * sizeof(uint32_t), s));
+    GS_HIP(hipMemsetAsync(geom.flags, 0, geom.zero_bytes, s));
     PreprocessArgs pa;
     pa.P = P; pa.D = prm->D; pa.M = prm->M; pa.W = prm->width; pa.H = prm->height; pa.gx = gx; pa.gy = gy;
     pa.focal_y = prm->height / (2.0f * prm->tan_fovy);  // rasterizer_impl.cu:348-349
@@ -226,11 +228,20 @@ int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_
     pa.scale_modifier = prm->scale_modifier; pa.prefiltered = prm->prefiltered; pa.no_color = prm->no_color; pa.raw = prm->raw_params;
     pa.means = means3D; pa.scales = scales; pa.rots = rotations; pa.opac = opacities; pa.dc = dc; pa.shs = shs;
     pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = cam_pos;
-    pa.radii = radii; pa.rec = geom.rec; pa.tiles_touched = geom.tiles_touched; pa.flags = geom.flags;
+    pa.radii = radii; pa.rec = geom.rec; pa.tiles_touched = geom.tiles_touched; pa.depth_keys = geom.depth_keys[0]; pa.flags = geom.flags; pa.ranges = img.ranges;
     GS_TRY(launch_preprocess(pa, s));
     DEBUG_SYNC(prm, s);
 
-    GS_TRY(scan_u32(geom.tiles_touched, geom.point_offsets, (size_t)P, false, geom.scan_temp, s));
+    // Level 1: order the GAUSSIANS by (depth bits, id) — 4 digit passes over P 8-byte pairs instead of over R 12-byte ones —
+    // and hand out emission slots in that order (rasterizer_impl.cu:395 scans in id order; the slot numbering is internal).
+    {
+        SortBuffers sb;
+        sb.keys[0] = geom.depth_keys[0]; sb.keys[1] = geom.depth_keys[1]; sb.v0[0] = geom.order[0]; sb.v0[1] = geom.order[1];
+        sb.v1[0] = sb.v1[1] = nullptr; sb.v0_identity = true;
+        GS_TRY(radix_sort_u32(sb, geom.plan, geom.sort_scratch, (onesweep_mask() & 1) != 0, K_DSORT_HIST, K_DSORT_SCATTER, s));
+    }
+    uint32_t* const order = geom.order[geom.plan.passes & 1];
+    GS_TRY(scan_u32_chained(geom.tiles_touched, order, geom.point_offsets, (size_t)P, false, geom.scan_state, s));
     uint32_t hostbuf[2] = {0, 0};
     GS_HIP(hipMemcpyAsync(&hostbuf[0], geom.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     GS_HIP(hipMemcpyAsync(&hostbuf[1], geom.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -246,22 +257,20 @@ int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_
     if (!bin_base) return set_error(GSLIC_ERR_ALLOC, "binning allocator returned NULL for %zu bytes", bin_bytes);
     BinningState bin = BinningState::carve(align256(bin_base), (size_t)R, end_bit, no_color, nullptr);
 
-    GS_HIP(hipMemsetAsync(img.ranges, 0, (size_t)T * sizeof(uint2), s));  // rasterizer_impl.cu:426
     if (R > 0) {
         KeybuildArgs ka;
-        ka.P = P; ka.gx = gx; ka.gy = gy; ka.radii = radii; ka.rec = geom.rec; ka.offsets = geom.point_offsets;
-        ka.keys = bin.keys[0]; ka.vals = bin.vals[0]; ka.inst_gauss = bin.inst_gauss;
+        ka.P = P; ka.gx = gx; ka.gy = gy; ka.radii = radii; ka.rec = geom.rec; ka.order = order; ka.offsets = geom.point_offsets;
+        ka.tile_keys = bin.tile_keys[0]; ka.gauss = bin.gauss[0]; ka.gauss_start = geom.gauss_start;
         GS_TRY(launch_keybuild(ka, s));
         DEBUG_SYNC(prm, s);
-        // Default: histogram + scan + scatter per digit (no inter-block waiting).  GSLIC_SORT_ONESWEEP=1 selects the single-pass
-        // decoupled-look-back variant: same result bit for bit, 8 launches instead of 30, measured within noise end to end on
-        // config 3 (its look-back polling costs what the saved launches gain) — kept for the next round's tuning.
-        static const bool onesweep = getenv("GSLIC_SORT_ONESWEEP") != nullptr;
-        if (onesweep) GS_TRY(radix_sort_pairs_onesweep(bin.keys, bin.vals, bin.plan, bin.onesweep_state, s));
-        else GS_TRY(radix_sort_pairs(bin.keys, bin.vals, bin.plan, bin.hist, bin.scan_temp, s));
+        // Level 2: stable sort of the instances on the tile id alone (ceil(log2(tiles)/8) digit passes, 2 at 1080p), carrying the
+        // emission slot (identity at the start) and the Gaussian id; the sorted Gaussian-id payload IS the point list.
+        SortBuffers sb;
+        for (int i = 0; i < 2; i++) { sb.keys[i] = bin.tile_keys[i]; sb.v0[i] = bin.slots[i]; sb.v1[i] = bin.gauss[i]; }
+        sb.v0_identity = true;
+        GS_TRY(radix_sort_u32(sb, bin.plan, bin.sort_scratch, (onesweep_mask() & 2) != 0, K_SORT_HIST, K_SORT_SCATTER, s));
         DEBUG_SYNC(prm, s);
-        const int fin = bin.plan.passes & 1;
-        GS_TRY(launch_finalize_lists(R, bin.keys[fin], bin.vals[fin], bin.inst_gauss, bin.point_list, img.ranges, s));
+        GS_TRY(launch_finalize_ranges(R, bin.sorted_tiles(), img.ranges, s));
         DEBUG_SYNC(prm, s);
     }
 
@@ -269,8 +278,7 @@ int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_
     memset(&smp, 0, sizeof(smp));
     uint32_t B = 0;
     if (!no_color) {
-        GS_TRY(launch_bucket_count(T, img.ranges, img.bucket_offsets, s));
-        GS_TRY(scan_u32(img.bucket_offsets, img.bucket_offsets, (size_t)T, false, img.scan_temp, s));
+        GS_TRY(launch_bucket_scan(T, img.ranges, img.bucket_offsets, s));
         GS_HIP(hipMemcpyAsync(&hostbuf[0], img.bucket_offsets + (T - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         GS_HIP(hipStreamSynchronize(s));  // rasterizer_impl.cu:442
         B = hostbuf[0];
@@ -283,7 +291,7 @@ int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_
 
     RenderFwdArgs ra;
     ra.W = prm->width; ra.H = prm->height; ra.gx = gx; ra.gy = gy; ra.no_color = prm->no_color;
-    ra.ranges = img.ranges; ra.point_list = bin.point_list; ra.rec = geom.rec; ra.bucket_offsets = img.bucket_offsets;
+    ra.ranges = img.ranges; ra.point_list = bin.point_list(); ra.rec = geom.rec; ra.bucket_offsets = img.bucket_offsets;
     ra.bucket_to_tile = smp.bucket_to_tile; ra.ckpt = smp.ckpt; ra.pix_final = img.pix_final; ra.max_contrib = img.max_contrib;
     ra.out_color = out_color; ra.out_final_T = out_final_T;
     GS_TRY(launch_render_fwd(ra, s));
@@ -334,7 +342,7 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
 
     RenderBwdArgs rb;
     rb.W = prm->width; rb.H = prm->height; rb.gx = gx; rb.B = B;
-    rb.ranges = img.ranges; rb.point_list = bin.point_list; rb.inst_slot = bin.vals[bin.plan.passes & 1]; rb.rec = geom.rec;
+    rb.ranges = img.ranges; rb.point_list = bin.point_list(); rb.inst_slot = bin.inst_slot(); rb.rec = geom.rec;
     rb.bucket_offsets = img.bucket_offsets; rb.bucket_to_tile = smp.bucket_to_tile; rb.ckpt = smp.ckpt; rb.pix_final = img.pix_final;
     rb.max_contrib = img.max_contrib; rb.dL_dpix = dL_dpix; rb.partials = bin.partials;
     GS_TRY(launch_render_bwd(rb, s));
@@ -347,7 +355,7 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
     pb.limx_neg = prm->limx_neg; pb.limx_pos = prm->limx_pos; pb.limy_neg = prm->limy_neg; pb.limy_pos = prm->limy_pos;
     pb.scale_modifier = prm->scale_modifier; pb.lambda_erank = lambda_erank;
     pb.means = means3D; pb.scales = scales; pb.rots = rotations; pb.dc = dc; pb.shs = shs; pb.view = viewmatrix; pb.proj = projmatrix;
-    pb.campos = cam_pos; pb.radii = radii; pb.rec = geom.rec; pb.offsets = geom.point_offsets; pb.partials = bin.partials;
+    pb.campos = cam_pos; pb.radii = radii; pb.rec = geom.rec; pb.tiles_touched = geom.tiles_touched; pb.gauss_start = geom.gauss_start; pb.partials = bin.partials;
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_ddc = dL_ddc; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale;
     pb.dL_drot = dL_drot;
@@ -545,6 +553,13 @@ __global__ __launch_bounds__(256) void export_geom_kernel(int P, const float4* _
     if (o_co) { o_co[4 * i] = r0.z; o_co[4 * i + 1] = r0.w; o_co[4 * i + 2] = r1.x; o_co[4 * i + 3] = r1.y; }
     if (o_rgb) { o_rgb[3 * i] = r1.z; o_rgb[3 * i + 1] = r1.w; o_rgb[3 * i + 2] = r2.x; }
 }
+// the reference's sorted 64-bit keys (tile << 32 | depth bits), rebuilt from the sorted tile ids and the point list
+__global__ __launch_bounds__(256) void export_keys_kernel(uint32_t R, const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ point_list,
+                                                          const float4* __restrict__ rec, uint64_t* __restrict__ o)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k < R) o[k] = ((uint64_t)tiles[k] << 32) | __float_as_uint(rec[3 * (size_t)point_list[k] + 2].y);
+}
 __global__ __launch_bounds__(256) void export_ncontrib_kernel(int W, int H, int gx, const float4* __restrict__ pix_final, uint32_t* o)
 {
     const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -574,9 +589,10 @@ extern "C" int gslic_debug_export(const gslic_raster_params* prm, int32_t R, int
         GS_LAUNCH(K_DEBUG_EXPORT, export_geom_kernel, dim3(div_up(P, 256)), dim3(256), 0, s, P, (const float4*)geom.rec,
                   (const uint32_t*)geom.tiles_touched, tiles_touched, means2D, depths, conic_opacity, rgb);
     if (R > 0 && sorted_keys)
-        GS_HIP(hipMemcpyAsync(sorted_keys, bin.keys[bin.plan.passes & 1], (size_t)R * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+        GS_LAUNCH(K_DEBUG_EXPORT, export_keys_kernel, dim3(((uint32_t)R + 255u) / 256u), dim3(256), 0, s, (uint32_t)R,
+                  (const uint32_t*)bin.sorted_tiles(), (const uint32_t*)bin.point_list(), (const float4*)geom.rec, sorted_keys);
     if (R > 0 && point_list)
-        GS_HIP(hipMemcpyAsync(point_list, bin.point_list, (size_t)R * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        GS_HIP(hipMemcpyAsync(point_list, bin.point_list(), (size_t)R * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     if (ranges) GS_HIP(hipMemcpyAsync(ranges, img.ranges, (size_t)T * sizeof(uint2), hipMemcpyDeviceToDevice, s));
     if (!prm->no_color) {
         if (max_contrib) GS_HIP(hipMemcpyAsync(max_contrib, img.max_contrib, (size_t)T * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));

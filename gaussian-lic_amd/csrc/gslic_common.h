@@ -52,6 +52,8 @@ enum KernelId {
     K_KNN_SEARCH,
     K_DEBUG_EXPORT,
     K_EXTEND,
+    K_DSORT_HIST,
+    K_DSORT_SCATTER,
     K_COUNT
 };
 void prof_begin(int id, hipStream_t s);
@@ -97,6 +99,10 @@ static inline uint32_t higher_msb(uint32_t n)
 size_t scan_temp_elems(size_t n);  // u32 elements of scratch needed by scan_u32 for n inputs
 // inclusive (or exclusive) prefix sum of n u32 values; in == out allowed
 int scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, uint32_t* temp, hipStream_t s);
+// the same in ONE launch (chained tiles); optional gather: scans in[gather[i]].  `zeroed_state`: scan_state_bytes(n) bytes the
+// caller has zeroed on the stream (it is consumed: zero it again before the next scan)
+size_t scan_state_bytes(size_t n);
+int scan_u32_chained(const uint32_t* in, const uint32_t* gather, uint32_t* out, size_t n, bool exclusive, void* zeroed_state, hipStream_t s);
 
 // radix_sort.hip ------------------------------------------------------------------------------------------
 #define GS_SORT_ITEMS 16
@@ -104,26 +110,37 @@ int scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, uint32
 #define GS_SORT_TILE (GS_SORT_ITEMS * GS_SORT_BLOCK)
 struct SortPlan {
     size_t n;
-    int passes;      // ceil(end_bit / 8)
+    int passes;      // ceil(end_bit / 8), at most 4
     size_t nblk;     // ceil(n / GS_SORT_TILE)
     size_t hist_elems;  // 256 * nblk
 };
 SortPlan sort_plan(size_t n, int end_bit);
-// Stable LSD radix sort of (u64 key, u32 value) pairs on bits [0, end_bit).  Ping-pongs between the two
-// buffer pairs starting from index 0; the result is in buffers [plan.passes & 1].
-int radix_sort_pairs(uint64_t* keys[2], uint32_t* vals[2], const SortPlan& plan, uint32_t* hist,
-                     uint32_t* scan_temp, hipStream_t s);
-// Onesweep variant (single pass per digit, decoupled look-back); `state` = onesweep_state_bytes(plan) bytes of device scratch.
-size_t onesweep_state_bytes(const SortPlan& plan);
-int radix_sort_pairs_onesweep(uint64_t* keys[2], uint32_t* vals[2], const SortPlan& plan, void* state, hipStream_t s);
+// Stable LSD radix sort of u32 keys on bits [0, end_bit) carrying one (v1[0] == NULL) or two u32 payloads.  Ping-pongs between
+// the two buffer sets starting from index 0; the result is in buffers [plan.passes & 1].  v0_identity: the first payload starts
+// as the element index (argsort) and v0[0] is never read.  `scratch`: sort_scratch_bytes(plan) bytes.  onesweep selects the
+// decoupled-look-back variant (same result bit for bit).  id_*: profiling slots the launches are booked under.
+struct SortBuffers {
+    uint32_t* keys[2];
+    uint32_t* v0[2];
+    uint32_t* v1[2];
+    bool v0_identity;
+};
+size_t sort_scratch_bytes(const SortPlan& plan);
+int radix_sort_u32(const SortBuffers& b, const SortPlan& plan, void* scratch, bool onesweep, int id_hist, int id_scatter, hipStream_t s);
 
 // opaque scratch layouts ----------------------------------------------------------------------------------
 struct GeomState {
     float4* rec;             // [3P] per Gaussian: {mx,my,conic.x,conic.y} {conic.z,opacity,r,g} {b,depth,clamped-bits,0}
     uint32_t* tiles_touched; // [P]
-    uint32_t* point_offsets; // [P] inclusive scan of tiles_touched
-    uint32_t* scan_temp;
-    uint32_t* flags;         // [16] device-side status words ([0] = prefiltered violation)
+    uint32_t* depth_keys[2]; // [P] ping-pong: depth bits (0xffffffff when culled)
+    uint32_t* order[2];      // [P] ping-pong: Gaussian ids; after the depth sort order[0] = ids by ascending (depth, id)
+    uint32_t* point_offsets; // [P] inclusive scan of tiles_touched in DEPTH order: emission slots of order[0][i] end here
+    uint32_t* gauss_start;   // [P] first emission slot of Gaussian g (written for visible Gaussians only)
+    void* sort_scratch;
+    uint32_t* flags;         // [64] device-side status words ([0] = prefiltered violation), zeroed together with scan_state
+    void* scan_state;        // chained-scan state of the emission-slot scan (directly behind flags)
+    size_t zero_bytes;       // flags + scan_state
+    SortPlan plan;
     static GeomState carve(const void* base, size_t P, size_t* bytes);
 };
 struct ImageState {
@@ -131,19 +148,18 @@ struct ImageState {
     uint32_t* bucket_offsets; // [T] inclusive scan of ceil(n_t / GS_BUCKET)
     uint32_t* max_contrib;    // [T]
     float4* pix_final;        // [T*256] tile-major {C.r,C.g,C.b, n_contrib bits}
-    uint32_t* scan_temp;
     static ImageState carve(const void* base, size_t T, size_t* bytes);
 };
 struct BinningState {
-    uint64_t* keys[2];        // [R] ping-pong
-    uint32_t* vals[2];        // [R] ping-pong payload = emission slot u
-    uint32_t* inst_gauss;     // [R] emission slot -> Gaussian id
-    uint32_t* point_list;     // [R] sorted position -> Gaussian id
-    uint32_t* hist;           // [256 * nblk]
-    uint32_t* scan_temp;
-    void* onesweep_state;     // look-back status words + global digit histograms
+    uint32_t* tile_keys[2];   // [R] ping-pong: tile id of the instance
+    uint32_t* slots[2];       // [R] ping-pong payload: emission slot u (where the backward writes the instance's partials)
+    uint32_t* gauss[2];       // [R] ping-pong payload: Gaussian id; gauss[passes & 1] after the sort IS the point list
+    void* sort_scratch;
     float4* partials;         // [3R] per emission slot: 9 partial gradients (+3 pad), only when !no_color
     SortPlan plan;
+    uint32_t* point_list() const { return gauss[plan.passes & 1]; }
+    uint32_t* inst_slot() const { return slots[plan.passes & 1]; }
+    uint32_t* sorted_tiles() const { return tile_keys[plan.passes & 1]; }
     static BinningState carve(const void* base, size_t R, int end_bit, bool no_color, size_t* bytes);
 };
 struct SampleState {

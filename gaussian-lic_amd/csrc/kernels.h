@@ -13,6 +13,8 @@ struct PreprocessArgs {
     int32_t* radii;
     float4* rec;
     uint32_t* tiles_touched;
+    uint32_t* depth_keys;  // [P] depth bits, 0xffffffff when culled
+    uint2* ranges;         // [gx*gy] zeroed here (rasterizer_impl.cu:426) to save a memset launch
     uint32_t* flags;
 };
 int launch_preprocess(const PreprocessArgs& a, hipStream_t s);
@@ -21,15 +23,15 @@ struct KeybuildArgs {
     int P, gx, gy;
     const int32_t* radii;
     const float4* rec;
-    const uint32_t* offsets;
-    uint64_t* keys;
-    uint32_t* vals;
-    uint32_t* inst_gauss;
+    const uint32_t* order;     // [P] Gaussian ids by ascending (depth, id)
+    const uint32_t* offsets;   // [P] inclusive scan of tiles_touched[order[i]]
+    uint32_t* tile_keys;       // [R] out: tile id per emission slot
+    uint32_t* gauss;           // [R] out: Gaussian id per emission slot
+    uint32_t* gauss_start;     // [P] out: first emission slot of each visible Gaussian
 };
 int launch_keybuild(const KeybuildArgs& a, hipStream_t s);
-int launch_finalize_lists(uint32_t R, const uint64_t* keys, const uint32_t* slots, const uint32_t* inst_gauss,
-                          uint32_t* point_list, uint2* ranges, hipStream_t s);
-int launch_bucket_count(int T, const uint2* ranges, uint32_t* bucket_count, hipStream_t s);
+int launch_finalize_ranges(uint32_t R, const uint32_t* sorted_tiles, uint2* ranges, hipStream_t s);
+int launch_bucket_scan(int T, const uint2* ranges, uint32_t* bucket_offsets, hipStream_t s);  // scan.hip
 
 struct RenderFwdArgs {
     int W, H, gx, gy, no_color;
@@ -76,7 +78,8 @@ struct PreprocessBwdArgs {
     const float *means, *scales, *rots, *dc, *shs, *view, *proj, *campos;
     const int32_t* radii;
     const float4* rec;
-    const uint32_t* offsets;
+    const uint32_t* tiles_touched;
+    const uint32_t* gauss_start;
     const float4* partials;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_ddc, *dL_dsh, *dL_dscale, *dL_drot;
     AdamFusedArgs adam;

@@ -49,7 +49,7 @@ __device__ __forceinline__ uint32_t prep_morton(uint32_t x)
 }
 
 __global__ __launch_bounds__(256) void knn_morton_kernel(int P, const float* __restrict__ pts, const float* __restrict__ mm,
-                                                         uint64_t* __restrict__ codes, uint32_t* __restrict__ ids)
+                                                         uint32_t* __restrict__ codes, uint32_t* __restrict__ ids)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void knn_morton_kernel(int P, const float* __r
         // float -> uint32 conversion: NaN/negative -> 0 (degenerate axis), matching CUDA's saturating cast
         c[k] = prep_morton((f > 0.f) ? (uint32_t)fminf(f, 4294967040.f) : 0u);
     }
-    codes[i] = (uint64_t)(c[0] | (c[1] << 1) | (c[2] << 2));
+    codes[i] = (uint32_t)(c[0] | (c[1] << 1) | (c[2] << 2));
     ids[i] = (uint32_t)i;
 }
 
@@ -148,18 +148,17 @@ int knn_mean_dist2(int P, const float* points, float* mean_dists, gslic_alloc_fn
     size_t bytes = 0;
     {
         Carver c(nullptr);
-        c.take<uint64_t>(P); c.take<uint64_t>(P); c.take<uint32_t>(P); c.take<uint32_t>(P);
-        c.take<uint32_t>(plan.hist_elems); c.take<uint32_t>(scan_temp_elems(plan.hist_elems));
+        c.take<uint32_t>(P); c.take<uint32_t>(P); c.take<uint32_t>(P); c.take<uint32_t>(P);
+        c.take<char>(sort_scratch_bytes(plan));
         c.take<float>(3 * (size_t)P); c.take<float>(6 * (size_t)nb); c.take<float>(8);
         bytes = c.used(nullptr) + 256;
     }
     char* base = alloc(ctx, bytes);
     if (!base) return set_error(GSLIC_ERR_ALLOC, "knn scratch allocator returned NULL for %zu bytes", bytes);
     Carver c(base);
-    uint64_t* keys[2] = {c.take<uint64_t>(P), c.take<uint64_t>(P)};
+    uint32_t* keys[2] = {c.take<uint32_t>(P), c.take<uint32_t>(P)};
     uint32_t* vals[2] = {c.take<uint32_t>(P), c.take<uint32_t>(P)};
-    uint32_t* hist = c.take<uint32_t>(plan.hist_elems);
-    uint32_t* stemp = c.take<uint32_t>(scan_temp_elems(plan.hist_elems));
+    void* sort_scratch = c.take<char>(sort_scratch_bytes(plan));
     float* sorted = c.take<float>(3 * (size_t)P);
     float* boxes = c.take<float>(6 * (size_t)nb);
     float* mm = c.take<float>(8);
@@ -168,7 +167,9 @@ int knn_mean_dist2(int P, const float* points, float* mean_dists, gslic_alloc_fn
     if (mblocks > 1024) mblocks = 1024;
     GS_LAUNCH(K_KNN_MINMAX, knn_minmax_kernel, dim3(mblocks), dim3(256), 0, s, P, points, mm);
     GS_LAUNCH(K_KNN_MORTON, knn_morton_kernel, dim3(div_up(P, 256)), dim3(256), 0, s, P, points, (const float*)mm, keys[0], vals[0]);
-    GS_TRY(radix_sort_pairs(keys, vals, plan, hist, stemp, s));
+    SortBuffers sb;
+    sb.keys[0] = keys[0]; sb.keys[1] = keys[1]; sb.v0[0] = vals[0]; sb.v0[1] = vals[1]; sb.v1[0] = sb.v1[1] = nullptr; sb.v0_identity = false;
+    GS_TRY(radix_sort_u32(sb, plan, sort_scratch, false, K_SORT_HIST, K_SORT_SCATTER, s));
     const uint32_t* order = vals[plan.passes & 1];
     GS_LAUNCH(K_KNN_BOXES, knn_boxes_kernel, dim3(nb), dim3(BOX), 0, s, P, points, order, sorted, boxes);
     GS_LAUNCH(K_KNN_SEARCH, knn_search_kernel, dim3(div_up(P, 256)), dim3(256), 0, s, P, (const float*)sorted, order,

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a)
     __shared__ float lds_sh[LDS_SH ? 256 * 45 : 4];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    for (int t = idx; t < a.gx * a.gy; t += gridDim.x * 256) a.ranges[t] = make_uint2(0u, 0u);
     if constexpr (LDS_SH) {
         const int row0 = blockIdx.x * 256;
         const int rows = (a.P - row0) < 256 ? (a.P - row0) : 256;
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a)
     if (idx < a.P) {
         a.radii[idx] = visible ? radius : 0;
         a.tiles_touched[idx] = visible ? cnt : 0u;
+        a.depth_keys[idx] = visible ? __float_as_uint(depth) : 0xffffffffu;  // low half of the reference's sort key (forward.cu:254)
     }
     if constexpr (LDS_SH) __syncthreads();  // SH rows have landed in LDS (block-uniform: no thread has returned yet)
     if (!visible) return;
@@ -222,23 +224,28 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a)
     rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), 0.f);
 }
 
-// Emission slot u in [offsets[g-1], offsets[g]) in row-major tile order; key = tile << 32 | depth bits;
-// payload = u (so the backward can write per-instance partial gradients contiguously per Gaussian).
+// Thread i emits the instances of Gaussian g = order[i] (the i-th in ascending (depth, id) order) into the emission slots
+// u in [offsets[i-1], offsets[i]), tiles in row-major order: tile_keys[u] = tile, gauss[u] = g.  Emitting in depth order
+// makes the list "sorted by depth, ties by id" already, so a STABLE sort on the tile id alone yields exactly the order the
+// reference's 64-bit (tile << 32 | depth) sort produces (rasterizer_impl.cu:86-128, 419-424).  The slot u is also where the
+// backward writes the instance's partial gradients: contiguous per Gaussian, starting at gauss_start[g].
 __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const bool active = idx < a.P && a.radii[idx] > 0;
+    const int idx = i < a.P ? (int)a.order[i] : 0;
+    const int radius = i < a.P ? a.radii[idx] : 0;
+    const bool active = radius > 0;
     float mx = 0, my = 0, cA = 0, cB = 0, cC = 0, thr = 0;
-    uint32_t dbits = 0, off = 0;
+    uint32_t off = 0;
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     if (active) {
-        const float4 r0 = a.rec[3 * (size_t)idx], r1 = a.rec[3 * (size_t)idx + 1], r2 = a.rec[3 * (size_t)idx + 2];
+        const float4 r0 = a.rec[3 * (size_t)idx], r1 = a.rec[3 * (size_t)idx + 1];
         mx = r0.x; my = r0.y; cA = r0.z; cB = r0.w; cC = r1.x;
         thr = cull_threshold(r1.y);
-        dbits = __float_as_uint(r2.y);
-        off = (idx == 0) ? 0u : a.offsets[idx - 1];
-        get_rect(mx, my, a.radii[idx], a.gx, a.gy, x0, y0, x1, y1);
+        off = (i == 0) ? 0u : a.offsets[i - 1];
+        a.gauss_start[idx] = off;
+        get_rect(mx, my, radius, a.gx, a.gy, x0, y0, x1, y1);
     }
     const int rw = x1 - x0;
     const int ntiles = active ? rw * (y1 - y0) : 0;
@@ -247,9 +254,8 @@ __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
         const int nseq = ntiles < SEQ_TILES ? ntiles : SEQ_TILES;
         for (int t = 0; t < nseq; t++) {
             if (tile_min_power(cA, cB, cC, mx, my, tx, ty) <= thr) {
-                a.keys[off] = ((uint64_t)(uint32_t)(ty * a.gx + tx) << 32) | dbits;
-                a.vals[off] = off;
-                a.inst_gauss[off] = (uint32_t)idx;
+                a.tile_keys[off] = (uint32_t)(ty * a.gx + tx);
+                a.gauss[off] = (uint32_t)idx;
                 off++;
             }
             if (++tx == x1) { tx = x0; ++ty; }
@@ -263,7 +269,6 @@ __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
         const float smx = readlane_f(mx, src), smy = readlane_f(my, src), sthr = readlane_f(thr, src);
         const int sx0 = __builtin_amdgcn_readlane(x0, src), sy0 = __builtin_amdgcn_readlane(y0, src);
         const int srw = __builtin_amdgcn_readlane(rw, src), sn = __builtin_amdgcn_readlane(ntiles, src);
-        const uint32_t sd = readlane_u(dbits, src);
         const uint32_t sidx = (uint32_t)__builtin_amdgcn_readlane(idx, src);
         uint32_t soff = readlane_u(off, src);
         for (int base = SEQ_TILES; base < sn; base += 64) {
@@ -274,42 +279,30 @@ __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
             const uint64_t m = __ballot(ok);
             if (ok) {
                 const uint32_t o = soff + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                a.keys[o] = ((uint64_t)(uint32_t)(ty * a.gx + tx) << 32) | sd;
-                a.vals[o] = o;
-                a.inst_gauss[o] = sidx;
+                a.tile_keys[o] = (uint32_t)(ty * a.gx + tx);
+                a.gauss[o] = sidx;
             }
             soff += (uint32_t)__popcll(m);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void finalize_lists_kernel(uint32_t R, const uint64_t* __restrict__ keys,
-                                                             const uint32_t* __restrict__ slots,
-                                                             const uint32_t* __restrict__ inst_gauss,
-                                                             uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
+// tile ranges of the sorted instance list (identifyTileRanges, rasterizer_impl.cu:131-156)
+__global__ __launch_bounds__(256) void finalize_ranges_kernel(uint32_t R, const uint32_t* __restrict__ tiles, uint2* __restrict__ ranges)
 {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= R) return;
-    const uint32_t tile = (uint32_t)(keys[k] >> 32);
-    point_list[k] = inst_gauss[slots[k]];
+    const uint32_t tile = tiles[k];
     if (k == 0) {
         ranges[tile].x = 0;
     } else {
-        const uint32_t prev = (uint32_t)(keys[k - 1] >> 32);
+        const uint32_t prev = tiles[k - 1];
         if (tile != prev) {
             ranges[prev].y = k;
             ranges[tile].x = k;
         }
     }
     if (k == R - 1) ranges[tile].y = R;
-}
-
-__global__ __launch_bounds__(256) void bucket_count_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ bucket_count)
-{
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= T) return;
-    const uint2 r = ranges[t];
-    bucket_count[t] = (r.y - r.x + (GS_BUCKET - 1)) / GS_BUCKET;
 }
 
 int launch_preprocess(const PreprocessArgs& a, hipStream_t s)
@@ -326,18 +319,10 @@ int launch_keybuild(const KeybuildArgs& a, hipStream_t s)
     GS_LAUNCH(K_KEYBUILD, keybuild_kernel, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
     return GSLIC_OK;
 }
-int launch_finalize_lists(uint32_t R, const uint64_t* keys, const uint32_t* slots, const uint32_t* inst_gauss,
-                          uint32_t* point_list, uint2* ranges, hipStream_t s)
+int launch_finalize_ranges(uint32_t R, const uint32_t* sorted_tiles, uint2* ranges, hipStream_t s)
 {
     if (R == 0) return GSLIC_OK;
-    GS_LAUNCH(K_FINALIZE_LISTS, finalize_lists_kernel, dim3((R + 255u) / 256u), dim3(256), 0, s, R, keys, slots, inst_gauss,
-              point_list, ranges);
+    GS_LAUNCH(K_FINALIZE_LISTS, finalize_ranges_kernel, dim3((R + 255u) / 256u), dim3(256), 0, s, R, sorted_tiles, ranges);
     return GSLIC_OK;
 }
-int launch_bucket_count(int T, const uint2* ranges, uint32_t* bucket_count, hipStream_t s)
-{
-    GS_LAUNCH(K_BUCKET_COUNT, bucket_count_kernel, dim3(div_up(T, 256)), dim3(256), 0, s, T, ranges, bucket_count);
-    return GSLIC_OK;
-}
-
 }  // namespace gslic

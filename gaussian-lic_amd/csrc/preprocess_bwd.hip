@@ -97,24 +97,43 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreprocessBwdArgs a
         const AdamFusedArgs& A = a.adam;
         if (rows == 256) {
             const float4* s4 = reinterpret_cast<const float4*>(lds_sh);
-            for (int i = threadIdx.x; i < 256 * 45 / 4; i += 256) {
-                const float4 g = s4[i];
-                if (a.dL_dsh) reinterpret_cast<float4*>(a.dL_dsh + base)[i] = g;
-                if (A.on) {
-                    const int e = 4 * i;
-                    const bool v0 = lds_vis[e / 45], v1 = lds_vis[(e + 1) / 45], v2 = lds_vis[(e + 2) / 45], v3 = lds_vis[(e + 3) / 45];
-                    if (v0 | v1 | v2 | v3) {
-                        float4 p = reinterpret_cast<float4*>(A.p[2] + base)[i];
-                        float4 m = reinterpret_cast<float4*>(A.m[2] + base)[i];
-                        float4 v = reinterpret_cast<float4*>(A.v[2] + base)[i];
-                        if (v0) adam_scalar(p.x, g.x, m.x, v.x, A.lr[2], A.b1, A.b2, A.eps);
-                        if (v1) adam_scalar(p.y, g.y, m.y, v.y, A.lr[2], A.b1, A.b2, A.eps);
-                        if (v2) adam_scalar(p.z, g.z, m.z, v.z, A.lr[2], A.b1, A.b2, A.eps);
-                        if (v3) adam_scalar(p.w, g.w, m.w, v.w, A.lr[2], A.b1, A.b2, A.eps);
-                        reinterpret_cast<float4*>(A.p[2] + base)[i] = p;
-                        reinterpret_cast<float4*>(A.m[2] + base)[i] = m;
-                        reinterpret_cast<float4*>(A.v[2] + base)[i] = v;
+            constexpr int NV = 256 * 45 / 4, U = 4;
+            // U independent float4 triples (param, exp_avg, exp_avg_sq) in flight per thread: the kernel runs at 3 waves/SIMD
+            // (LDS-limited), so memory-level parallelism has to come from inside the wave
+            for (int i0 = threadIdx.x; i0 < NV; i0 += 256 * U) {
+                float4 g[U], p[U], m[U], v[U];
+                bool vis[U][4], any[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int i = i0 + 256 * u;
+                    any[u] = false;
+                    if (i < NV) {
+                        g[u] = s4[i];
+                        if (a.dL_dsh) reinterpret_cast<float4*>(a.dL_dsh + base)[i] = g[u];
+                        if (A.on) {
+                            const int e = 4 * i;
+                            vis[u][0] = lds_vis[e / 45]; vis[u][1] = lds_vis[(e + 1) / 45];
+                            vis[u][2] = lds_vis[(e + 2) / 45]; vis[u][3] = lds_vis[(e + 3) / 45];
+                            any[u] = vis[u][0] | vis[u][1] | vis[u][2] | vis[u][3];
+                        }
                     }
+                    if (any[u]) {
+                        p[u] = reinterpret_cast<float4*>(A.p[2] + base)[i];
+                        m[u] = reinterpret_cast<float4*>(A.m[2] + base)[i];
+                        v[u] = reinterpret_cast<float4*>(A.v[2] + base)[i];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (!any[u]) continue;
+                    const int i = i0 + 256 * u;
+                    if (vis[u][0]) adam_scalar(p[u].x, g[u].x, m[u].x, v[u].x, A.lr[2], A.b1, A.b2, A.eps);
+                    if (vis[u][1]) adam_scalar(p[u].y, g[u].y, m[u].y, v[u].y, A.lr[2], A.b1, A.b2, A.eps);
+                    if (vis[u][2]) adam_scalar(p[u].z, g[u].z, m[u].z, v[u].z, A.lr[2], A.b1, A.b2, A.eps);
+                    if (vis[u][3]) adam_scalar(p[u].w, g[u].w, m[u].w, v[u].w, A.lr[2], A.b1, A.b2, A.eps);
+                    reinterpret_cast<float4*>(A.p[2] + base)[i] = p[u];
+                    reinterpret_cast<float4*>(A.m[2] + base)[i] = m[u];
+                    reinterpret_cast<float4*>(A.v[2] + base)[i] = v[u];
                 }
             }
         } else {
@@ -162,14 +181,26 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
     // ---- segmented sum of the per-instance partial gradients (ascending tile order) ----
     float s_mx = 0, s_my = 0, s_cx = 0, s_cy = 0, s_cw = 0, s_op = 0, s_r = 0, s_g = 0, s_b = 0;
     {
-        const uint32_t u0 = (idx == 0) ? 0u : a.offsets[idx - 1];
-        const uint32_t u1 = a.offsets[idx];
-        for (uint32_t u = u0; u < u1; u++) {
-            const float4* p = a.partials + 3 * (size_t)u;
-            const float4 p0 = p[0], p1 = p[1], p2 = p[2];
-            s_mx += p0.x; s_my += p0.y; s_cx += p0.z; s_cy += p0.w;
-            s_cw += p1.x; s_op += p1.y; s_r += p1.z; s_g += p1.w;
-            s_b += p2.x;
+        const uint32_t u0 = a.gauss_start[idx];
+        const uint32_t u1 = u0 + a.tiles_touched[idx];
+        // four records in flight per lane (clamped loads, masked adds): same summation order, a quarter of the
+        // dependent-latency round trips of the longest run in the wave
+        constexpr int UP = 4;
+        for (uint32_t u = u0; u < u1; u += UP) {
+            float4 q[UP][3];
+#pragma unroll
+            for (int j = 0; j < UP; j++) {
+                const float4* p = a.partials + 3 * (size_t)min(u + j, u1 - 1);
+                q[j][0] = p[0]; q[j][1] = p[1]; q[j][2] = p[2];
+            }
+#pragma unroll
+            for (int j = 0; j < UP; j++) {
+                if (u + j < u1) {
+                    s_mx += q[j][0].x; s_my += q[j][0].y; s_cx += q[j][0].z; s_cy += q[j][0].w;
+                    s_cw += q[j][1].x; s_op += q[j][1].y; s_r += q[j][1].z; s_g += q[j][1].w;
+                    s_b += q[j][2].x;
+                }
+            }
         }
     }
     if (a.dL_dmean2D) { a.dL_dmean2D[3 * idx] = s_mx; a.dL_dmean2D[3 * idx + 1] = s_my; a.dL_dmean2D[3 * idx + 2] = 0; }

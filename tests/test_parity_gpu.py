@@ -149,7 +149,7 @@ def test_large_scene_properties():
 
 
 def test_onesweep_sort_variant_is_bit_identical():
-    """GSLIC_SORT_ONESWEEP=1 (single pass per digit with decoupled look-back) must give exactly the default sort's lists."""
+    """GSLIC_SORT_ONESWEEP=3 (both sorts single pass per digit with decoupled look-back) must give exactly the default sort's lists."""
     import os
     import subprocess
     import sys
@@ -164,7 +164,7 @@ np.savez(sys.argv[1], keys=npy(f['dbg']['sorted_keys']), pl=npy(f['dbg']['point_
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for name, env in (("a", {}), ("b", {"GSLIC_SORT_ONESWEEP": "1"})):
+    for name, env in (("a", {}), ("b", {"GSLIC_SORT_ONESWEEP": "3"})):
         path = os.path.join(root, "gpurun_out", f"_sortcmp_{name}.npz") if os.path.isdir(os.path.join(root, "gpurun_out")) else f"/tmp/_sortcmp_{name}.npz"
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", code, path], cwd=root, env=e, capture_output=True, text=True, timeout=300)

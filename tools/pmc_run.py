@@ -20,7 +20,8 @@ W, H, P = 1920, 1080, 2_000_000
 model = trainer.GaussianModel(random_scene(P, W, H, 3, 0), dev); model.training_setup()
 cam = synthetic_camera(W, H).to_device(dev)
 gt = gt_image(H, W).to(dev); bg = torch.zeros(3, device=dev)
+fused = os.environ.get("PMC_HOST", "fused") == "fused"   # the default bench path; PMC_HOST=dropin for the per-op path
 for _ in range(4):
-    trainer.training_step(model, cam, gt, bg)
+    (trainer.training_step_fused if fused else trainer.training_step)(model, cam, gt, bg)
 torch.cuda.synchronize()
 print("pmc workload done")
