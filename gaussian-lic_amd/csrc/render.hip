@@ -141,56 +141,82 @@ __device__ __forceinline__ uint32_t shift_in_u(uint32_t inject, uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)inject, (int)v, 0x138, 0xf, 0xf, false);
 }
 
+// Drain variant: nothing is injected, lane 0 receives 0 (bound_ctrl), so source and destination may be the same register.
+__device__ __forceinline__ float shift_zero_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ uint32_t shift_zero_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define GS_PK_FMA(a, b, c) __builtin_elementwise_fma((a), (b), (c))
+#define GS_SPLAT(x) ((v2f){(x), (x)})
+
 // One pipeline step.  The evolving part of a pixel's state {T, ar[3]} and its tag (n_contrib << 8 | pixel index) move
 // lane -> lane+1 with one DPP each; the injected values enter through the DPP's `old` operand (lane 0 has no source lane).
 // The per-pixel CONSTANTS (dL/dpixel) do not travel: the wave parks every 64-pixel chunk in LDS once (coalesced
 // ds_write_b128) and a lane fetches its current pixel's record with one ds_read_b128.  VALU is the bound of this kernel
-// (profiles/r01_sq_counters_render.md), so every value taken off the conveyor is three VALU ops saved per step.
-#define GS_BWD_STEP(inj /*float4 {T, ar0..2}*/, itag)                                                                \
+// (profiles/r01_sq_counters_render.md), so every value taken off the conveyor is three VALU ops saved per step, and the
+// gradient arithmetic is written on float2 pairs: gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 at the rate of the scalar forms
+// (the fp32 peak of the part assumes them), with op_sel covering the splats and the one swizzle for free.  Each component
+// still sees exactly the scalar operation sequence, so the results do not change.
+#define GS_BWD_SHIFT(inj /*float4 {ar0, ar1, T, ar2}: ar0/ar1 land in an even-aligned register pair*/, itag)          \
     do {                                                                                                             \
-        T = shift_in_f((inj).x, T); ar0 = shift_in_f((inj).y, ar0); ar1 = shift_in_f((inj).z, ar1);                  \
+        ar01.x = shift_in_f((inj).x, ar01.x); ar01.y = shift_in_f((inj).y, ar01.y); T = shift_in_f((inj).z, T);      \
         ar2 = shift_in_f((inj).w, ar2); tag = shift_in_u(itag, tag);                                                 \
+    } while (0)
+#define GS_BWD_SHIFT_ZERO()                                                                                          \
+    do {                                                                                                             \
+        T = shift_zero_f(T); ar01.x = shift_zero_f(ar01.x); ar01.y = shift_zero_f(ar01.y); ar2 = shift_zero_f(ar2);  \
+        tag = shift_zero_u(tag);                                                                                     \
+    } while (0)
+#define GS_BWD_BODY()                                                                                                \
+    do {                                                                                                             \
         if (kcmp < tag) { /* kit < n_contrib of this pixel (backward.cu:538) */                                     \
-            const float4 gr = grec[tag & 255u];                                                                      \
-            const float dx = dx0 - (float)(tag & 15u);                                                               \
-            const float dy = dy0 - (float)((tag >> 4) & 15u);                                                        \
-            float p2 = (hA * dx) * dx;                                                                               \
-            p2 = __builtin_fmaf(hC * dy, dy, p2);                                                                    \
-            p2 = __builtin_fmaf(nB * dx, dy, p2); /* = log2(e) * power */                                            \
+            const v2f pxy = {(float)(tag & 15u), (float)((tag >> 4) & 15u)};                                         \
+            const v2f d = d0 - pxy;                                                                                  \
+            float p2 = (hA * d.x) * d.x; /* same operation order as render_fwd: identical alpha on both sides */    \
+            p2 = __builtin_fmaf(hC * d.y, d.y, p2);                                                                  \
+            p2 = __builtin_fmaf(nB * d.x, d.y, p2); /* = log2(e) * power */                                          \
             const float G = __builtin_amdgcn_exp2f(p2);                                                              \
             const float alpha = fminf(0.99f, op * G);                                                                \
             if (!(p2 > 0.0f) && !(alpha < (1.0f / 255.0f))) {                                                        \
+                const float4 gr = grec[tag & 255u];                                                                  \
+                const v2f grxy = {gr.x, gr.y};                                                                       \
                 const float om = 1.0f - alpha;                                                                       \
                 const float rinv = __builtin_amdgcn_rcpf(om);                                                        \
                 const float Ta = T * alpha;                                                                          \
-                ar0 = __builtin_fmaf(Ta, colr, ar0); ar1 = __builtin_fmaf(Ta, colg, ar1); ar2 = __builtin_fmaf(Ta, colb, ar2); \
-                acc_r = __builtin_fmaf(Ta, gr.x, acc_r); acc_g = __builtin_fmaf(Ta, gr.y, acc_g); acc_b = __builtin_fmaf(Ta, gr.z, acc_b); \
-                float dLda = __builtin_fmaf(rinv, ar0, colr * T) * gr.x;                                             \
-                dLda = __builtin_fmaf(__builtin_fmaf(rinv, ar1, colg * T), gr.y, dLda);                              \
-                dLda = __builtin_fmaf(__builtin_fmaf(rinv, ar2, colb * T), gr.z, dLda);                              \
+                ar01 = GS_PK_FMA(GS_SPLAT(Ta), col_rg, ar01); ar2 = __builtin_fmaf(Ta, colb, ar2);                   \
+                acc_rg = GS_PK_FMA(GS_SPLAT(Ta), grxy, acc_rg); acc_b = __builtin_fmaf(Ta, gr.z, acc_b);             \
+                const v2f t = GS_PK_FMA(GS_SPLAT(rinv), ar01, col_rg * GS_SPLAT(T));                                 \
+                const float tb = __builtin_fmaf(rinv, ar2, colb * T);                                                \
+                float dLda = t.x * gr.x;                                                                             \
+                dLda = __builtin_fmaf(t.y, gr.y, dLda);                                                              \
+                dLda = __builtin_fmaf(tb, gr.z, dLda);                                                               \
                 T *= om;                                                                                             \
                 const float q = op * dLda; /* dL/dG */                                                               \
-                const float gdx = G * dx, gdy = G * dy;                                                              \
-                acc_mx = __builtin_fmaf(q, __builtin_fmaf(gdx, cA, gdy * cB), acc_mx); /* sign and 0.5*W applied at the end */ \
-                acc_my = __builtin_fmaf(q, __builtin_fmaf(gdy, cC, gdx * cB), acc_my);                               \
-                acc_cx = __builtin_fmaf(gdx * dx, q, acc_cx); /* -0.5 applied at the end */                          \
-                acc_cy = __builtin_fmaf(gdx * dy, q, acc_cy);                                                        \
-                acc_cw = __builtin_fmaf(gdy * dy, q, acc_cw);                                                        \
+                const v2f gd = GS_SPLAT(G) * d;                                                                      \
+                const v2f gdyx = {gd.y, gd.x};                                                                       \
+                const v2f inner = GS_PK_FMA(gd, cAC, gdyx * GS_SPLAT(cB)); /* sign and 0.5*W applied at the end */  \
+                acc_m = GS_PK_FMA(GS_SPLAT(q), inner, acc_m);                                                        \
+                acc_cxy = GS_PK_FMA(GS_SPLAT(gd.x) * d, GS_SPLAT(q), acc_cxy); /* -0.5 applied at the end */         \
+                acc_cw = __builtin_fmaf(gd.y * d.y, q, acc_cw);                                                      \
                 acc_op = __builtin_fmaf(G, dLda, acc_op);                                                            \
             }                                                                                                        \
         }                                                                                                            \
     } while (0)
 
-__global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a)
+static constexpr int BWD_WAVES = 1;  // buckets (waves) per workgroup
+__global__ __launch_bounds__(64 * BWD_WAVES) void render_bwd_kernel(RenderBwdArgs a)
 {
     // per-wave LDS: the pixel records of the whole tile (dL/dpixel, by pixel index) and the current chunk's start states
-    __shared__ float4 s_grec[4][GS_TILE_PIX];
-    __shared__ float4 s_init[4][64];
+    __shared__ float4 s_grec[BWD_WAVES][GS_TILE_PIX];
+    __shared__ float4 s_init[BWD_WAVES][64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     float4* const grec = s_grec[wave];
     float4* const init = s_init[wave];
-    const uint32_t bucket = blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t bucket = blockIdx.x * (uint32_t)BWD_WAVES + (uint32_t)wave;
     if (bucket >= (uint32_t)a.B) return;
     const uint32_t tile = a.bucket_to_tile[bucket];
     const uint2 range = a.ranges[tile];
@@ -212,22 +238,26 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a)
     }
 
     const int tx0 = (int)(tile % (uint32_t)a.gx) * GS_TILE, ty0 = (int)(tile / (uint32_t)a.gx) * GS_TILE;
-    float dx0 = 0, dy0 = 0, cA = 0, cB = 0, cC = 0, op = 0, colr = 0, colg = 0, colb = 0;
+    float cA = 0, cB = 0, cC = 0, op = 0, colb = 0;
+    v2f d0 = {0.f, 0.f}, col_rg = {0.f, 0.f};
     if (valid) {
         const uint32_t g = a.point_list[range.x + kit];
         const float4* rp = a.rec + 3 * (size_t)g;
         const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-        dx0 = r0.x - (float)tx0; dy0 = r0.y - (float)ty0;
-        cA = r0.z; cB = r0.w; cC = r1.x; op = r1.y; colr = r1.z; colg = r1.w; colb = r2.x;
+        d0.x = r0.x - (float)tx0; d0.y = r0.y - (float)ty0;
+        cA = r0.z; cB = r0.w; cC = r1.x; op = r1.y; col_rg.x = r1.z; col_rg.y = r1.w; colb = r2.x;
     }
     const float LOG2E = 1.4426950408889634f;
     const float hA = -0.5f * LOG2E * cA, hC = -0.5f * LOG2E * cC, nB = -LOG2E * cB;
+    const v2f cAC = {cA, cC};
     const uint32_t kcmp = (kit << 8) | 0xffu;  // kcmp < (n_contrib << 8 | idx)  <=>  kit < n_contrib
-    float acc_mx = 0, acc_my = 0, acc_cx = 0, acc_cy = 0, acc_cw = 0, acc_op = 0, acc_r = 0, acc_g = 0, acc_b = 0;
+    v2f acc_m = {0.f, 0.f}, acc_cxy = {0.f, 0.f}, acc_rg = {0.f, 0.f};
+    float acc_cw = 0, acc_op = 0, acc_b = 0;
     const size_t plane = (size_t)a.H * a.W;
 
     // evolving pixel state travelling through the lanes
-    float T = 0, ar0 = 0, ar1 = 0, ar2 = 0;
+    float T = 0, ar2 = 0;
+    v2f ar01 = {0.f, 0.f};
     uint32_t tag = 0;
 
     // 64-pixel feed chunk (register double buffer: chunk c+1 is in flight while chunk c streams through)
@@ -253,31 +283,47 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a)
         const uint32_t ncp = inside ? __float_as_uint(pf.w) : 0u;
         const uint32_t ftag = (ncp << 8) | (uint32_t)(c * 64 + lane);
         grec[c * 64 + lane] = make_float4(fg0, fg1, fg2, 0.f);
-        init[lane] = make_float4(ck.x, ck.y - pf.x, ck.z - pf.y, ck.w - pf.z);  // T, ar = checkpoint colour - final colour
+        init[lane] = make_float4(ck.y - pf.x, ck.z - pf.y, ck.x, ck.w - pf.z);  // ar0, ar1, T, ar2 (ar = checkpoint colour - final colour)
         uint64_t active = __ballot(ncp > bstart);  // pixels that reach this bucket; the others contribute nothing here
         if (c < 3) load_chunk(c + 1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // two steps per trip: a DPP's destination is the register that held the injected value, so the state ping-pongs
+        // between two register sets; a single-step loop pays five v_mov per step to bring it back
         while (active) {
-            const int sl = __builtin_ctzll(active);
-            active &= active - 1;
-            const float4 inj = init[sl];  // wave-uniform address: LDS broadcast
-            const uint32_t itag = readlane_u(ftag, sl);
-            GS_BWD_STEP(inj, itag);
+            {
+                const int sl = __builtin_ctzll(active);
+                active &= active - 1;
+                const float4 inj = init[sl];  // wave-uniform address: LDS broadcast
+                const uint32_t itag = readlane_u(ftag, sl);
+                GS_BWD_SHIFT(inj, itag);
+                GS_BWD_BODY();
+            }
+            if (!active) break;
+            {
+                const int sl = __builtin_ctzll(active);
+                active &= active - 1;
+                const float4 inj = init[sl];
+                const uint32_t itag = readlane_u(ftag, sl);
+                GS_BWD_SHIFT(inj, itag);
+                GS_BWD_BODY();
+            }
         }
         __builtin_amdgcn_wave_barrier();  // init[] is rewritten by the next chunk only after its last read above
     }
     // drain: the last injected pixel still has to pass the bucket's remaining (valid) lanes
     const int nvalid = (n - bstart) < (uint32_t)GS_BUCKET ? (int)(n - bstart) : GS_BUCKET;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
-    for (int d = 1; d < nvalid; d++) GS_BWD_STEP(zero4, 0u);
+    for (int dr = 1; dr < nvalid; dr++) {
+        GS_BWD_SHIFT_ZERO();
+        GS_BWD_BODY();
+    }
 
     if (valid) {
         const float sx = -0.5f * (float)a.W, sy = -0.5f * (float)a.H;  // -(...) * ddelx_dx, ddelx_dx = 0.5 W (backward.cu:464-465)
         float4* o = a.partials + 3 * (size_t)slot;
-        o[0] = make_float4(acc_mx * sx, acc_my * sy, -0.5f * acc_cx, -0.5f * acc_cy);
-        o[1] = make_float4(-0.5f * acc_cw, acc_op, acc_r, acc_g);
+        o[0] = make_float4(acc_m.x * sx, acc_m.y * sy, -0.5f * acc_cxy.x, -0.5f * acc_cxy.y);
+        o[1] = make_float4(-0.5f * acc_cw, acc_op, acc_rg.x, acc_rg.y);
         o[2] = make_float4(acc_b, 0.f, 0.f, 0.f);
     }
 }
@@ -290,7 +336,7 @@ int launch_render_fwd(const RenderFwdArgs& a, hipStream_t s)
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s)
 {
     if (a.B <= 0) return GSLIC_OK;
-    GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel, dim3((a.B + 3) / 4), dim3(256), 0, s, a);
+    GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel, dim3((a.B + BWD_WAVES - 1) / BWD_WAVES), dim3(64 * BWD_WAVES), 0, s, a);
     return GSLIC_OK;
 }
 
