@@ -46,29 +46,86 @@ struct ShOut {  // what phase B needs to write a Gaussian's dL_dsh row
 };
 
 template <bool LDS_SH>
-__device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so);
+__device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so, float* lds_g, int bs);
+
+// Cooperative Adam on the 14 small scalars per Gaussian of one block (see lds_g in the kernel).  Group g of width w: the
+// block's region is rows * w floats starting at param[g] + row0 * w, 16-byte aligned because BS is a multiple of 4.
+template <int BS>
+__device__ __forceinline__ void small_groups_adam(const AdamFusedArgs& A, const float* lds_g, const uint8_t* lds_vis, int row0, int rows)
+{
+    constexpr int NG = 5;
+    constexpr int gid[NG] = {0, 1, 3, 4, 5};   // xyz, features_dc, opacity, scaling, rotation
+    constexpr int wid[NG] = {3, 3, 1, 3, 4};
+    constexpr int off[NG] = {0, 3 * BS, 6 * BS, 7 * BS, 10 * BS};
+    const int t = threadIdx.x;
+    if (rows == BS) {
+        float4 g[NG], p[NG], m[NG], v[NG];
+        bool on[NG], vis[NG][4];
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            on[k] = false;
+            if (t < BS * wid[k] / 4) {
+                const int e = 4 * t;
+#pragma unroll
+                for (int c = 0; c < 4; c++) vis[k][c] = lds_vis[(e + c) / wid[k]];
+                on[k] = vis[k][0] | vis[k][1] | vis[k][2] | vis[k][3];
+            }
+            if (on[k]) {
+                const size_t base = (size_t)row0 * wid[k];
+                g[k] = reinterpret_cast<const float4*>(lds_g + off[k])[t];
+                p[k] = reinterpret_cast<const float4*>(A.p[gid[k]] + base)[t];
+                m[k] = reinterpret_cast<const float4*>(A.m[gid[k]] + base)[t];
+                v[k] = reinterpret_cast<const float4*>(A.v[gid[k]] + base)[t];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            if (!on[k]) continue;
+            const float lr = A.lr[gid[k]];
+            if (vis[k][0]) adam_scalar(p[k].x, g[k].x, m[k].x, v[k].x, lr, A.b1, A.b2, A.eps);
+            if (vis[k][1]) adam_scalar(p[k].y, g[k].y, m[k].y, v[k].y, lr, A.b1, A.b2, A.eps);
+            if (vis[k][2]) adam_scalar(p[k].z, g[k].z, m[k].z, v[k].z, lr, A.b1, A.b2, A.eps);
+            if (vis[k][3]) adam_scalar(p[k].w, g[k].w, m[k].w, v[k].w, lr, A.b1, A.b2, A.eps);
+            const size_t base = (size_t)row0 * wid[k];
+            reinterpret_cast<float4*>(A.p[gid[k]] + base)[t] = p[k];
+            reinterpret_cast<float4*>(A.m[gid[k]] + base)[t] = m[k];
+            reinterpret_cast<float4*>(A.v[gid[k]] + base)[t] = v[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            const size_t base = (size_t)row0 * wid[k];
+            for (int i = t; i < rows * wid[k]; i += BS)
+                if (lds_vis[i / wid[k]])
+                    adam_scalar(A.p[gid[k]][base + i], lds_g[off[k] + i], A.m[gid[k]][base + i], A.v[gid[k]][base + i], A.lr[gid[k]], A.b1, A.b2, A.eps);
+        }
+    }
+}
 
 // LDS_SH (M == 15): the block's 256 x 45 SH floats (contiguous in memory) are staged through LDS with coalesced float4
 // accesses and read row-wise by the owning thread (row stride 45 floats: odd, bank-conflict free); the block's dL_dsh rows go
 // back the same way — instead of 45 strided 4-byte accesses per thread in each direction (measured 2.6x write amplification).
-template <bool LDS_SH>
-__global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreprocessBwdArgs a)
+template <bool LDS_SH, int BS>
+__global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
 {
-    __shared__ float lds_sh[LDS_SH ? 256 * 45 : 4];
-    __shared__ uint8_t lds_vis[256];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float lds_sh[LDS_SH ? BS * 45 : 4];
+    __shared__ uint8_t lds_vis[BS];
+    // the 14 small-group gradients of every Gaussian of the block, group-major (xyz | dc | opacity | scale | rotation), for the
+    // cooperative float4 Adam below: per-thread 4-byte accesses at stride 12 / 16 B cost this kernel 0.29 ms of 0.86
+    __shared__ float lds_g[LDS_SH ? 14 * BS : 4];
+    const int idx = blockIdx.x * BS + threadIdx.x;
     const int M = a.M;
     lds_vis[threadIdx.x] = (idx < a.P && a.radii[idx] > 0) ? 1 : 0;
-    const int row0 = blockIdx.x * 256;
-    const int rows = (a.P - row0) < 256 ? (a.P - row0) : 256;
+    const int row0 = blockIdx.x * BS;
+    const int rows = (a.P - row0) < BS ? (a.P - row0) : BS;
     if constexpr (LDS_SH) {
         const float* src = a.shs + (size_t)row0 * 45;
-        if (rows == 256) {
+        if (rows == BS) {
             const float4* s4 = reinterpret_cast<const float4*>(src);
             float4* d4 = reinterpret_cast<float4*>(lds_sh);
-            for (int i = threadIdx.x; i < 256 * 45 / 4; i += 256) d4[i] = s4[i];
+            for (int i = threadIdx.x; i < BS * 45 / 4; i += BS) d4[i] = s4[i];
         } else {
-            for (int i = threadIdx.x; i < rows * 45; i += 256) lds_sh[i] = src[i];
+            for (int i = threadIdx.x; i < rows * 45; i += BS) lds_sh[i] = src[i];
         }
         __syncthreads();
     }
@@ -76,9 +133,14 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreprocessBwdArgs a
     so.x = so.y = so.z = so.dR = so.dG = so.dB = 0.f;
     so.on = false;
     const float* sh_row = LDS_SH ? (lds_sh + threadIdx.x * 45) : (a.shs ? a.shs + (size_t)3 * M * idx : nullptr);
-    if (idx < a.P) bwd_phase_a<LDS_SH>(a, idx, M, sh_row, so);
+    if (idx < a.P) bwd_phase_a<LDS_SH>(a, idx, M, sh_row, so, (LDS_SH && a.adam.on) ? lds_g : nullptr, BS);
     if constexpr (LDS_SH) __syncthreads();  // every SH row has been consumed: the buffer now takes the dL_dsh rows
 
+    // ---- small groups: the block's rows of xyz / dc / opacity / scale / rotation are contiguous in memory, so the Adam update runs
+    // on float4 columns of those five regions (at most one float4 per thread and group, all fifteen loads issued before the math)
+    if constexpr (LDS_SH) {
+        if (a.adam.on) small_groups_adam<BS>(a.adam, lds_g, lds_vis, row0, rows);
+    }
     // ---- phase B: this Gaussian's dL_dsh row (zeros when invisible, when shs == NULL, and above the active degree)
     if constexpr (LDS_SH) {
         if (idx < a.P) {
@@ -95,17 +157,17 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreprocessBwdArgs a
         // ---- phase C: the block's 256 x 45 gradient rows leave LDS coalesced: to dL_dsh and / or straight into Adam
         const size_t base = (size_t)row0 * 45;
         const AdamFusedArgs& A = a.adam;
-        if (rows == 256) {
+        if (rows == BS) {
             const float4* s4 = reinterpret_cast<const float4*>(lds_sh);
-            constexpr int NV = 256 * 45 / 4, U = 4;
+            constexpr int NV = BS * 45 / 4, U = 4;
             // U independent float4 triples (param, exp_avg, exp_avg_sq) in flight per thread: the kernel runs at 3 waves/SIMD
             // (LDS-limited), so memory-level parallelism has to come from inside the wave
-            for (int i0 = threadIdx.x; i0 < NV; i0 += 256 * U) {
+            for (int i0 = threadIdx.x; i0 < NV; i0 += BS * U) {
                 float4 g[U], p[U], m[U], v[U];
                 bool vis[U][4], any[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    const int i = i0 + 256 * u;
+                    const int i = i0 + BS * u;
                     any[u] = false;
                     if (i < NV) {
                         g[u] = s4[i];
@@ -126,7 +188,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreprocessBwdArgs a
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     if (!any[u]) continue;
-                    const int i = i0 + 256 * u;
+                    const int i = i0 + BS * u;
                     if (vis[u][0]) adam_scalar(p[u].x, g[u].x, m[u].x, v[u].x, A.lr[2], A.b1, A.b2, A.eps);
                     if (vis[u][1]) adam_scalar(p[u].y, g[u].y, m[u].y, v[u].y, A.lr[2], A.b1, A.b2, A.eps);
                     if (vis[u][2]) adam_scalar(p[u].z, g[u].z, m[u].z, v[u].z, A.lr[2], A.b1, A.b2, A.eps);
@@ -137,7 +199,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreprocessBwdArgs a
                 }
             }
         } else {
-            for (int i = threadIdx.x; i < rows * 45; i += 256) {
+            for (int i = threadIdx.x; i < rows * 45; i += BS) {
                 const float g = lds_sh[i];
                 if (a.dL_dsh) a.dL_dsh[base + i] = g;
                 if (A.on && lds_vis[i / 45]) adam_scalar(A.p[2][base + i], g, A.m[2][base + i], A.v[2][base + i], A.lr[2], A.b1, A.b2, A.eps);
@@ -160,7 +222,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreprocessBwdArgs a
 }
 
 template <bool LDS_SH>
-__device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so)
+__device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so, float* lds_g, int bs)
 {
     const bool visible = a.radii[idx] > 0;
 
@@ -421,7 +483,19 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
     if (a.dL_ddc) { a.dL_ddc[3 * idx] = ddc[0]; a.dL_ddc[3 * idx + 1] = ddc[1]; a.dL_ddc[3 * idx + 2] = ddc[2]; }
     if (a.dL_dscale) { a.dL_dscale[3 * idx] = dscale[0]; a.dL_dscale[3 * idx + 1] = dscale[1]; a.dL_dscale[3 * idx + 2] = dscale[2]; }
     if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = dq;
-    if (a.adam.on) {
+    if (a.adam.on && lds_g) {
+        const int t = threadIdx.x;
+        float* g = lds_g;
+        g[3 * t] = dmean[0]; g[3 * t + 1] = dmean[1]; g[3 * t + 2] = dmean[2];
+        g += 3 * bs;
+        g[3 * t] = ddc[0]; g[3 * t + 1] = ddc[1]; g[3 * t + 2] = ddc[2];
+        g += 3 * bs;
+        g[t] = g_op;
+        g += bs;
+        g[3 * t] = dscale[0]; g[3 * t + 1] = dscale[1]; g[3 * t + 2] = dscale[2];
+        g += 3 * bs;
+        reinterpret_cast<float4*>(g)[t] = dq;
+    } else if (a.adam.on) {
         const AdamFusedArgs& A = a.adam;
         const float dqv[4] = {dq.x, dq.y, dq.z, dq.w};
 #pragma unroll
@@ -440,9 +514,11 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
 int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
 {
     if (a.M == 15 && a.shs && (a.dL_dsh || a.adam.on)) {
-        GS_LAUNCH(K_PREPROCESS_BWD, preprocess_bwd_kernel<true>, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+        // one wave per workgroup: 64 Gaussians' SH rows (11.25 KiB) + small-group gradients in LDS, the phase barriers are wave-level,
+        // and ten workgroups per CU sit in different phases (measured 0.72 ms against 0.75 at 128 and 0.88 at 256 threads)
+        GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64>), dim3(div_up(a.P, 64)), dim3(64), 0, s, a);
     } else {
-        GS_LAUNCH(K_PREPROCESS_BWD, preprocess_bwd_kernel<false>, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+        GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<false, 256>), dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
     }
     return GSLIC_OK;
 }

@@ -20,6 +20,34 @@
 
 namespace gslic {
 
+// Upper bound of p2(x, y) = hA dx^2 + hC dy^2 + nB dx dy (dx = gx - x, dy = gy - y; a negative-definite form scaled by log2 e)
+// over the pixel rectangle [x0, x1] x [y0, y1], plus a rounding margin: the maximum of a concave quadratic over a rectangle that
+// does not contain its centre lies on an edge facing the centre, where it is a 1-D parabola.  Used to skip whole 16x4 pixel
+// strips that an entry cannot reach (alpha < 1/255 everywhere): conservative, so the image is unchanged bit for bit.
+__device__ __forceinline__ float strip_max_p2(float hA, float hC, float nB, float gx, float gy, float x0, float x1, float y0, float y1)
+{
+    const bool in_x = gx >= x0 && gx <= x1, in_y = gy >= y0 && gy <= y1;
+    if (in_x && in_y) return 0.0f;
+    float best = -3.0e38f;
+    if (!in_y) {  // horizontal edge y = ye facing the centre: maximise over x in [x0, x1]
+        const float ye = gy < y0 ? y0 : y1;
+        const float dy = gy - ye;
+        float dx = -(nB * dy) / (2.0f * hA);            // stationary point of hA dx^2 + nB dy dx
+        dx = fminf(fmaxf(dx, gx - x1), gx - x0);         // dx = gx - x with x in [x0, x1]
+        best = fmaxf(best, (hA * dx) * dx + (hC * dy) * dy + (nB * dx) * dy);
+    }
+    if (!in_x) {  // vertical edge x = xe
+        const float xe = gx < x0 ? x0 : x1;
+        const float dx = gx - xe;
+        float dy = -(nB * dx) / (2.0f * hC);
+        dy = fminf(fmaxf(dy, gy - y1), gy - y0);
+        best = fmaxf(best, (hA * dx) * dx + (hC * dy) * dy + (nB * dx) * dy);
+    }
+    // rounding margin: a few ulp of the largest term anywhere in the rectangle
+    const float DX = fmaxf(fabsf(gx - x0), fabsf(gx - x1)), DY = fmaxf(fabsf(gy - y0), fabsf(gy - y1));
+    return best + 1.0e-5f * (fabsf(hA) * DX * DX + fabsf(hC) * DY * DY + fabsf(nB) * DX * DY) + 1.0e-6f;
+}
+
 __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
 {
     const int tile = blockIdx.x;
@@ -62,6 +90,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
         const int m = (n - base) < GS_BUCKET ? (n - base) : GS_BUCKET;
         // each lane fetches one record and pre-scales its conic: exponent in base 2, relative to this lane-independent tile origin
         float fdx = 0, fdy = 0, fhA = 0, fhC = 0, fnB = 0, fop = 0, fr = 0, fg = 0, fb = 0;
+        uint32_t fmask = 0;
         if (lane < m) {
             const uint32_t g = a.point_list[range.x + (uint32_t)(base + lane)];
             const float4* rp = a.rec + 3 * (size_t)g;
@@ -69,9 +98,17 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
             fdx = r0.x - (float)tx0; fdy = r0.y - (float)ty0;
             fhA = -0.5f * LOG2E * r0.z; fnB = -LOG2E * r0.w; fhC = -0.5f * LOG2E * r1.x;
             fop = r1.y; fr = r1.z; fg = r1.w; fb = r2.x;
+            // which of the tile's four 16x4 strips (= the four pixels of every lane) can this entry reach at all
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float pm = strip_max_p2(fhA, fhC, fnB, fdx, fdy, 0.0f, 15.0f, (float)(4 * q), (float)(4 * q + 3));
+                if (!(fop * __builtin_amdgcn_exp2f(pm) < 0.999f * (1.0f / 255.0f))) fmask |= 1u << q;
+            }
         }
         const float lx = (float)(lane & 15), ly = (float)(lane >> 4);
         for (int j = 0; j < m; j++) {
+            const uint32_t smask = readlane_u(fmask, j);
+            if (smask == 0u) continue;
             const float gdx = readlane_f(fdx, j), gdy = readlane_f(fdy, j);
             const float hA = readlane_f(fhA, j), nB = readlane_f(fnB, j), hC = readlane_f(fhC, j);
             const float op = readlane_f(fop, j);
@@ -83,6 +120,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
             const float dy0 = gdy - ly;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
+                if (!(smask & (1u << q))) continue;  // wave-uniform
                 const float dy = dy0 - (float)(4 * q);
                 const float p2 = __builtin_fmaf(pB, dy, __builtin_fmaf(hC * dy, dy, pA));  // log2(e) * power
                 const float alpha = fminf(0.99f, op * __builtin_amdgcn_exp2f(p2));
