@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--host", default="fused", choices=["fused", "dropin"],
                     help="fused = the framework's own step on the fused entry points (activations + loss inside the kernels, no autograd "
                          "graph); dropin = the reference's operator API + LibTorch autograd, i.e. what an unmodified reference host runs")
+    ap.add_argument("--split-adam", action="store_true", help="fused host path with Adam as its own launch (the N > 1 compute path: gradients to the slab, then Adam), on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every kernel inside the timed region (adds overhead)")
     args = ap.parse_args()
@@ -136,7 +137,7 @@ def main():
                 slam["ms"] += e0.elapsed_time(e1); slam["calls"] += 1
         if args.mode in ("train", "slam"):
             if host["mode"] == "fused":
-                return trainer.training_step_fused(model, cam, gt, bg)[1]
+                return trainer.training_step_fused(model, cam, gt, bg, adam_in_backward=not args.split_adam)[1]
             return trainer.training_step(model, cam, gt, bg)[1]
         return trainer.render_fwd_bwd(model, cam, dL, bg)
 

@@ -31,23 +31,33 @@ __device__ __forceinline__ float fmax_c(float a, float b) { return (b > a) ? b :
 // LDS_SH (M == 15, colour mode): the block's 256 x 45 SH floats are contiguous in memory; they are staged through LDS with
 // coalesced float4 loads issued first (their latency hides under the projection / tile counting) and read row-wise by the
 // owning thread (row stride 45 floats: odd, bank-conflict free) instead of 45 strided 4-byte loads per visible Gaussian.
-template <bool LDS_SH>
-__global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a)
+template <bool LDS_SH, int BS>
+__global__ __launch_bounds__(BS) void preprocess_kernel(PreprocessArgs a)
 {
-    __shared__ float lds_sh[LDS_SH ? 256 * 45 : 4];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float lds_sh[LDS_SH ? BS * 45 : 4];
+    const int idx = blockIdx.x * BS + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    for (int t = idx; t < a.gx * a.gy; t += gridDim.x * 256) a.ranges[t] = make_uint2(0u, 0u);
+    for (int t = idx; t < a.gx * a.gy; t += gridDim.x * BS) a.ranges[t] = make_uint2(0u, 0u);
+    constexpr int SH_REGS = LDS_SH ? (BS * 45 / 4 + BS - 1) / BS : 1;  // float4 per thread of the block's SH region
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f sh_pre[SH_REGS];
+#pragma unroll
+    for (int k = 0; k < SH_REGS; k++) sh_pre[k] = (v4f){0.f, 0.f, 0.f, 0.f};
     if constexpr (LDS_SH) {
-        const int row0 = blockIdx.x * 256;
-        const int rows = (a.P - row0) < 256 ? (a.P - row0) : 256;
+        const int row0 = blockIdx.x * BS;
+        const int rows = (a.P - row0) < BS ? (a.P - row0) : BS;
         const float* src = a.shs + (size_t)row0 * 45;
-        if (rows == 256) {
-            const float4* s4 = reinterpret_cast<const float4*>(src);
-            float4* d4 = reinterpret_cast<float4*>(lds_sh);
-            for (int i = threadIdx.x; i < 256 * 45 / 4; i += 256) d4[i] = s4[i];
+        if (rows == BS) {
+            // the loads are issued here and parked in registers; they land in LDS only after the geometry below, which
+            // therefore runs under their latency (the kernel is latency-bound: 3 waves per SIMD, one dependent chain each)
+            const v4f* s4 = reinterpret_cast<const v4f*>(src);
+#pragma unroll
+            for (int k = 0; k < SH_REGS; k++) {
+                const int i = threadIdx.x + k * BS;
+                if (i < BS * 45 / 4) sh_pre[k] = s4[i];
+            }
         } else {
-            for (int i = threadIdx.x; i < rows * 45; i += 256) lds_sh[i] = src[i];
+            for (int i = threadIdx.x; i < rows * 45; i += BS) lds_sh[i] = src[i];
         }
     }
     bool active = idx < a.P;
@@ -181,7 +191,17 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a)
         a.tiles_touched[idx] = visible ? cnt : 0u;
         a.depth_keys[idx] = visible ? __float_as_uint(depth) : 0xffffffffu;  // low half of the reference's sort key (forward.cu:254)
     }
-    if constexpr (LDS_SH) __syncthreads();  // SH rows have landed in LDS (block-uniform: no thread has returned yet)
+    if constexpr (LDS_SH) {
+        if ((a.P - (int)(blockIdx.x * BS)) >= BS) {
+            v4f* d4 = reinterpret_cast<v4f*>(lds_sh);
+#pragma unroll
+            for (int k = 0; k < SH_REGS; k++) {
+                const int i = threadIdx.x + k * BS;
+                if (i < BS * 45 / 4) d4[i] = sh_pre[k];
+            }
+        }
+        __syncthreads();  // SH rows have landed in LDS (block-uniform: no thread has returned yet)
+    }
     if (!visible) return;
 
     // ---- SH -> RGB (forward.cu:29-77) ----
@@ -308,9 +328,12 @@ __global__ __launch_bounds__(256) void finalize_ranges_kernel(uint32_t R, const 
 int launch_preprocess(const PreprocessArgs& a, hipStream_t s)
 {
     if (a.M == 15 && a.D > 0 && a.shs && !a.no_color) {
-        GS_LAUNCH(K_PREPROCESS, preprocess_kernel<true>, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+        // one wave per workgroup (as preprocess_bwd): the SH staging barrier is wave-level; 0.197 ms against 0.216 at 256 threads.
+        // Staging the small inputs / the record through LDS as well was measured and is SLOWER here (0.30 ms): the kernel is
+        // latency-bound and the extra barrier ahead of the geometry serialises load -> compute -> store inside the wave.
+        GS_LAUNCH(K_PREPROCESS, (preprocess_kernel<true, 64>), dim3(div_up(a.P, 64)), dim3(64), 0, s, a);
     } else {
-        GS_LAUNCH(K_PREPROCESS, preprocess_kernel<false>, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+        GS_LAUNCH(K_PREPROCESS, (preprocess_kernel<false, 256>), dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
     }
     return GSLIC_OK;
 }

@@ -48,10 +48,12 @@ struct ShOut {  // what phase B needs to write a Gaussian's dL_dsh row
 template <bool LDS_SH>
 __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so, float* lds_g, int bs);
 
-// Cooperative Adam on the 14 small scalars per Gaussian of one block (see lds_g in the kernel).  Group g of width w: the
+// Cooperative sink of the 14 small gradients per Gaussian of one block (see lds_g in the kernel): coalesced float4 stores into the
+// gradient tensors that were asked for (gout, group order of lds_g) and / or the in-place Adam update.  Group g of width w: the
 // block's region is rows * w floats starting at param[g] + row0 * w, 16-byte aligned because BS is a multiple of 4.
 template <int BS>
-__device__ __forceinline__ void small_groups_adam(const AdamFusedArgs& A, const float* lds_g, const uint8_t* lds_vis, int row0, int rows)
+__device__ __forceinline__ void small_groups_sink(const AdamFusedArgs& A, float* const (&gout)[5], const float* lds_g, const uint8_t* lds_vis, int row0,
+                                                  int rows)
 {
     constexpr int NG = 5;
     constexpr int gid[NG] = {0, 1, 3, 4, 5};   // xyz, features_dc, opacity, scaling, rotation
@@ -65,14 +67,17 @@ __device__ __forceinline__ void small_groups_adam(const AdamFusedArgs& A, const 
         for (int k = 0; k < NG; k++) {
             on[k] = false;
             if (t < BS * wid[k] / 4) {
-                const int e = 4 * t;
+                g[k] = reinterpret_cast<const float4*>(lds_g + off[k])[t];
+                if (gout[k]) reinterpret_cast<float4*>(gout[k] + (size_t)row0 * wid[k])[t] = g[k];
+                if (A.on) {
+                    const int e = 4 * t;
 #pragma unroll
-                for (int c = 0; c < 4; c++) vis[k][c] = lds_vis[(e + c) / wid[k]];
-                on[k] = vis[k][0] | vis[k][1] | vis[k][2] | vis[k][3];
+                    for (int c = 0; c < 4; c++) vis[k][c] = lds_vis[(e + c) / wid[k]];
+                    on[k] = vis[k][0] | vis[k][1] | vis[k][2] | vis[k][3];
+                }
             }
             if (on[k]) {
                 const size_t base = (size_t)row0 * wid[k];
-                g[k] = reinterpret_cast<const float4*>(lds_g + off[k])[t];
                 p[k] = reinterpret_cast<const float4*>(A.p[gid[k]] + base)[t];
                 m[k] = reinterpret_cast<const float4*>(A.m[gid[k]] + base)[t];
                 v[k] = reinterpret_cast<const float4*>(A.v[gid[k]] + base)[t];
@@ -95,9 +100,11 @@ __device__ __forceinline__ void small_groups_adam(const AdamFusedArgs& A, const 
 #pragma unroll
         for (int k = 0; k < NG; k++) {
             const size_t base = (size_t)row0 * wid[k];
-            for (int i = t; i < rows * wid[k]; i += BS)
-                if (lds_vis[i / wid[k]])
+            for (int i = t; i < rows * wid[k]; i += BS) {
+                if (gout[k]) gout[k][base + i] = lds_g[off[k] + i];
+                if (A.on && lds_vis[i / wid[k]])
                     adam_scalar(A.p[gid[k]][base + i], lds_g[off[k] + i], A.m[gid[k]][base + i], A.v[gid[k]][base + i], A.lr[gid[k]], A.b1, A.b2, A.eps);
+            }
         }
     }
 }
@@ -108,11 +115,11 @@ __device__ __forceinline__ void small_groups_adam(const AdamFusedArgs& A, const 
 template <bool LDS_SH, int BS>
 __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
 {
-    __shared__ float lds_sh[LDS_SH ? BS * 45 : 4];
+    __shared__ __attribute__((aligned(16))) float lds_sh[LDS_SH ? BS * 45 : 4];
     __shared__ uint8_t lds_vis[BS];
     // the 14 small-group gradients of every Gaussian of the block, group-major (xyz | dc | opacity | scale | rotation), for the
     // cooperative float4 Adam below: per-thread 4-byte accesses at stride 12 / 16 B cost this kernel 0.29 ms of 0.86
-    __shared__ float lds_g[LDS_SH ? 14 * BS : 4];
+    __shared__ __attribute__((aligned(16))) float lds_g[LDS_SH ? 14 * BS : 4];
     const int idx = blockIdx.x * BS + threadIdx.x;
     const int M = a.M;
     lds_vis[threadIdx.x] = (idx < a.P && a.radii[idx] > 0) ? 1 : 0;
@@ -133,13 +140,14 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
     so.x = so.y = so.z = so.dR = so.dG = so.dB = 0.f;
     so.on = false;
     const float* sh_row = LDS_SH ? (lds_sh + threadIdx.x * 45) : (a.shs ? a.shs + (size_t)3 * M * idx : nullptr);
-    if (idx < a.P) bwd_phase_a<LDS_SH>(a, idx, M, sh_row, so, (LDS_SH && a.adam.on) ? lds_g : nullptr, BS);
+    if (idx < a.P) bwd_phase_a<LDS_SH>(a, idx, M, sh_row, so, LDS_SH ? lds_g : nullptr, BS);
     if constexpr (LDS_SH) __syncthreads();  // every SH row has been consumed: the buffer now takes the dL_dsh rows
 
     // ---- small groups: the block's rows of xyz / dc / opacity / scale / rotation are contiguous in memory, so the Adam update runs
     // on float4 columns of those five regions (at most one float4 per thread and group, all fifteen loads issued before the math)
     if constexpr (LDS_SH) {
-        if (a.adam.on) small_groups_adam<BS>(a.adam, lds_g, lds_vis, row0, rows);
+        float* const gout[5] = {a.dL_dmean3D, a.dL_ddc, a.dL_dopacity, a.dL_dscale, a.dL_drot};
+        small_groups_sink<BS>(a.adam, gout, lds_g, lds_vis, row0, rows);
     }
     // ---- phase B: this Gaussian's dL_dsh row (zeros when invisible, when shs == NULL, and above the active degree)
     if constexpr (LDS_SH) {
@@ -229,11 +237,18 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
     if (!visible) {
         if (a.dL_dmean2D) { a.dL_dmean2D[3 * idx] = 0; a.dL_dmean2D[3 * idx + 1] = 0; a.dL_dmean2D[3 * idx + 2] = 0; }
         if (a.dL_dconic) reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(0, 0, 0, 0);
-        if (a.dL_dopacity) a.dL_dopacity[idx] = 0;
         if (a.dL_dcolor) { a.dL_dcolor[3 * idx] = 0; a.dL_dcolor[3 * idx + 1] = 0; a.dL_dcolor[3 * idx + 2] = 0; }
-        if (a.dL_dmean3D) { a.dL_dmean3D[3 * idx] = 0; a.dL_dmean3D[3 * idx + 1] = 0; a.dL_dmean3D[3 * idx + 2] = 0; }
         if (a.dL_dcov3D)
             for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * idx + k] = 0;
+        if (lds_g) {  // the five parameter-gradient rows leave through the block's staged float4 stores
+            const int t = threadIdx.x;
+            for (int k = 0; k < 3; k++) { lds_g[3 * t + k] = 0.f; lds_g[3 * bs + 3 * t + k] = 0.f; lds_g[7 * bs + 3 * t + k] = 0.f; }
+            lds_g[6 * bs + t] = 0.f;
+            reinterpret_cast<float4*>(lds_g + 10 * bs)[t] = make_float4(0, 0, 0, 0);
+            return;
+        }
+        if (a.dL_dopacity) a.dL_dopacity[idx] = 0;
+        if (a.dL_dmean3D) { a.dL_dmean3D[3 * idx] = 0; a.dL_dmean3D[3 * idx + 1] = 0; a.dL_dmean3D[3 * idx + 2] = 0; }
         if (a.dL_ddc) { a.dL_ddc[3 * idx] = 0; a.dL_ddc[3 * idx + 1] = 0; a.dL_ddc[3 * idx + 2] = 0; }
         if (a.dL_dscale) { a.dL_dscale[3 * idx] = 0; a.dL_dscale[3 * idx + 1] = 0; a.dL_dscale[3 * idx + 2] = 0; }
         if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0, 0, 0, 0);
@@ -478,12 +493,7 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
         dq = dr;
     }
     // ---- sinks: gradient tensors (each optional) and / or the in-place Adam update of this Gaussian's 14 small scalars
-    if (a.dL_dopacity) a.dL_dopacity[idx] = g_op;
-    if (a.dL_dmean3D) { a.dL_dmean3D[3 * idx] = dmean[0]; a.dL_dmean3D[3 * idx + 1] = dmean[1]; a.dL_dmean3D[3 * idx + 2] = dmean[2]; }
-    if (a.dL_ddc) { a.dL_ddc[3 * idx] = ddc[0]; a.dL_ddc[3 * idx + 1] = ddc[1]; a.dL_ddc[3 * idx + 2] = ddc[2]; }
-    if (a.dL_dscale) { a.dL_dscale[3 * idx] = dscale[0]; a.dL_dscale[3 * idx + 1] = dscale[1]; a.dL_dscale[3 * idx + 2] = dscale[2]; }
-    if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = dq;
-    if (a.adam.on && lds_g) {
+    if (lds_g) {  // staged: the block stores / updates these rows with float4 columns (small_groups_sink)
         const int t = threadIdx.x;
         float* g = lds_g;
         g[3 * t] = dmean[0]; g[3 * t + 1] = dmean[1]; g[3 * t + 2] = dmean[2];
@@ -495,7 +505,14 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
         g[3 * t] = dscale[0]; g[3 * t + 1] = dscale[1]; g[3 * t + 2] = dscale[2];
         g += 3 * bs;
         reinterpret_cast<float4*>(g)[t] = dq;
-    } else if (a.adam.on) {
+        return;
+    }
+    if (a.dL_dopacity) a.dL_dopacity[idx] = g_op;
+    if (a.dL_dmean3D) { a.dL_dmean3D[3 * idx] = dmean[0]; a.dL_dmean3D[3 * idx + 1] = dmean[1]; a.dL_dmean3D[3 * idx + 2] = dmean[2]; }
+    if (a.dL_ddc) { a.dL_ddc[3 * idx] = ddc[0]; a.dL_ddc[3 * idx + 1] = ddc[1]; a.dL_ddc[3 * idx + 2] = ddc[2]; }
+    if (a.dL_dscale) { a.dL_dscale[3 * idx] = dscale[0]; a.dL_dscale[3 * idx + 1] = dscale[1]; a.dL_dscale[3 * idx + 2] = dscale[2]; }
+    if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = dq;
+    if (a.adam.on) {
         const AdamFusedArgs& A = a.adam;
         const float dqv[4] = {dq.x, dq.y, dq.z, dq.w};
 #pragma unroll
