@@ -1,0 +1,31 @@
+#!/bin/bash
+# Everything profiles/ and DESIGN.md section 6 quote, in one call on the MI355X box:
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/measure_all.sh r01d'
+# Writes small summaries to gpurun_out/<tag>_*; rocprofv3 databases stay in /tmp (too large to merge back).
+set -u
+TAG=${1:-rXX}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B="timeout 300 python $R/bench.py"
+{
+  $B 2>/dev/null | tail -1
+  $B --mode render --no-cpu-baseline 2>/dev/null | tail -1
+  $B --mode slam --no-cpu-baseline 2>/dev/null | tail -1
+  $B --split-adam --no-cpu-baseline 2>/dev/null | tail -1
+  $B --scene lidar --no-cpu-baseline 2>/dev/null | tail -1
+  $B --gaussians 5000000 --width 3840 --height 2160 --no-cpu-baseline --steps 10 2>/dev/null | tail -1
+} > $OUT/${TAG}_bench_lines.jsonl
+# per-kernel durations
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG -- python $R/bench.py --steps 10 --warmup 4 --no-cpu-baseline > /tmp/prof_$TAG.log 2>&1
+python $R/tools/rocpd_summary.py $(find /tmp/prof_$TAG -name "*.db" | head -1) $OUT/${TAG}_train_2M_1080p_kernel_stats > /dev/null
+# HBM traffic (separate passes), SQ counters
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf_$TAG -o f -- python $R/tools/pmc_run.py > /tmp/pf.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw_$TAG -o w -- python $R/tools/pmc_run.py > /tmp/pw.log 2>&1
+python $R/tools/pmc_extract.py $(find /tmp/pf_$TAG -name "*.db" | head -1) $(find /tmp/pw_$TAG -name "*.db" | head -1) $OUT/${TAG}_pmc_traffic.json > /dev/null
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -d /tmp/sq_$TAG -o sq -- python $R/tools/pmc_run.py > /tmp/sq.log 2>&1
+python $R/tools/pmc_sq_extract.py $(find /tmp/sq_$TAG -name "*.db" | head -1) > $OUT/${TAG}_sq_counters.txt 2>&1
+timeout 60 $R/tools/ubench/valu_rate > $OUT/${TAG}_ubench.txt 2>&1
+timeout 60 $R/tools/ubench/hbm_rate >> $OUT/${TAG}_ubench.txt 2>&1
+ls -la $OUT | tail -12

@@ -41,6 +41,13 @@ def main(fetch_db, write_db, out):
         wb = w.get(k, (0, 0.0))[1] * 1024.0 * write_factor
         res["kernels"][short] = {"launches": f.get(k, (0, 0))[0], "fetch_bytes": fb, "write_bytes": wb, "hbm_bytes_per_launch": fb + wb,
                                  "raw_FETCH_SIZE_KB": f.get(k, (0, 0.0))[1], "raw_WRITE_SIZE_KB": w.get(k, (0, 0.0))[1]}
+    # template kernels also under their bare name when that is unambiguous (bench.py looks kernels up as "<name>_kernel")
+    bare = {}
+    for k in res["kernels"]:
+        bare.setdefault(k.split("<")[0], []).append(k)
+    for b, ks in bare.items():
+        if len(ks) == 1 and b not in res["kernels"]:
+            res["kernels"][b] = res["kernels"][ks[0]]
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in res["kernels"].items()}), "MB/launch; factors", fetch_factor, write_factor)
 

@@ -17,7 +17,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 del a, b
 W, H, P = 1920, 1080, 2_000_000
-model = trainer.GaussianModel(random_scene(P, W, H, 3, 0), dev); model.training_setup()
+model = trainer.GaussianModel(random_scene(P, W, H, 3, 0), dev); model.training_setup({k: v * 0.01 for k, v in trainer.DEFAULT_LRS.items()})  # stationary scene, as bench.py
 cam = synthetic_camera(W, H).to_device(dev)
 gt = gt_image(H, W).to(dev); bg = torch.zeros(3, device=dev)
 fused = os.environ.get("PMC_HOST", "fused") == "fused"   # the default bench path; PMC_HOST=dropin for the per-op path
