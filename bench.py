@@ -90,12 +90,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    torch.cuda.set_device(dev)   # before the process group: RCCL binds the communicator to the current device
+    if world > 1 or os.environ.get("GSLIC_FORCE_DIST") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import gaussian_lic_amd  # noqa: F401
     from gaussian_lic_amd import _lib, trainer
@@ -221,7 +222,7 @@ def main():
     stats = dict(P=P, V=int(visible.sum().item()), R=int(Rn), B=int(Bn), N=W * H, T=((W + 15) // 16) * ((H + 15) // 16), K=16)
 
     if rank != 0:
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
 
@@ -282,7 +283,7 @@ def main():
         "kernel_ms_per_step": {k: round(v[0] / max(nprof, 1), 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
     }
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

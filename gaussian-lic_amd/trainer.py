@@ -6,6 +6,8 @@ One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" 
 holds a full replica of the parameters and Adam state, renders a different camera view, and applies the identical
 sparse-Adam update, so replicas stay bit-identical without a broadcast.
 """
+import os
+
 import torch
 
 from . import loss as loss_utils
@@ -127,7 +129,11 @@ class GaussianModel:
 
 
 def _dist_on():
-    return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    """True when the per-step gradient exchange has to run.  GSLIC_FORCE_DIST=1 also takes the exchange path in a process group of
+    ONE rank (the RCCL smoke test on a single-GPU box: same code path as N > 1, the all-reduce degenerates to a copy)."""
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return False
+    return torch.distributed.get_world_size() > 1 or os.environ.get("GSLIC_FORCE_DIST") == "1"
 
 
 class GradSlab:

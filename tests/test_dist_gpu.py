@@ -1,0 +1,78 @@
+"""RCCL smoke test of the N > 1 step on a single-GPU box: a process group of ONE rank with GSLIC_FORCE_DIST=1 takes exactly the code
+path every rank takes at N > 1 (gradients to the flat slab -> all_reduce(SUM) on the slab + all_reduce(MAX) on the visibility bytes
+through torch.distributed's nccl (= RCCL) backend -> masked Adam).  With one rank the sum is the identity, so the trajectory must
+equal the single-process split-Adam path bit for bit.  (World size 2 is covered on CPU with gloo, tests/test_distributed_cpu.py.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SNIPPET = r"""
+import os, sys, torch
+sys.path.insert(0, {root!r})
+import gaussian_lic_amd
+from gaussian_lic_amd import trainer
+from gaussian_lic_amd.camera import synthetic_camera
+from gaussian_lic_amd.synthetic import random_scene, gt_image
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+forced = os.environ.get("GSLIC_FORCE_DIST") == "1"
+if forced:
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+W, H, P = 320, 192, 30000
+model = trainer.GaussianModel(random_scene(P, W, H, 3, 5), dev); model.training_setup()
+cam = synthetic_camera(W, H).to_device(dev); gt = gt_image(H, W).to(dev); bg = torch.zeros(3, device=dev)
+for _ in range(3):
+    loss = trainer.training_step_fused(model, cam, gt, bg, adam_in_backward=False)[0]
+torch.cuda.synchronize()
+import hashlib
+h = hashlib.sha256()
+for t in (model.xyz, model.features_dc, model.features_rest, model.opacity, model.scaling, model.rotation):
+    h.update(t.detach().cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest(), float(torch.as_tensor(loss).double().sum()))
+if forced:
+    torch.distributed.destroy_process_group()
+"""
+
+
+def _run(force):
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if force:
+        env["GSLIC_FORCE_DIST"] = "1"
+    else:
+        env.pop("GSLIC_FORCE_DIST", None)
+    r = subprocess.run([sys.executable, "-c", SNIPPET.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1].split()
+    return line[1], float(line[2])
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_path_world1_matches_local_path():
+    d_local, l_local = _run(False)
+    d_dist, l_dist = _run(True)
+    assert l_local == l_dist
+    assert d_local == d_dist
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_one_rank():
+    """bench.py launched the way the driver launches it (torch.distributed.run, RANK / WORLD_SIZE from the environment) prints one
+    JSON line with the contract's keys."""
+    env = dict(os.environ)
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", GSLIC_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--gaussians", "100000",
+           "--width", "640", "--height", "360", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
