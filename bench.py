@@ -310,7 +310,41 @@ def cpu_baseline(args):
         t_spent += time.perf_counter() - t0
         iters += 1
     per_view = t_spent / iters
-    return {"value": round(1.0 / (16.0 * per_view), 4), "unit": "views/s", "cores": orc.max_threads(), "kind": "port",
+    # the oracle as the CHECKER on the same sample: PSNR of the HIP image against the oracle image, worst gradient error
+    parity = None
+    try:
+        import torch
+        from gaussian_lic_amd import rasterizer as rz
+        from gaussian_lic_amd.camera import synthetic_camera as _sc
+        dev = torch.device("cuda", torch.cuda.current_device())
+        camo = _sc(Ws, Hs)
+        act = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in activate(raw).items()}
+        e = torch.empty(0, device=dev)
+        vm, pm = torch.from_numpy(camo.world_view_transform).to(dev), torch.from_numpy(camo.full_proj_transform).to(dev)
+        cp = torch.from_numpy(camo.camera_center).to(dev)
+        lim = (float(camo.limx_neg), float(camo.limx_pos), float(camo.limy_neg), float(camo.limy_pos))
+        R, B, color, final_T, radii, geom, binning, img, sample = rz.rasterize_gaussians(
+            torch.zeros(3, device=dev), act["means"], e, act["opac"], act["scales"], act["rots"], 1.0, e, vm, pm, float(camo.tanfovx),
+            float(camo.tanfovy), Hs, Ws, *lim, act["dc"], act["shs"], act["D"], cp, False, False, False)
+        g = rz.rasterize_gaussians_backward(torch.zeros(3, device=dev), act["means"], radii, e, act["scales"], act["rots"], 1.0, e, vm, pm,
+                                            float(camo.tanfovx), float(camo.tanfovy), *lim, torch.from_numpy(dL).to(dev), act["dc"], act["shs"],
+                                            act["D"], cp, geom, R, binning, img, B, sample, 0.0, False)
+        ob = orc.backward(sc, cam, f, dL)
+        mse = float(np.mean((color.cpu().numpy().astype(np.float64) - f["color"].astype(np.float64)) ** 2))
+        names = ["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_ddc", "dL_dsh", "dL_dscale", "dL_drot"]
+        worst = 0.0
+        for n_, t_ in zip(names, g):
+            if n_ in ob and t_ is not None and t_.numel():
+                ref = np.asarray(ob[n_], dtype=np.float64).reshape(-1)
+                got = t_.detach().cpu().numpy().astype(np.float64).reshape(-1)
+                if ref.shape == got.shape and np.abs(ref).max() > 0:
+                    # 99.99th percentile: a handful of alpha < 1/255 threshold flips per million are expected
+                    worst = max(worst, float(np.quantile(np.abs(got - ref), 0.9999) / np.abs(ref).max()))
+        parity = {"psnr_image_vs_oracle_db": round(10.0 * np.log10(1.0 / max(mse, 1e-30)), 1), "grad_err_p9999_rel_maxabs": float(f"{worst:.2e}"),
+                  "instances_equal": int(R) == int(f["num_rendered"])}
+    except Exception as ex:  # the baseline leg must never take the bench line down
+        parity = {"error": str(ex)[:200]}
+    return {"value": round(1.0 / (16.0 * per_view), 4), "unit": "views/s", "cores": orc.max_threads(), "kind": "port", "hip_vs_oracle": parity,
             "sample": f"1/16-scale instance ({Ps} Gaussians, {Ws}x{Hs}, SH degree 3) render fwd+bwd, {iters} iterations, "
                       f"{per_view * 1e3:.1f} ms/view measured; value = 1/(16 x that) full-size-equivalent views/s"}
 
