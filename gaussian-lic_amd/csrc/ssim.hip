@@ -13,6 +13,7 @@ namespace gslic {
 
 static constexpr int ST = 32;        // output tile edge
 static constexpr int SH_ = ST + 10;  // halo tile edge (42)
+static constexpr int HALO_TRIPS = (SH_ * SH_ + 255) / 256;  // halo elements per thread (7)
 
 __constant__ float c_G[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.036000773310661316f, 0.10936068743467331f,
                               0.21300552785396576f,  0.26601171493530273f,   0.21300552785396576f,  0.10936068743467331f,
@@ -36,10 +37,20 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, float C1, f
     const float* b = img2 + plane;
     const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
     const int tid = threadIdx.x;
-    for (int t = tid; t < SH_ * SH_; t += 256) {
-        const int ly = t / SH_, lx = t % SH_;
-        sa[ly][lx] = pix_or_zero(a, H, W, y0 + ly - 5, x0 + lx - 5);
-        sb[ly][lx] = pix_or_zero(b, H, W, y0 + ly - 5, x0 + lx - 5);
+    {   // all of a thread's halo loads are issued before the first LDS store: a rolled loop pays one memory round trip per trip
+        float va[HALO_TRIPS], vb[HALO_TRIPS];
+#pragma unroll
+        for (int k = 0; k < HALO_TRIPS; k++) {
+            const int t = tid + 256 * k;
+            const int ly = t / SH_, lx = t - ly * SH_;
+            va[k] = (t < SH_ * SH_) ? pix_or_zero(a, H, W, y0 + ly - 5, x0 + lx - 5) : 0.f;
+            vb[k] = (t < SH_ * SH_) ? pix_or_zero(b, H, W, y0 + ly - 5, x0 + lx - 5) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < HALO_TRIPS; k++) {
+            const int t = tid + 256 * k;
+            if (t < SH_ * SH_) { (&sa[0][0])[t] = va[k]; (&sb[0][0])[t] = vb[k]; }
+        }
     }
     __syncthreads();
     for (int t = tid; t < SH_ * ST; t += 256) {
@@ -100,13 +111,24 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float
     const size_t plane = (size_t)blockIdx.z * H * W;
     const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
     const int tid = threadIdx.x;
-    for (int t = tid; t < SH_ * SH_; t += 256) {
-        const int ly = t / SH_, lx = t % SH_;
-        const int y = y0 + ly - 5, x = x0 + lx - 5;
-        const float dl = pix_or_zero(dL_dmap + plane, H, W, y, x);
-        s1[ly][lx] = pix_or_zero(dm_dmu1 + plane, H, W, y, x) * dl;
-        s2[ly][lx] = pix_or_zero(dm_dsigma1_sq + plane, H, W, y, x) * dl;
-        s3[ly][lx] = pix_or_zero(dm_dsigma12 + plane, H, W, y, x) * dl;
+    {
+        float v0[HALO_TRIPS], v1[HALO_TRIPS], v2[HALO_TRIPS], v3[HALO_TRIPS];
+#pragma unroll
+        for (int k = 0; k < HALO_TRIPS; k++) {
+            const int t = tid + 256 * k;
+            const int ly = t / SH_, lx = t - ly * SH_;
+            const int y = y0 + ly - 5, x = x0 + lx - 5;
+            const bool in = t < SH_ * SH_;
+            v0[k] = in ? pix_or_zero(dL_dmap + plane, H, W, y, x) : 0.f;
+            v1[k] = in ? pix_or_zero(dm_dmu1 + plane, H, W, y, x) : 0.f;
+            v2[k] = in ? pix_or_zero(dm_dsigma1_sq + plane, H, W, y, x) : 0.f;
+            v3[k] = in ? pix_or_zero(dm_dsigma12 + plane, H, W, y, x) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < HALO_TRIPS; k++) {
+            const int t = tid + 256 * k;
+            if (t < SH_ * SH_) { (&s1[0][0])[t] = v1[k] * v0[k]; (&s2[0][0])[t] = v2[k] * v0[k]; (&s3[0][0])[t] = v3[k] * v0[k]; }
+        }
     }
     __syncthreads();
     for (int t = tid; t < SH_ * ST; t += 256) {
@@ -172,10 +194,20 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(int H, int W, float C1, f
     const float* b = img2 + plane;
     const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
     const int tid = threadIdx.x;
-    for (int t = tid; t < SH_ * SH_; t += 256) {
-        const int ly = t / SH_, lx = t % SH_;
-        sa[ly][lx] = pix_or_zero(a, H, W, y0 + ly - 5, x0 + lx - 5);
-        sb[ly][lx] = pix_or_zero(b, H, W, y0 + ly - 5, x0 + lx - 5);
+    {   // all of a thread's halo loads are issued before the first LDS store: a rolled loop pays one memory round trip per trip
+        float va[HALO_TRIPS], vb[HALO_TRIPS];
+#pragma unroll
+        for (int k = 0; k < HALO_TRIPS; k++) {
+            const int t = tid + 256 * k;
+            const int ly = t / SH_, lx = t - ly * SH_;
+            va[k] = (t < SH_ * SH_) ? pix_or_zero(a, H, W, y0 + ly - 5, x0 + lx - 5) : 0.f;
+            vb[k] = (t < SH_ * SH_) ? pix_or_zero(b, H, W, y0 + ly - 5, x0 + lx - 5) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < HALO_TRIPS; k++) {
+            const int t = tid + 256 * k;
+            if (t < SH_ * SH_) { (&sa[0][0])[t] = va[k]; (&sb[0][0])[t] = vb[k]; }
+        }
     }
     __syncthreads();
     for (int t = tid; t < SH_ * ST; t += 256) {
@@ -255,12 +287,23 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(int H, int W, float w_l1,
     const size_t plane = (size_t)blockIdx.z * H * W;
     const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
     const int tid = threadIdx.x;
-    for (int t = tid; t < SH_ * SH_; t += 256) {
-        const int ly = t / SH_, lx = t % SH_;
-        const int y = y0 + ly - 5, x = x0 + lx - 5;
-        s1[ly][lx] = pix_or_zero(dm_dmu1 + plane, H, W, y, x);
-        s2[ly][lx] = pix_or_zero(dm_dsigma1_sq + plane, H, W, y, x);
-        s3[ly][lx] = pix_or_zero(dm_dsigma12 + plane, H, W, y, x);
+    {
+        float v1[HALO_TRIPS], v2[HALO_TRIPS], v3[HALO_TRIPS];
+#pragma unroll
+        for (int k = 0; k < HALO_TRIPS; k++) {
+            const int t = tid + 256 * k;
+            const int ly = t / SH_, lx = t - ly * SH_;
+            const int y = y0 + ly - 5, x = x0 + lx - 5;
+            const bool in = t < SH_ * SH_;
+            v1[k] = in ? pix_or_zero(dm_dmu1 + plane, H, W, y, x) : 0.f;
+            v2[k] = in ? pix_or_zero(dm_dsigma1_sq + plane, H, W, y, x) : 0.f;
+            v3[k] = in ? pix_or_zero(dm_dsigma12 + plane, H, W, y, x) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < HALO_TRIPS; k++) {
+            const int t = tid + 256 * k;
+            if (t < SH_ * SH_) { (&s1[0][0])[t] = v1[k]; (&s2[0][0])[t] = v2[k]; (&s3[0][0])[t] = v3[k]; }
+        }
     }
     __syncthreads();
     for (int t = tid; t < SH_ * ST; t += 256) {
