@@ -190,11 +190,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define GS_PK_FMA(a, b, c) __builtin_elementwise_fma((a), (b), (c))
 #define GS_SPLAT(x) ((v2f){(x), (x)})
 
-// One pipeline step.  The evolving part of a pixel's state {T, ar[3]} and its tag (n_contrib << 8 | pixel index) move
+// One pipeline step.  The evolving part of a pixel's state {T, ar[3]} and its tag (rel << 16 | py << 8 | 16 px, see kcmp) move
 // lane -> lane+1 with one DPP each; the injected values enter through the DPP's `old` operand (lane 0 has no source lane).
 // The per-pixel CONSTANTS (dL/dpixel) do not travel: the wave parks every 64-pixel chunk in LDS once (coalesced
 // ds_write_b128) and a lane fetches its current pixel's record with one ds_read_b128.  VALU is the bound of this kernel
-// (profiles/r01_sq_counters_render.md), so every value taken off the conveyor is three VALU ops saved per step, and the
+// (profiles/r01e_sq_counters.txt), so every value taken off the conveyor is three VALU ops saved per step, and the
 // gradient arithmetic is written on float2 pairs: gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 at the rate of the scalar forms
 // (the fp32 peak of the part assumes them), with op_sel covering the splats and the one swizzle for free.  Each component
 // still sees exactly the scalar operation sequence, so the results do not change.
@@ -210,16 +210,16 @@ typedef float v2f __attribute__((ext_vector_type(2)));
     } while (0)
 #define GS_BWD_BODY()                                                                                                \
     do {                                                                                                             \
-        if (kcmp < tag) { /* kit < n_contrib of this pixel (backward.cu:538) */                                     \
-            const v2f pxy = {(float)(tag & 15u), (float)((tag >> 4) & 15u)};                                         \
-            const v2f d = d0 - pxy;                                                                                  \
+        if (kcmp < tag) { /* lane < n_contrib - bucket start: this Gaussian precedes the pixel's last one (backward.cu:538) */ \
+            const v2f pxy16 = {(float)(tag & 0xffu), (float)((tag >> 8) & 0xffu)}; /* v_cvt_f32_ubyte0 / ubyte1: {16 px, py} */ \
+            const v2f d = GS_PK_FMA(pxy16, ((v2f){-0.0625f, -1.0f}), d0); /* exact: d0 - {px, py} */                 \
             float p2 = (hA * d.x) * d.x; /* same operation order as render_fwd: identical alpha on both sides */    \
             p2 = __builtin_fmaf(hC * d.y, d.y, p2);                                                                  \
             p2 = __builtin_fmaf(nB * d.x, d.y, p2); /* = log2(e) * power */                                          \
             const float G = __builtin_amdgcn_exp2f(p2);                                                              \
             const float alpha = fminf(0.99f, op * G);                                                                \
             if (!(p2 > 0.0f) && !(alpha < (1.0f / 255.0f))) {                                                        \
-                const float4 gr = grec[tag & 255u];                                                                  \
+                const float4 gr = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(grec) + (tag & 0xffffu)); \
                 const v2f grxy = {gr.x, gr.y};                                                                       \
                 const float om = 1.0f - alpha;                                                                       \
                 const float rinv = __builtin_amdgcn_rcpf(om);                                                        \
@@ -288,7 +288,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void render_bwd_kernel(RenderBwdArg
     const float LOG2E = 1.4426950408889634f;
     const float hA = -0.5f * LOG2E * cA, hC = -0.5f * LOG2E * cC, nB = -LOG2E * cB;
     const v2f cAC = {cA, cC};
-    const uint32_t kcmp = (kit << 8) | 0xffu;  // kcmp < (n_contrib << 8 | idx)  <=>  kit < n_contrib
+    // pixel tag = rel << 16 | py << 8 | 16 px, rel = min(n_contrib - bucket start, 64): the low half is both the byte offset of the pixel's
+    // float4 in grec[] (row stride 256 B) and two bytes v_cvt_f32_ubyte0/1 turn into coordinates; kcmp < tag  <=>  lane < rel
+    const uint32_t kcmp = ((uint32_t)lane << 16) | 0xffffu;
     v2f acc_m = {0.f, 0.f}, acc_cxy = {0.f, 0.f}, acc_rg = {0.f, 0.f};
     float acc_cw = 0, acc_op = 0, acc_b = 0;
     const size_t plane = (size_t)a.H * a.W;
@@ -319,7 +321,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void render_bwd_kernel(RenderBwdArg
     for (int c = 0; c < 4; c++) {
         // park this chunk in LDS, then start the next chunk's global loads
         const uint32_t ncp = inside ? __float_as_uint(pf.w) : 0u;
-        const uint32_t ftag = (ncp << 8) | (uint32_t)(c * 64 + lane);
+        const uint32_t pidx = (uint32_t)(c * 64 + lane);
+        const uint32_t rel = ncp > bstart ? (ncp - bstart < 64u ? ncp - bstart : 64u) : 0u;
+        const uint32_t ftag = (rel << 16) | ((pidx >> 4) << 8) | ((pidx & 15u) << 4);
         grec[c * 64 + lane] = make_float4(fg0, fg1, fg2, 0.f);
         init[lane] = make_float4(ck.y - pf.x, ck.z - pf.y, ck.x, ck.w - pf.z);  // ar0, ar1, T, ar2 (ar = checkpoint colour - final colour)
         uint64_t active = __ballot(ncp > bstart);  // pixels that reach this bucket; the others contribute nothing here
