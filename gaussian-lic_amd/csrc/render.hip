@@ -187,6 +187,7 @@ __device__ __forceinline__ float shift_zero_f(float v)
 __device__ __forceinline__ uint32_t shift_zero_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 #define GS_PK_FMA(a, b, c) __builtin_elementwise_fma((a), (b), (c))
 #define GS_SPLAT(x) ((v2f){(x), (x)})
 
@@ -198,14 +199,18 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // gradient arithmetic is written on float2 pairs: gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 at the rate of the scalar forms
 // (the fp32 peak of the part assumes them), with op_sel covering the splats and the one swizzle for free.  Each component
 // still sees exactly the scalar operation sequence, so the results do not change.
-#define GS_BWD_SHIFT(inj /*float4 {ar0, ar1, T, ar2}: ar0/ar1 land in an even-aligned register pair*/, itag)          \
+#define GS_BWD_SHIFT(sl, itag)                                                                                       \
     do {                                                                                                             \
-        ar01.x = shift_in_f((inj).x, ar01.x); ar01.y = shift_in_f((inj).y, ar01.y); T = shift_in_f((inj).z, T);      \
-        ar2 = shift_in_f((inj).w, ar2); tag = shift_in_u(itag, tag);                                                 \
+        st.x = shift_zero_f(st.x); st.y = shift_zero_f(st.y); st.z = shift_zero_f(st.z); st.w = shift_zero_f(st.w);  \
+        tag = shift_zero_u(tag);                                                                                     \
+        if (lane == 0) { /* one ds_read_b128 under a one-lane exec mask, straight into the state registers */       \
+            st = *reinterpret_cast<const v4f*>(&init[sl]);                                                           \
+            tag = (itag);                                                                                            \
+        }                                                                                                            \
     } while (0)
 #define GS_BWD_SHIFT_ZERO()                                                                                          \
     do {                                                                                                             \
-        T = shift_zero_f(T); ar01.x = shift_zero_f(ar01.x); ar01.y = shift_zero_f(ar01.y); ar2 = shift_zero_f(ar2);  \
+        st.x = shift_zero_f(st.x); st.y = shift_zero_f(st.y); st.z = shift_zero_f(st.z); st.w = shift_zero_f(st.w);  \
         tag = shift_zero_u(tag);                                                                                     \
     } while (0)
 #define GS_BWD_BODY()                                                                                                \
@@ -223,15 +228,15 @@ typedef float v2f __attribute__((ext_vector_type(2)));
                 const v2f grxy = {gr.x, gr.y};                                                                       \
                 const float om = 1.0f - alpha;                                                                       \
                 const float rinv = __builtin_amdgcn_rcpf(om);                                                        \
-                const float Ta = T * alpha;                                                                          \
-                ar01 = GS_PK_FMA(GS_SPLAT(Ta), col_rg, ar01); ar2 = __builtin_fmaf(Ta, colb, ar2);                   \
+                const float Ta = st.z * alpha;                                                                          \
+                st.xy = GS_PK_FMA(GS_SPLAT(Ta), col_rg, st.xy); st.w = __builtin_fmaf(Ta, colb, st.w);                   \
                 acc_rg = GS_PK_FMA(GS_SPLAT(Ta), grxy, acc_rg); acc_b = __builtin_fmaf(Ta, gr.z, acc_b);             \
-                const v2f t = GS_PK_FMA(GS_SPLAT(rinv), ar01, col_rg * GS_SPLAT(T));                                 \
-                const float tb = __builtin_fmaf(rinv, ar2, colb * T);                                                \
+                const v2f t = GS_PK_FMA(GS_SPLAT(rinv), st.xy, col_rg * GS_SPLAT(st.z));                                 \
+                const float tb = __builtin_fmaf(rinv, st.w, colb * st.z);                                                \
                 float dLda = t.x * gr.x;                                                                             \
                 dLda = __builtin_fmaf(t.y, gr.y, dLda);                                                              \
                 dLda = __builtin_fmaf(tb, gr.z, dLda);                                                               \
-                T *= om;                                                                                             \
+                st.z *= om;                                                                                          \
                 const float q = op * dLda; /* dL/dG */                                                               \
                 const v2f gd = GS_SPLAT(G) * d;                                                                      \
                 const v2f gdyx = {gd.y, gd.x};                                                                       \
@@ -296,8 +301,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void render_bwd_kernel(RenderBwdArg
     const size_t plane = (size_t)a.H * a.W;
 
     // evolving pixel state travelling through the lanes
-    float T = 0, ar2 = 0;
-    v2f ar01 = {0.f, 0.f};
+    v4f st = {0.f, 0.f, 0.f, 0.f};  // {ar0, ar1, T, ar2}: one register quad, ar0/ar1 an aligned pair for the packed ops
     uint32_t tag = 0;
 
     // 64-pixel feed chunk (register double buffer: chunk c+1 is in flight while chunk c streams through)
@@ -336,18 +340,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void render_bwd_kernel(RenderBwdArg
             {
                 const int sl = __builtin_ctzll(active);
                 active &= active - 1;
-                const float4 inj = init[sl];  // wave-uniform address: LDS broadcast
                 const uint32_t itag = readlane_u(ftag, sl);
-                GS_BWD_SHIFT(inj, itag);
+                GS_BWD_SHIFT(sl, itag);
                 GS_BWD_BODY();
             }
             if (!active) break;
             {
                 const int sl = __builtin_ctzll(active);
                 active &= active - 1;
-                const float4 inj = init[sl];
                 const uint32_t itag = readlane_u(ftag, sl);
-                GS_BWD_SHIFT(inj, itag);
+                GS_BWD_SHIFT(sl, itag);
                 GS_BWD_BODY();
             }
         }
