@@ -199,13 +199,13 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // gradient arithmetic is written on float2 pairs: gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 at the rate of the scalar forms
 // (the fp32 peak of the part assumes them), with op_sel covering the splats and the one swizzle for free.  Each component
 // still sees exactly the scalar operation sequence, so the results do not change.
-#define GS_BWD_SHIFT(sl, itag)                                                                                       \
+#define GS_BWD_SHIFT(sl)                                                                                             \
     do {                                                                                                             \
         st.x = shift_zero_f(st.x); st.y = shift_zero_f(st.y); st.z = shift_zero_f(st.z); st.w = shift_zero_f(st.w);  \
         tag = shift_zero_u(tag);                                                                                     \
         if (lane == 0) { /* one ds_read_b128 under a one-lane exec mask, straight into the state registers */       \
             st = *reinterpret_cast<const v4f*>(&init[sl]);                                                           \
-            tag = (itag);                                                                                            \
+            tag = itags[sl];                                                                                         \
         }                                                                                                            \
     } while (0)
 #define GS_BWD_SHIFT_ZERO()                                                                                          \
@@ -255,10 +255,12 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void render_bwd_kernel(RenderBwdArg
     // per-wave LDS: the pixel records of the whole tile (dL/dpixel, by pixel index) and the current chunk's start states
     __shared__ float4 s_grec[BWD_WAVES][GS_TILE_PIX];
     __shared__ float4 s_init[BWD_WAVES][64];
+    __shared__ uint32_t s_itag[BWD_WAVES][64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     float4* const grec = s_grec[wave];
     float4* const init = s_init[wave];
+    uint32_t* const itags = s_itag[wave];
     const uint32_t bucket = blockIdx.x * (uint32_t)BWD_WAVES + (uint32_t)wave;
     if (bucket >= (uint32_t)a.B) return;
     const uint32_t tile = a.bucket_to_tile[bucket];
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void render_bwd_kernel(RenderBwdArg
         const uint32_t ftag = (rel << 16) | ((pidx >> 4) << 8) | ((pidx & 15u) << 4);
         grec[c * 64 + lane] = make_float4(fg0, fg1, fg2, 0.f);
         init[lane] = make_float4(ck.y - pf.x, ck.z - pf.y, ck.x, ck.w - pf.z);  // ar0, ar1, T, ar2 (ar = checkpoint colour - final colour)
+        itags[lane] = ftag;
         uint64_t active = __ballot(ncp > bstart);  // pixels that reach this bucket; the others contribute nothing here
         if (c < 3) load_chunk(c + 1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -340,16 +343,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void render_bwd_kernel(RenderBwdArg
             {
                 const int sl = __builtin_ctzll(active);
                 active &= active - 1;
-                const uint32_t itag = readlane_u(ftag, sl);
-                GS_BWD_SHIFT(sl, itag);
+                GS_BWD_SHIFT(sl);
                 GS_BWD_BODY();
             }
             if (!active) break;
             {
                 const int sl = __builtin_ctzll(active);
                 active &= active - 1;
-                const uint32_t itag = readlane_u(ftag, sl);
-                GS_BWD_SHIFT(sl, itag);
+                GS_BWD_SHIFT(sl);
                 GS_BWD_BODY();
             }
         }
