@@ -259,7 +259,7 @@ int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_
 
     if (R > 0) {
         KeybuildArgs ka;
-        ka.P = P; ka.gx = gx; ka.gy = gy; ka.radii = radii; ka.rec = geom.rec; ka.order = order; ka.offsets = geom.point_offsets;
+        ka.P = P; ka.gx = gx; ka.gy = gy; ka.rec = geom.rec; ka.order = order; ka.offsets = geom.point_offsets;
         ka.tile_keys = bin.tile_keys[0]; ka.gauss = bin.gauss[0]; ka.gauss_start = geom.gauss_start;
         GS_TRY(launch_keybuild(ka, s));
         DEBUG_SYNC(prm, s);

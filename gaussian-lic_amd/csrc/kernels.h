@@ -21,7 +21,6 @@ int launch_preprocess(const PreprocessArgs& a, hipStream_t s);
 
 struct KeybuildArgs {
     int P, gx, gy;
-    const int32_t* radii;
     const float4* rec;
     const uint32_t* order;     // [P] Gaussian ids by ascending (depth, id)
     const uint32_t* offsets;   // [P] inclusive scan of tiles_touched[order[i]]
