@@ -117,10 +117,16 @@ def test_determinism_and_lambda_erank(oracle32):
     assert rel_err(g1["dL_dscale"], gref["dL_dscale"]) < TOL
 
 
-def test_large_scene_properties():
-    """Size-independent properties at a BASELINE-scale shape (500k Gaussians, 1080p)."""
-    from gpu_helpers import hip_forward, npy
-    raw, sc, camd, cam = make_scene("random", 500000, 1920, 1080, 3, 0)
+@pytest.mark.parametrize("P,W,H", [(500000, 1920, 1080),     # BASELINE config 2 shape
+                                   (2000000, 1920, 1080),    # config 3 / 4: the headline workload of bench.py
+                                   (5000000, 3840, 2160)])   # config 5: 32400 tiles, ~15M instances
+def test_large_scene_properties(P, W, H):
+    """Size-independent properties at BASELINE.json's full sizes (the oracle takes minutes there): sortedness and stability of the
+    instance list, ranges partitioning it, multiplicities, bounds of the image statistics; then linearity of the backward in
+    dL/dimage and run-to-run bit-reproducibility."""
+    from gpu_helpers import hip_backward, hip_forward, npy
+    from gaussian_lic_amd.synthetic import pixel_grad
+    raw, sc, camd, cam = make_scene("random", P, W, H, 3, 0)
     f = hip_forward(raw, cam, export=("tiles_touched", "sorted_keys", "point_list", "ranges", "n_contrib", "max_contrib"))
     d = f["dbg"]
     keys = npy(d["sorted_keys"]).view(np.uint64)
@@ -146,6 +152,18 @@ def test_large_scene_properties():
     ncb = npy(d["n_contrib"]).astype(np.int64)
     assert ncb.max() <= cnt.max()
     assert int(npy(d["max_contrib"]).max()) == int(ncb.max())
+    del keys, pl, tiles, d
+    # backward: linear in dL/dimage, and bit-reproducible
+    d1, d2 = pixel_grad(H, W, seed=1), pixel_grad(H, W, seed=2)
+    g1 = hip_backward(f, d1)
+    g2 = hip_backward(f, d2)
+    g12 = hip_backward(f, d1 + 2.0 * d2)
+    g1b = hip_backward(f, d1)
+    for k in g1:
+        np.testing.assert_array_equal(g1[k], g1b[k])
+        lin = g1[k].astype(np.float64) + 2.0 * g2[k].astype(np.float64)
+        scale = max(float(np.abs(lin).max()), 1e-30)
+        assert float(np.abs(g12[k] - lin).max()) / scale < 2e-4, k
 
 
 def test_onesweep_sort_variant_is_bit_identical():
