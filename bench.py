@@ -41,7 +41,7 @@ def algorithmic_bytes(kernel, s):
         "dsort_scatter": 16 * P,
         "depth_gather": 12 * P,
         # per Gaussian: order 4 + radius 4; per visible: record 32 + offset 4 in, start 4 out; per instance: tile 4 + gaussian id 4 out
-        "keybuild": 8 * P + 40 * V + 8 * R,
+        "keybuild": 8 * P + 52 * V + 8 * R,
         "sort_hist": 4 * R,                       # tile keys once per pass
         "sort_scatter": 24 * R,                   # key + slot + gaussian id in and out, per pass (the first pass reads no slot: 20)
         "finalize_lists": 4 * R + 8 * T,          # sorted tile ids in, ranges out
@@ -251,7 +251,7 @@ def main():
         # so this is an upper bound of the pairs actually evaluated (no FLOP claim is derived from it)
         slots = 256.0 * 64.0 * stats["B"]
         roofline["valu"] = dict(pair_slots_per_launch=slots, gslots_per_s=round(slots / (avg_ms * 1e-3) / 1e9, 2) if avg_ms > 0 else 0,
-                                note="VALU-issue bound (profiles/r01e_sq_counters.txt); HBM frac above is not the limiter")
+                                note="VALU-issue bound (profiles/r01f_sq_counters.txt); HBM frac above is not the limiter")
 
     # ---- CPU baseline: the oracle (C port of the reference kernels, OpenMP) on a 1/16-scale sample of the same workload
     cpu = None
