@@ -50,6 +50,7 @@ __device__ __forceinline__ float strip_max_p2(float hA, float hC, float nB, floa
 
 __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
 {
+    __shared__ float4 s_rec[3 * GS_BUCKET];
     const int tile = blockIdx.x;
     const int lane = threadIdx.x;
     const int tx0 = (tile % a.gx) * GS_TILE, ty0 = (tile / a.gx) * GS_TILE;
@@ -106,13 +107,21 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
             }
         }
         const float lx = (float)(lane & 15), ly = (float)(lane >> 4);
+        // the batch's 64 pre-scaled records are parked in LDS and entry j is fetched with three ds_read_b128 at a wave-uniform
+        // address (LDS broadcast; the next entry is in flight while this one is blended): ten v_readlane per entry cost VALU
+        // issue slots, which is what bounds this kernel — LDS reads do not
+        s_rec[3 * lane] = make_float4(fdx, fdy, fhA, fnB);
+        s_rec[3 * lane + 1] = make_float4(fhC, fop, fr, fg);
+        s_rec[3 * lane + 2] = make_float4(fb, __uint_as_float(fmask), 0.f, 0.f);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float4 n0 = s_rec[0], n1 = s_rec[1], n2 = s_rec[2];
         for (int j = 0; j < m; j++) {
-            const uint32_t smask = readlane_u(fmask, j);
+            const float4 e0 = n0, e1 = n1, e2 = n2;
+            if (j + 1 < m) { n0 = s_rec[3 * (j + 1)]; n1 = s_rec[3 * (j + 1) + 1]; n2 = s_rec[3 * (j + 1) + 2]; }
+            const uint32_t smask = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(e2.y));
             if (smask == 0u) continue;
-            const float gdx = readlane_f(fdx, j), gdy = readlane_f(fdy, j);
-            const float hA = readlane_f(fhA, j), nB = readlane_f(fnB, j), hC = readlane_f(fhC, j);
-            const float op = readlane_f(fop, j);
-            const float colr = readlane_f(fr, j), colg = readlane_f(fg, j), colb = readlane_f(fb, j);
+            const float gdx = e0.x, gdy = e0.y, hA = e0.z, nB = e0.w, hC = e1.x, op = e1.y, colr = e1.z, colg = e1.w, colb = e2.x;
             const uint32_t contributor = (uint32_t)(base + j + 1);
             const float dx = gdx - lx;
             const float pA = (hA * dx) * dx;   // log2(e) * (-1/2 A dx^2)
