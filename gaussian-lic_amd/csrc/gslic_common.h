@@ -210,16 +210,6 @@ __device__ __forceinline__ uint32_t block256_exclusive_prefix(uint32_t thread_su
 }
 __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
-// whole-wave shift right by one lane (lane l receives lane l-1; lane 0 keeps its own value): v_mov_b32 dpp wave_shr:1
-__device__ __forceinline__ float wave_shr1_f(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
-}
-__device__ __forceinline__ uint32_t wave_shr1_u(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
-}
-
 // The Adam update of adam.cu:26-37, one definition for every kernel that applies it (adam.hip and the fused backward):
 // contraction is pinned off so that the two call sites round identically (their results are compared bit for bit).
 __device__ __forceinline__ void adam_scalar(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps)

@@ -3,18 +3,22 @@
 // render_fwd_kernel  replaces renderCUDA<3> (forward.cu:321-481)
 //   ONE WAVE PER 16x16 TILE, four pixels per lane (lane l owns pixels l, l+64, l+128, l+192 of the tile in
 //   thread_rank order, i.e. column l&15, rows (l>>4)+{0,4,8,12}).  The wave fetches 64 list entries at a time
-//   (one 48-byte record per lane, three dwordx4 loads) and broadcasts entry j with v_readlane into SGPRs, so the
-//   inner loop has no LDS traffic, no barrier and no shared memory at all; a checkpoint {T, C} per pixel is
-//   stored at every 64th entry (bucket = one wave of entries) as one coalesced 1-KiB dwordx4 store per quarter.
+//   (one 48-byte record per lane, three dwordx4 loads), pre-scales them, parks them in LDS and fetches entry j with three
+//   ds_read_b128 at a wave-uniform address (LDS broadcast, next entry prefetched): the kernel is VALU-issue bound and LDS reads cost
+//   no issue slot, ten v_readlane per entry did.  A 4-bit mask per entry says which 16x4 pixel strips it can reach at all; a
+//   checkpoint {T, C} per pixel is stored at every 64th entry (bucket = one wave of entries) as one coalesced 1-KiB dwordx4
+//   store per quarter.  One wave per workgroup: no barrier anywhere.
 //
 // render_bwd_kernel  replaces PerGaussianRenderCUDA<3> (backward.cu:379-597)
-//   ONE WAVE PER BUCKET of 64 list entries: lane = Gaussian, the tile's 256 pixels stream through the lanes as a
-//   64-deep systolic pipeline; the evolving per-pixel state {T, ar[3], n_contrib|index} moves lane -> lane+1 with one
-//   v_mov_b32 DPP wave_shr:1 per value (no ds_bpermute), injected through the DPP's bound-lane `old` operand; the per-pixel
-//   constants (dL/dpixel) are parked in LDS per chunk and fetched with one ds_read_b128 per step.  Only pixels whose n_contrib reaches this bucket are injected (a 64-bit ballot per chunk,
-//   walked with s_ff1): pixels that terminated earlier cost no pipeline step at all.  Each lane accumulates its Gaussian's nine 2D gradients in registers and writes them
-//   ONCE to its emission slot (plain 48-byte store): no atomics — the sum over a Gaussian's tiles is a
-//   contiguous segmented reduction in preprocess_bwd_kernel, deterministic run to run.
+//   ONE WAVE PER BUCKET of 64 list entries: lane = Gaussian, the tile's pixels stream through the lanes as a 64-deep systolic
+//   pipeline; the evolving per-pixel state {ar0, ar1, T, ar2} and the pixel's tag move lane -> lane+1 with one in-place
+//   v_mov_b32 DPP wave_shr:1 per value (no ds_bpermute, no copies); lane 0 is then re-loaded with the next pixel by one
+//   ds_read_b128 + ds_read_b32 under a one-lane exec mask.  The per-pixel constants (dL/dpixel) are parked in LDS once per tile
+//   and fetched with one ds_read_b96 when a lane actually blends.  Only pixels whose n_contrib reaches this bucket are injected
+//   (a 64-bit ballot per 64-pixel chunk, walked with s_ff1): pixels that terminated earlier cost no pipeline step at all.  Each
+//   lane accumulates its Gaussian's nine 2D gradients in registers and writes them ONCE to its emission slot (plain 48-byte
+//   store): no atomics — the sum over a Gaussian's tiles is a contiguous segmented reduction in preprocess_bwd_kernel,
+//   deterministic run to run.
 #include "gslic_common.h"
 #include "kernels.h"
 
@@ -177,18 +181,8 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
     }
 }
 
-// Whole-wave shift by one lane with injection: lane l >= 1 receives v[l-1]; lane 0 has no source lane, so with
-// bound_ctrl = 0 it keeps the DPP "old" operand — which we set to the (wave-uniform) value to inject.  2 VALU ops.
-__device__ __forceinline__ float shift_in_f(float inject, float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(inject), __float_as_int(v), 0x138, 0xf, 0xf, false));
-}
-__device__ __forceinline__ uint32_t shift_in_u(uint32_t inject, uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)inject, (int)v, 0x138, 0xf, 0xf, false);
-}
-
-// Drain variant: nothing is injected, lane 0 receives 0 (bound_ctrl), so source and destination may be the same register.
+// Whole-wave shift by one lane: lane l >= 1 receives v[l-1], lane 0 receives 0 (bound_ctrl), so source and destination may be the same
+// register (v_mov_b32 v, v wave_shr:1): one VALU op per value, no copies.
 __device__ __forceinline__ float shift_zero_f(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
