@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference/src/rasterizer/cuda_rasterizer"
 OUT = os.path.join(os.path.dirname(HERE), "_ref")
 SRCS = ["backward.cu", "adam.cu"]            # compiled directly from /root/reference
-WRAPS = ["wrap_forward.hip", "wrap_rasterizer_impl.hip"]  # #include the reference .cu after re-defining WARP_SIZE
+WRAPS = ["wrap_forward.hip", "wrap_rasterizer_impl.hip",  # #include the reference .cu after re-defining WARP_SIZE
+         "wrap_ssim.hip"]  # fused-ssim kernels.  (simple_knn.cu cannot be compiled in place: its `<< <grid, block >> >` launches only parse with nvcc)
 
 
 def main():

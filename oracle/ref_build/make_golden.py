@@ -69,7 +69,32 @@ def main(outdir):
     rk.adam(p1, g, m1, v1, vis, 2.5e-3)
     np.savez_compressed(os.path.join(outdir, "adam_500x45.npz"), p=p, g=g, m=m, v=v, vis=vis, p1=p1, m1=m1, v1=v1, lr=np.float32(2.5e-3))
     print("adam ok")
+    ssim_golden(rk, outdir)
+
+
+SSIM_CASES = [("ssim_1x3x70x50", 1, 3, 50, 70, 21),      # ragged: neither side a multiple of the 32x32 block
+              ("ssim_2x3x96x64", 2, 3, 64, 96, 22)]      # batch of two, block-aligned
+
+
+def ssim_golden(rk, outdir):
+    """fused-SSIM golden vectors from the reference's own kernels (ssim.cu through oracle/ref_build/wrap_ssim.hip)."""
+    for name, B, CH, H, W, seed in SSIM_CASES:
+        rng = np.random.default_rng(seed)
+        img1 = rng.random((B, CH, H, W)).astype(np.float32)
+        img2 = np.clip(img1 + 0.1 * rng.standard_normal((B, CH, H, W)), 0.0, 1.0).astype(np.float32)
+        dL = rng.standard_normal((B, CH, H, W)).astype(np.float32)
+        m, d1, d2, d3 = rk.ssim_forward(img1, img2)
+        g = rk.ssim_backward(img1, img2, dL, d1, d2, d3)
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), img1=img1, img2=img2, dL_dmap=dL, ssim_map=m, dm_dmu1=d1, dm_dsigma1_sq=d2,
+                            dm_dsigma12=d3, dL_dimg1=g)
+        print(name, "mean ssim", float(m.mean()), flush=True)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "golden"))
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "golden")
+    if len(sys.argv) > 2 and sys.argv[2] == "ssim":   # only the fused-SSIM vectors
+        from oracle.ref_build.refkernels import RefKernels
+        os.makedirs(out, exist_ok=True)
+        ssim_golden(RefKernels(), out)
+    else:
+        main(out)

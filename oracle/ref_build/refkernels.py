@@ -76,3 +76,24 @@ class RefKernels:
         rc = self.lib.ref_adam(_p(param), _p(np.ascontiguousarray(grad, np.float32)), _p(m), _p(v), _p(vis), cf(lr), cf(b1), cf(b2), cf(eps),
                                ctypes.c_uint(N), ctypes.c_uint(M))
         assert rc == 0
+
+    def ssim_forward(self, img1, img2, C1=0.01 ** 2, C2=0.03 ** 2):
+        """The reference's fusedssimCUDA (ssim.cu:186-285) with train = true.  img [B,CH,H,W] -> (map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12)."""
+        a, b = np.ascontiguousarray(img1, np.float32), np.ascontiguousarray(img2, np.float32)
+        B, CH, H, W = a.shape
+        outs = [np.zeros_like(a) for _ in range(4)]
+        cf = ctypes.c_float
+        rc = self.lib.ref_ssim_forward(B, CH, H, W, cf(C1), cf(C2), _p(a), _p(b), *[_p(o) for o in outs])
+        assert rc == 0
+        return tuple(outs)
+
+    def ssim_backward(self, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, C1=0.01 ** 2, C2=0.03 ** 2):
+        """The reference's fusedssim_backwardCUDA (ssim.cu:287-365) -> dL_dimg1."""
+        arrs = [np.ascontiguousarray(x, np.float32) for x in (img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12)]
+        B, CH, H, W = arrs[0].shape
+        out = np.zeros_like(arrs[0])
+        cf = ctypes.c_float
+        rc = self.lib.ref_ssim_backward(B, CH, H, W, cf(C1), cf(C2), *[_p(x) for x in arrs], _p(out))
+        assert rc == 0
+        return out
+
