@@ -46,7 +46,7 @@ struct ShOut {  // what phase B needs to write a Gaussian's dL_dsh row
 };
 
 template <bool LDS_SH>
-__device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so, float* lds_g, int bs);
+__device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so, float* sg);
 
 // Cooperative sink of the 14 small gradients per Gaussian of one block (see lds_g in the kernel): coalesced float4 stores into the
 // gradient tensors that were asked for (gout, group order of lds_g) and / or the in-place Adam update.  Group g of width w: the
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
     __shared__ uint8_t lds_vis[BS];
     // the 14 small-group gradients of every Gaussian of the block, group-major (xyz | dc | opacity | scale | rotation), for the
     // cooperative float4 Adam below: per-thread 4-byte accesses at stride 12 / 16 B cost this kernel 0.29 ms of 0.86
-    __shared__ __attribute__((aligned(16))) float lds_g[LDS_SH ? 14 * BS : 4];
+    float* const lds_g = lds_sh;  // overlays the head of lds_sh between "SH rows consumed" and "dL_dsh rows written" (LDS per wave 15.2 -> 11.6 KB)
     const int idx = blockIdx.x * BS + threadIdx.x;
     const int M = a.M;
     lds_vis[threadIdx.x] = (idx < a.P && a.radii[idx] > 0) ? 1 : 0;
@@ -140,14 +140,27 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
     so.x = so.y = so.z = so.dR = so.dG = so.dB = 0.f;
     so.on = false;
     const float* sh_row = LDS_SH ? (lds_sh + threadIdx.x * 45) : (a.shs ? a.shs + (size_t)3 * M * idx : nullptr);
-    if (idx < a.P) bwd_phase_a<LDS_SH>(a, idx, M, sh_row, so, LDS_SH ? lds_g : nullptr, BS);
-    if constexpr (LDS_SH) __syncthreads();  // every SH row has been consumed: the buffer now takes the dL_dsh rows
+    float sg[14];
+#pragma unroll
+    for (int k = 0; k < 14; k++) sg[k] = 0.f;
+    if (idx < a.P) bwd_phase_a<LDS_SH>(a, idx, M, sh_row, so, LDS_SH ? sg : nullptr);
+    if constexpr (LDS_SH) {
+        __syncthreads();  // every SH row has been consumed: the buffer first takes the 14 small gradients per Gaussian, group-major
+        const int t = threadIdx.x;
+        lds_g[3 * t] = sg[0]; lds_g[3 * t + 1] = sg[1]; lds_g[3 * t + 2] = sg[2];
+        lds_g[3 * BS + 3 * t] = sg[3]; lds_g[3 * BS + 3 * t + 1] = sg[4]; lds_g[3 * BS + 3 * t + 2] = sg[5];
+        lds_g[6 * BS + t] = sg[6];
+        lds_g[7 * BS + 3 * t] = sg[7]; lds_g[7 * BS + 3 * t + 1] = sg[8]; lds_g[7 * BS + 3 * t + 2] = sg[9];
+        reinterpret_cast<float4*>(lds_g + 10 * BS)[t] = make_float4(sg[10], sg[11], sg[12], sg[13]);
+        __syncthreads();
+    }
 
     // ---- small groups: the block's rows of xyz / dc / opacity / scale / rotation are contiguous in memory, so the Adam update runs
     // on float4 columns of those five regions (at most one float4 per thread and group, all fifteen loads issued before the math)
     if constexpr (LDS_SH) {
         float* const gout[5] = {a.dL_dmean3D, a.dL_ddc, a.dL_dopacity, a.dL_dscale, a.dL_drot};
         small_groups_sink<BS>(a.adam, gout, lds_g, lds_vis, row0, rows);
+        __syncthreads();  // ... and then the dL_dsh rows
     }
     // ---- phase B: this Gaussian's dL_dsh row (zeros when invisible, when shs == NULL, and above the active degree)
     if constexpr (LDS_SH) {
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
 }
 
 template <bool LDS_SH>
-__device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so, float* lds_g, int bs)
+__device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so, float* sg)
 {
     const bool visible = a.radii[idx] > 0;
 
@@ -240,13 +253,7 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
         if (a.dL_dcolor) { a.dL_dcolor[3 * idx] = 0; a.dL_dcolor[3 * idx + 1] = 0; a.dL_dcolor[3 * idx + 2] = 0; }
         if (a.dL_dcov3D)
             for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * idx + k] = 0;
-        if (lds_g) {  // the five parameter-gradient rows leave through the block's staged float4 stores
-            const int t = threadIdx.x;
-            for (int k = 0; k < 3; k++) { lds_g[3 * t + k] = 0.f; lds_g[3 * bs + 3 * t + k] = 0.f; lds_g[7 * bs + 3 * t + k] = 0.f; }
-            lds_g[6 * bs + t] = 0.f;
-            reinterpret_cast<float4*>(lds_g + 10 * bs)[t] = make_float4(0, 0, 0, 0);
-            return;
-        }
+        if (sg) return;  // the five parameter-gradient rows leave through the block's staged float4 stores (sg[] is pre-zeroed)
         if (a.dL_dopacity) a.dL_dopacity[idx] = 0;
         if (a.dL_dmean3D) { a.dL_dmean3D[3 * idx] = 0; a.dL_dmean3D[3 * idx + 1] = 0; a.dL_dmean3D[3 * idx + 2] = 0; }
         if (a.dL_ddc) { a.dL_ddc[3 * idx] = 0; a.dL_ddc[3 * idx + 1] = 0; a.dL_ddc[3 * idx + 2] = 0; }
@@ -493,18 +500,12 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
         dq = dr;
     }
     // ---- sinks: gradient tensors (each optional) and / or the in-place Adam update of this Gaussian's 14 small scalars
-    if (lds_g) {  // staged: the block stores / updates these rows with float4 columns (small_groups_sink)
-        const int t = threadIdx.x;
-        float* g = lds_g;
-        g[3 * t] = dmean[0]; g[3 * t + 1] = dmean[1]; g[3 * t + 2] = dmean[2];
-        g += 3 * bs;
-        g[3 * t] = ddc[0]; g[3 * t + 1] = ddc[1]; g[3 * t + 2] = ddc[2];
-        g += 3 * bs;
-        g[t] = g_op;
-        g += bs;
-        g[3 * t] = dscale[0]; g[3 * t + 1] = dscale[1]; g[3 * t + 2] = dscale[2];
-        g += 3 * bs;
-        reinterpret_cast<float4*>(g)[t] = dq;
+    if (sg) {  // staged: the block stores / updates these rows with float4 columns (small_groups_sink)
+        sg[0] = dmean[0]; sg[1] = dmean[1]; sg[2] = dmean[2];
+        sg[3] = ddc[0]; sg[4] = ddc[1]; sg[5] = ddc[2];
+        sg[6] = g_op;
+        sg[7] = dscale[0]; sg[8] = dscale[1]; sg[9] = dscale[2];
+        sg[10] = dq.x; sg[11] = dq.y; sg[12] = dq.z; sg[13] = dq.w;
         return;
     }
     if (a.dL_dopacity) a.dL_dopacity[idx] = g_op;
