@@ -83,8 +83,9 @@ typedef struct gslic_raster_params {
  *  num_buckets     host int: B = number of checkpoint buckets (0 if no_color) } returns (rasterizer_impl.cu:473)
  *
  * Allocator call order geom(P) -> img(N,T) -> binning(R) -> sample(B); sample is called only when
- * !no_color (rasterizer_impl.cu:355,359,401,437-447).  The function synchronises `stream` twice (to learn
- * R and B on the host), exactly where the reference blocks (rasterizer_impl.cu:398,442).
+ * !no_color (rasterizer_impl.cu:355,359,401,437-447).  The host waits for the device twice (to learn R and
+ * B), exactly where the reference blocks (rasterizer_impl.cu:398,442); the wait is a spin on a pinned-memory
+ * mailbox a one-thread kernel writes (GSLIC_NO_MAILBOX=1: hipMemcpyAsync + hipStreamSynchronize instead).
  * P == 0 returns immediately with R = B = 0 and calls no allocator (rasterize_points.cu:110).
  */
 int gslic_rasterize_forward(
