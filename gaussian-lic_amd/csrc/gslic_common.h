@@ -270,7 +270,16 @@ __device__ __forceinline__ void get_rect(float px, float py, int radius, int gx,
 __device__ __forceinline__ float saturate_f(float v) { return (v > 0.0f) ? ((v < 1.0f) ? v : 1.0f) : 0.0f; }
 
 // forward.h:39-78: min over the tile's pixel-centre rectangle of 1/2 d^T Q d; co = (A, B, C) conic.
-__device__ __forceinline__ float tile_min_power(float cA, float cB, float cC, float mx, float my, int tx, int ty)
+// The rectangle's edge lengths are GS_TILE - 1 = 15 for every tile (rmax - rmin of exactly representable integers), so the two
+// correctly-rounded divisions 1 / (s * s * A), 1 / (s * s * C) of the reference formula depend on the Gaussian alone: callers that
+// test many tiles of one Gaussian compute them once (tile_power_prep) — same values bit for bit, 20 VALU instructions less per tile.
+__device__ __forceinline__ void tile_power_prep(float cA, float cC, float& rcpx, float& rcpy)
+{
+    const float s = (float)(GS_TILE - 1);
+    rcpx = 1.0f / (s * s * cA);
+    rcpy = 1.0f / (s * s * cC);
+}
+__device__ __forceinline__ float tile_min_power_p(float cA, float cB, float cC, float mx, float my, float rcpx, float rcpy, int tx, int ty)
 {
     const float rminx = (float)(tx * GS_TILE), rminy = (float)(ty * GS_TILE);
     const float rmaxx = (float)((tx + 1) * GS_TILE - 1), rmaxy = (float)((ty + 1) * GS_TILE - 1);
@@ -281,20 +290,24 @@ __device__ __forceinline__ float tile_min_power(float cA, float cB, float cC, fl
     const float y_above = (y_min_diff > 0.0f) ? 1.0f : 0.0f;
     const float not_in_y = y_above + ((my > rmaxy) ? 1.0f : 0.0f);
     if (!((not_in_y + not_in_x) > 0.0f)) return 0.0f;
-    const float sx = rmaxx - rminx, sy = rmaxy - rminy;
+    const float sx = rmaxx - rminx, sy = rmaxy - rminy;  // = GS_TILE - 1
     const float px = x_left * rminx + (1.0f - x_left) * rmaxx;
     const float py = y_above * rminy + (1.0f - y_above) * rmaxy;
     const float dx = copysignf(sx, x_min_diff);
     const float dy = copysignf(sy, y_min_diff);
     const float diffx = mx - px;
     const float diffy = my - py;
-    const float rcpx = 1.0f / (sx * sx * cA);
-    const float rcpy = 1.0f / (sy * sy * cC);
     const float tx_ = not_in_y * saturate_f((dx * cA * diffx + dx * cB * diffy) * rcpx);
     const float ty_ = not_in_x * saturate_f((dy * cB * diffx + dy * cC * diffy) * rcpy);
     const float qx = px + tx_ * dx, qy = py + ty_ * dy;
     const float ex = mx - qx, ey = my - qy;
     return 0.5f * (cA * ex * ex + cC * ey * ey) + cB * ex * ey;
+}
+__device__ __forceinline__ float tile_min_power(float cA, float cB, float cC, float mx, float my, int tx, int ty)
+{
+    float rcpx, rcpy;
+    tile_power_prep(cA, cC, rcpx, rcpy);
+    return tile_min_power_p(cA, cB, cC, mx, my, rcpx, rcpy, tx, ty);
 }
 
 }  // namespace gslic

@@ -158,11 +158,13 @@ __global__ __launch_bounds__(BS) void preprocess_kernel(PreprocessArgs a)
     const int rw = x1 - x0;
     const int ntiles = active ? rw * (y1 - y0) : 0;
     uint32_t cnt = 0;
+    float rcpx = 0.f, rcpy = 0.f;
+    if (active) tile_power_prep(cA, cC, rcpx, rcpy);
     {
         int tx = x0, ty = y0;
         const int nseq = ntiles < SEQ_TILES ? ntiles : SEQ_TILES;
         for (int t = 0; t < nseq; t++) {
-            cnt += (tile_min_power(cA, cB, cC, mx, my, tx, ty) <= thr) ? 1u : 0u;
+            cnt += (tile_min_power_p(cA, cB, cC, mx, my, rcpx, rcpy, tx, ty) <= thr) ? 1u : 0u;
             if (++tx == x1) { tx = x0; ++ty; }
         }
     }
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(BS) void preprocess_kernel(PreprocessArgs a)
         todo &= todo - 1;
         const float sA = readlane_f(cA, src), sB = readlane_f(cB, src), sC = readlane_f(cC, src);
         const float smx = readlane_f(mx, src), smy = readlane_f(my, src), sthr = readlane_f(thr, src);
+        const float srx = readlane_f(rcpx, src), sry = readlane_f(rcpy, src);
         const int sx0 = __builtin_amdgcn_readlane(x0, src), sy0 = __builtin_amdgcn_readlane(y0, src);
         const int srw = __builtin_amdgcn_readlane(rw, src), sn = __builtin_amdgcn_readlane(ntiles, src);
         uint32_t c = 0;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(BS) void preprocess_kernel(PreprocessArgs a)
             const int t = base + lane;
             const bool in = t < sn;
             const int ty = sy0 + t / srw, tx = sx0 + t % srw;
-            const bool ok = in && (tile_min_power(sA, sB, sC, smx, smy, tx, ty) <= sthr);
+            const bool ok = in && (tile_min_power_p(sA, sB, sC, smx, smy, srx, sry, tx, ty) <= sthr);
             c += (uint32_t)__popcll(__ballot(ok));
         }
         if (lane == src) cnt += c;
@@ -284,11 +287,13 @@ __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
     }
     const int rw = x1 - x0;
     const int ntiles = active ? rw * (y1 - y0) : 0;
+    float rcpx = 0.f, rcpy = 0.f;
+    if (active) tile_power_prep(cA, cC, rcpx, rcpy);
     {
         int tx = x0, ty = y0;
         const int nseq = ntiles < SEQ_TILES ? ntiles : SEQ_TILES;
         for (int t = 0; t < nseq; t++) {
-            if (tile_min_power(cA, cB, cC, mx, my, tx, ty) <= thr) {
+            if (tile_min_power_p(cA, cB, cC, mx, my, rcpx, rcpy, tx, ty) <= thr) {
                 const uint32_t key = (uint32_t)(ty * a.gx + tx);
                 if (staged) { st[off - wbase] = key; sg[off - wbase] = (uint32_t)idx; }
                 else { a.tile_keys[off] = key; a.gauss[off] = (uint32_t)idx; }
@@ -303,6 +308,7 @@ __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
         todo &= todo - 1;
         const float sA = readlane_f(cA, src), sB = readlane_f(cB, src), sC = readlane_f(cC, src);
         const float smx = readlane_f(mx, src), smy = readlane_f(my, src), sthr = readlane_f(thr, src);
+        const float srx = readlane_f(rcpx, src), sry = readlane_f(rcpy, src);
         const int sx0 = __builtin_amdgcn_readlane(x0, src), sy0 = __builtin_amdgcn_readlane(y0, src);
         const int srw = __builtin_amdgcn_readlane(rw, src), sn = __builtin_amdgcn_readlane(ntiles, src);
         const uint32_t sidx = (uint32_t)__builtin_amdgcn_readlane(idx, src);
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
             const int t = base + lane;
             const bool in = t < sn;
             const int ty = sy0 + t / srw, tx = sx0 + t % srw;
-            const bool ok = in && (tile_min_power(sA, sB, sC, smx, smy, tx, ty) <= sthr);
+            const bool ok = in && (tile_min_power_p(sA, sB, sC, smx, smy, srx, sry, tx, ty) <= sthr);
             const uint64_t m = __ballot(ok);
             if (ok) {
                 const uint32_t o = soff + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
