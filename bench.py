@@ -251,7 +251,7 @@ def main():
         # so this is an upper bound of the pairs actually evaluated (no FLOP claim is derived from it)
         slots = 256.0 * 64.0 * stats["B"]
         roofline["valu"] = dict(pair_slots_per_launch=slots, gslots_per_s=round(slots / (avg_ms * 1e-3) / 1e9, 2) if avg_ms > 0 else 0,
-                                note="VALU-issue bound (profiles/r01g_sq_counters.txt); HBM frac above is not the limiter")
+                                note="VALU-issue bound (profiles/r01h_sq_counters.txt); HBM frac above is not the limiter")
 
     # ---- CPU baseline: the oracle (C port of the reference kernels, OpenMP) on a 1/16-scale sample of the same workload
     cpu = None
