@@ -128,9 +128,23 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
     if constexpr (LDS_SH) {
         const float* src = a.shs + (size_t)row0 * 45;
         if (rows == BS) {
-            const float4* s4 = reinterpret_cast<const float4*>(src);
-            float4* d4 = reinterpret_cast<float4*>(lds_sh);
-            for (int i = threadIdx.x; i < BS * 45 / 4; i += BS) d4[i] = s4[i];
+            // all of a thread's loads are issued before the first LDS store: the rolled loop was load -> wait -> store twelve times,
+            // i.e. twelve dependent memory round trips at the head of every wave
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            constexpr int NT = (BS * 45 / 4 + BS - 1) / BS;
+            const v4f* s4 = reinterpret_cast<const v4f*>(src);
+            v4f* d4 = reinterpret_cast<v4f*>(lds_sh);
+            v4f pre[NT];
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                const int i = threadIdx.x + k * BS;
+                pre[k] = (i < BS * 45 / 4) ? s4[i] : (v4f){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                const int i = threadIdx.x + k * BS;
+                if (i < BS * 45 / 4) d4[i] = pre[k];
+            }
         } else {
             for (int i = threadIdx.x; i < rows * 45; i += BS) lds_sh[i] = src[i];
         }
