@@ -233,12 +233,14 @@ def main():
     abytes = algorithmic_bytes("preprocess_bwd+adam" if (dominant == "preprocess_bwd" and fused_adam) else dominant, stats)
     achieved = abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
+    pmc_workload_ok = False
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
             key = f"{dominant}_kernel"
-            if pmc.get("workload") == f"{args.scene}-{P}-{W}x{H}" and key in pmc.get("kernels", {}):
+            pmc_workload_ok = pmc.get("workload") == f"{args.scene}-{P}-{W}x{H}"
+            if pmc_workload_ok and key in pmc.get("kernels", {}):
                 traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -251,7 +253,22 @@ def main():
         # so this is an upper bound of the pairs actually evaluated (no FLOP claim is derived from it)
         slots = 256.0 * 64.0 * stats["B"]
         roofline["valu"] = dict(pair_slots_per_launch=slots, gslots_per_s=round(slots / (avg_ms * 1e-3) / 1e9, 2) if avg_ms > 0 else 0,
-                                note="VALU-issue bound (profiles/r01h_sq_counters.txt); HBM frac above is not the limiter")
+                                note="VALU-issue bound (profiles/*_sq_counters.txt); HBM frac above is not the limiter")
+        # issue-slot utilisation from the committed SQ counters of the same workload: VALU instructions per launch x the measured
+        # 4.1 cycles per wave64 instruction (tools/ubench/valu_rate, the fastest kind) / (1024 SIMDs x launch duration x 2.4 GHz)
+        try:
+            import ast
+            import glob
+            sq_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.txt")))   # the newest tag sorts last
+            for line in (open(sq_files[-1]) if sq_files else []):
+                name, _, rest = line.partition(" ")
+                if name == f"{dominant}_kernel" and pmc_workload_ok:
+                    c = ast.literal_eval(rest.strip())
+                    insts = c["SQ_INSTS_VALU"] * 32.0   # the extract averages per shader engine; 32 engines
+                    roofline["valu"].update(valu_insts_per_launch=insts,
+                                            issue_frac=round(insts * 4.1 / (1024.0 * c["dur_us"] * 1e-6 * 2.4e9), 3))
+        except Exception:
+            pass
 
     # ---- CPU baseline: the oracle (C port of the reference kernels, OpenMP) on a 1/16-scale sample of the same workload
     cpu = None
