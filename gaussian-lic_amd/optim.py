@@ -50,10 +50,13 @@ class SparseGaussianAdam:
             self.state[i] = dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
         return self.state[i]
 
-    def step(self, grads=None):
-        """grads: optional list of gradient tensors (defaults to each param's .grad)."""
+    def step(self, grads=None, only=None):
+        """grads: optional list of gradient tensors (defaults to each param's .grad); only: optional subset of group indices
+        (the pipelined N > 1 exchange updates a group as soon as its gradients have been reduced)."""
         groups, keep = [], []
         for i, prm in enumerate(self.params):
+            if only is not None and i not in only:
+                continue
             g = grads[i] if grads is not None else prm.grad
             if g is None:
                 continue

@@ -154,6 +154,15 @@ class GradSlab:
     def grads(self, model):
         return [self.views[n] for n in model.NAMES]
 
+    def segments(self, model):
+        """The slab as three contiguous runs of whole groups, largest first: features_rest (76 % of the bytes), then
+        xyz + features_dc, then opacity + scaling + rotation.  Returns [(flat slice, group indices)]."""
+        sizes = [self.views[n].numel() for n in model.NAMES]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
+        return [(self.flat[offs[2]:offs[3]], [2]), (self.flat[offs[0]:offs[2]], [0, 1]), (self.flat[offs[3]:offs[6]], [3, 4, 5])]
+
 
 def allreduce_slab(slab, visible):
     """The per-step exchange on a GradSlab: SUM all-reduce of the slab in place + MAX (= OR) of the visibility bytes."""
@@ -161,6 +170,17 @@ def allreduce_slab(slab, visible):
     torch.distributed.all_reduce(slab.flat, op=torch.distributed.ReduceOp.SUM)
     torch.distributed.all_reduce(vis, op=torch.distributed.ReduceOp.MAX)
     return vis.bool()
+
+
+def allreduce_slab_async(slab, visible, model):
+    """The same exchange, pipelined against the optimiser: the visibility mask first (2 MB, blocking), then the three segments of
+    the slab as asynchronous SUM all-reduces issued back to back.  Returns (reduced visibility, [(work, group indices)]): the
+    caller waits for a segment and runs Adam on ITS groups while the following segments are still on the links, so all but the
+    last, small Adam launch hide under the transfer (at 2M Gaussians the transfer is the longer leg of an N > 1 step)."""
+    vis = visible.to(torch.uint8)
+    torch.distributed.all_reduce(vis, op=torch.distributed.ReduceOp.MAX)
+    works = [(torch.distributed.all_reduce(seg, op=torch.distributed.ReduceOp.SUM, async_op=True), idx) for seg, idx in slab.segments(model)]
+    return vis.bool(), works
 
 
 def allreduce_gradients(grads, visible):
@@ -235,9 +255,15 @@ def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=Tr
         visible = radii > 0
         if do_step:
             if _dist_on():
-                visible = allreduce_slab(slab, visible)
-            model.optimizer.set_visibility_and_N(visible, model.P)
-            model.optimizer.step(slab.grads(model))       # group order of gaussian.cpp:399-418
+                visible, works = allreduce_slab_async(slab, visible, model)
+                model.optimizer.set_visibility_and_N(visible, model.P)
+                grads = slab.grads(model)
+                for work, idx in works:       # Adam on a segment's groups as soon as ITS all-reduce is done
+                    work.wait()
+                    model.optimizer.step(grads, only=idx)
+            else:
+                model.optimizer.set_visibility_and_N(visible, model.P)
+                model.optimizer.step(slab.grads(model))       # group order of gaussian.cpp:399-418
     return terms, visible
 
 

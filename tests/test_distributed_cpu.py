@@ -44,6 +44,17 @@ def _worker(rank, world, port, q):
     for a, b in zip(slab.grads(_M()), red):
         assert torch.equal(a, b)
     assert torch.equal(svis, rvis)
+    # the pipelined variant of the fused step: three asynchronous segment all-reduces, consumed in order
+    for v, x in zip(slab.grads(_M()), grads):
+        v.copy_(x)
+    pvis, works = trainer.allreduce_slab_async(slab, vis, _M())
+    seen = []
+    for work, idx in works:
+        work.wait()
+        seen += idx
+        for i in idx:
+            assert torch.equal(slab.grads(_M())[i], red[i])
+    assert sorted(seen) == [0, 1, 2, 3, 4, 5] and torch.equal(pvis, rvis)
     q.put((rank, [r.clone().numpy() for r in red], rvis.numpy(), [x.numpy() for x in grads], vis.numpy()))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
