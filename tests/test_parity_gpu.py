@@ -209,3 +209,39 @@ def test_non_default_stream_and_debug_flag(oracle32):
     assert f["R"] == base["R"] and torch.equal(f["color"], base["color"]) and torch.equal(f["final_T"], base["final_T"])
     for k in g:
         np.testing.assert_array_equal(g[k], gbase[k])
+
+
+def test_error_conventions_on_device():
+    """SURVEY.md 8b error conventions through the C-ABI: `prefiltered` with a culled point is an error (the reference __trap()s,
+    auxiliary.h:162-166), a NULL allocator result is GSLIC_ERR_ALLOC, colors_precomp is refused; every failure carries a message in gslic_last_error() and leaves the process usable."""
+    import ctypes
+    from gaussian_lic_amd import _lib
+    from gaussian_lic_amd import rasterizer as rz
+    from gpu_helpers import hip_forward, settings_from
+    from gaussian_lic_amd.synthetic import activate
+    raw, sc, camd, cam = make_scene("random", 2000, 96, 64, 3, 91)   # contains points behind the near plane
+    dev = torch.device("cuda:0")
+    act = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in activate(raw).items()}
+    rs = settings_from(cam, 3, dev)
+    e = torch.empty(0, device=dev)
+    args = lambda pref, colors: (rs.bg, act["means"], colors, act["opac"], act["scales"], act["rots"], 1.0, e, rs.viewmatrix, rs.projmatrix,
+                                 rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, rs.limx_neg, rs.limx_pos, rs.limy_neg, rs.limy_pos,
+                                 act["dc"], act["shs"], 3, rs.campos, pref, False, False)
+    with pytest.raises(_lib.GslicError, match="prefiltered"):
+        rz.rasterize_gaussians(*args(True, e))
+    with pytest.raises(_lib.GslicError, match="colors_precomp"):
+        rz.rasterize_gaussians(*args(False, torch.zeros(2000, 3, device=dev)))
+    # allocator failure: geom callback returns NULL
+    L = _lib.lib()
+    prm = _lib.RasterParams(2000, 3, 15, 96, 64, rs.tanfovx, rs.tanfovy, rs.limx_neg, rs.limx_pos, rs.limy_neg, rs.limy_pos, 1.0, 0, 0, 0, 0)
+    null_cb = _lib.ALLOC_FN(lambda c, n: 0)
+    out_c, out_t, radii = torch.zeros(3, 64, 96, device=dev), torch.zeros(64, 96, device=dev), torch.zeros(2000, dtype=torch.int32, device=dev)
+    R, B = ctypes.c_int32(0), ctypes.c_int32(0)
+    p = _lib.ptr
+    rc = L.gslic_rasterize_forward(ctypes.byref(prm), null_cb, None, null_cb, None, null_cb, None, null_cb, None, p(rs.bg), p(act["means"]),
+                                   p(act["dc"]), p(act["shs"]), None, p(act["opac"]), p(act["scales"]), p(act["rots"]), None, p(rs.viewmatrix),
+                                   p(rs.projmatrix), p(rs.campos), p(out_c), p(out_t), p(radii), ctypes.byref(R), ctypes.byref(B), None)
+    assert rc == -3 and b"allocator" in L.gslic_last_error()
+    # and the library still works afterwards
+    ok = hip_forward(raw, cam)
+    assert ok["R"] > 0
