@@ -76,3 +76,71 @@ def test_bench_under_torchrun_one_rank():
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
+
+
+TWO_RANK_SNIPPET = r"""
+import os, sys, hashlib, torch
+sys.path.insert(0, {root!r})
+import gaussian_lic_amd
+from gaussian_lic_amd import trainer
+from gaussian_lic_amd.camera import synthetic_camera
+from gaussian_lic_amd.synthetic import random_scene, gt_image
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+W, H, P, STEPS = 320, 192, 30000, 3
+def digest(model):
+    h = hashlib.sha256()
+    for t in (model.xyz, model.features_dc, model.features_rest, model.opacity, model.scaling, model.rotation):
+        h.update(t.detach().cpu().numpy().tobytes())
+    return h.hexdigest()
+bg = torch.zeros(3, device=dev)
+if world > 1:
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU of the box
+    model = trainer.GaussianModel(random_scene(P, W, H, 3, 5), dev); model.training_setup()
+    cam = synthetic_camera(W, H, rank).to_device(dev); gt = gt_image(H, W, seed=2 + rank).to(dev)
+    for _ in range(STEPS):
+        trainer.training_step_fused(model, cam, gt, bg)
+    torch.cuda.synchronize()
+    print("DIGEST", rank, digest(model))
+    torch.distributed.barrier(); torch.distributed.destroy_process_group()
+else:
+    # single-process restatement of the same two-view step: gradients of view 0 and view 1 summed, masks OR-ed, one masked Adam
+    model = trainer.GaussianModel(random_scene(P, W, H, 3, 5), dev); model.training_setup()
+    cams = [synthetic_camera(W, H, k).to_device(dev) for k in range(2)]
+    gts = [gt_image(H, W, seed=2 + k).to(dev) for k in range(2)]
+    for _ in range(STEPS):
+        flats, vis = [], []
+        for k in range(2):
+            _, v = trainer.training_step_fused(model, cams[k], gts[k], bg, do_step=False, adam_in_backward=False)
+            flats.append(model._grad_slab.flat.clone()); vis.append(v.clone())
+        model._grad_slab.flat.copy_(flats[0] + flats[1])
+        model.optimizer.set_visibility_and_N(vis[0] | vis[1], model.P)
+        model.optimizer.step(model._grad_slab.grads(model))
+    torch.cuda.synchronize()
+    print("DIGEST", 0, digest(model))
+"""
+
+
+@pytest.mark.gpu
+def test_two_ranks_sharing_one_gpu_match_the_summed_gradient_step():
+    """The complete N = 2 step on real kernels: two processes (gloo backend on device tensors, both on the box's one GPU), rank k
+    renders view k, pipelined slab exchange, masked Adam.  Both replicas must end bit-identical to each other and to a
+    single-process restatement (gradients of the two views summed, masks OR-ed, one Adam)."""
+    port = "29561"
+    def run(rank, world):
+        env = dict(os.environ)
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("GSLIC_FORCE_DIST", None)
+        return subprocess.Popen([sys.executable, "-c", TWO_RANK_SNIPPET.format(root=ROOT)], env=env, stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True)
+    procs = [run(0, 2), run(1, 2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    d = [[l for l in so.splitlines() if l.startswith("DIGEST")][-1].split()[2] for so, _ in outs]
+    assert d[0] == d[1]
+    ref = run(0, 1)
+    so, se = ref.communicate(timeout=600)
+    assert ref.returncode == 0, se[-2000:]
+    dref = [l for l in so.splitlines() if l.startswith("DIGEST")][-1].split()[2]
+    assert d[0] == dref
