@@ -130,7 +130,7 @@ int radix_sort_u32(const SortBuffers& b, const SortPlan& plan, void* scratch, bo
 
 // opaque scratch layouts ----------------------------------------------------------------------------------
 struct GeomState {
-    float4* rec;             // [3P] per Gaussian: {mx,my,conic.x,conic.y} {conic.z,opacity,r,g} {b,depth,clamped-bits,0}
+    float4* rec;             // [3P] per Gaussian: {mx,my,conic.x,conic.y} {conic.z,opacity,r,g} {b,depth,clamped-bits,radius}
     uint32_t* tiles_touched; // [P]
     uint32_t* depth_keys[2]; // [P] ping-pong: depth bits (0xffffffff when culled)
     uint32_t* order[2];      // [P] ping-pong: Gaussian ids; after the depth sort order[0] = ids by ascending (depth, id)
