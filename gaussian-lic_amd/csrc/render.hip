@@ -198,7 +198,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // lane -> lane+1 with one DPP each; the injected values enter through the DPP's `old` operand (lane 0 has no source lane).
 // The per-pixel CONSTANTS (dL/dpixel) do not travel: the wave parks every 64-pixel chunk in LDS once (coalesced
 // ds_write_b128) and a lane fetches its current pixel's record with one ds_read_b128.  VALU is the bound of this kernel
-// (profiles/r01h_sq_counters.txt), so every value taken off the conveyor is three VALU ops saved per step, and the
+// (profiles/r01i_sq_counters.txt), so every value taken off the conveyor is three VALU ops saved per step, and the
 // gradient arithmetic is written on float2 pairs: gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 at the rate of the scalar forms
 // (the fp32 peak of the part assumes them), with op_sel covering the splats and the one swizzle for free.  Each component
 // still sees exactly the scalar operation sequence, so the results do not change.
