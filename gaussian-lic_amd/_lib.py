@@ -34,7 +34,7 @@ class AdamFused(ctypes.Structure):
 
 
 EXPORTS = [
-    "gslic_rasterize_forward", "gslic_rasterize_backward", "gslic_rasterize_backward_adam", "gslic_adam_update", "gslic_adam_update_groups",
+    "gslic_rasterize_forward", "gslic_rasterize_backward", "gslic_rasterize_backward_adam", "gslic_rasterize_backward_camera", "gslic_adam_update", "gslic_adam_update_groups",
     "gslic_fusedssim_forward", "gslic_fusedssim_backward", "gslic_knn_mean_dist2", "gslic_abi_version",
     "gslic_last_error", "gslic_geom_bytes", "gslic_img_bytes", "gslic_binning_bytes", "gslic_sample_bytes",
     "gslic_profile_enable", "gslic_profile_reset", "gslic_profile_collect", "gslic_profile_num_kernels",
@@ -76,6 +76,8 @@ def lib():
         [ctypes.POINTER(RasterParams), i32, i32] + [vp] * 12 + [vp] * 4 + [vp] + [vp] * 10 + [f32, vp])
     L.gslic_rasterize_backward_adam.argtypes = (
         [ctypes.POINTER(RasterParams), i32, i32] + [vp] * 12 + [vp] * 4 + [vp] + [vp] * 6 + [f32, ctypes.POINTER(AdamFused), vp])
+    L.gslic_rasterize_backward_camera.argtypes = (
+        [ctypes.POINTER(RasterParams), i32, i32] + [vp] * 12 + [vp] * 4 + [vp] + [vp] * 10 + [f32, vp, vp, vp, vp])
     L.gslic_adam_update.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, u32, u32, vp]
     L.gslic_adam_update_groups.argtypes = [ctypes.POINTER(AdamGroup), i32, vp, f32, f32, f32, u32, vp]
     L.gslic_fusedssim_forward.argtypes = [i32, i32, i32, i32, f32, f32] + [vp] * 6 + [vp]

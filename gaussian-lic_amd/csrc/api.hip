@@ -367,7 +367,7 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
                              const float* cam_pos, const int32_t* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
                              char* sample_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                              float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_ddc, float* dL_dsh, float* dL_dscale,
-                             float* dL_drot, float lambda_erank, const gslic_adam_fused* adam, void* stream)
+                             float* dL_drot, float lambda_erank, const gslic_adam_fused* adam, float* const dL_dcam[3], void* stream)
 {
     (void)background; (void)dc;
     GS_TRY(check_params(prm));
@@ -423,7 +423,19 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
         for (int g = 0; g < 6; g++) { pb.adam.p[g] = adam->param[g]; pb.adam.m[g] = adam->exp_avg[g]; pb.adam.v[g] = adam->exp_avg_sq[g]; pb.adam.lr[g] = adam->lr[g]; }
         pb.adam.b1 = adam->b1; pb.adam.b2 = adam->b2; pb.adam.eps = adam->eps; pb.adam.on = 1;
     }
+    pb.cam_partials = nullptr; pb.cam_out = nullptr;
+    if (dL_dcam) {
+        // scratch: the depth-sort ping-pong arrays of the geometry buffer are dead after the forward; their first slot takes the per-wave
+        // partial rows (128 B per 64 Gaussians <= 4 B per Gaussian), the second the 35 reduced terms
+        pb.cam_partials = reinterpret_cast<float*>(geom.depth_keys[0]);
+        pb.cam_out = reinterpret_cast<float*>(geom.depth_keys[1]);
+    }
     GS_TRY(launch_preprocess_bwd(pb, s));
+    if (dL_dcam) {
+        GS_HIP(hipMemcpyAsync(dL_dcam[0], pb.cam_out, 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        GS_HIP(hipMemcpyAsync(dL_dcam[1], pb.cam_out + 16, 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        GS_HIP(hipMemcpyAsync(dL_dcam[2], pb.cam_out + 32, 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
     DEBUG_SYNC(prm, s);
     return GSLIC_OK;
 }
@@ -439,7 +451,7 @@ int gslic_rasterize_backward(const gslic_raster_params* prm, int32_t R, int32_t 
     return rasterize_backward_impl(prm, R, B, background, means3D, dc, shs, colors_precomp, scales, rotations, cov3D_precomp, viewmatrix,
                                    projmatrix, cam_pos, radii, geom_buffer, binning_buffer, img_buffer, sample_buffer, dL_dpix, dL_dmean2D,
                                    dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_ddc, dL_dsh, dL_dscale, dL_drot,
-                                   lambda_erank, nullptr, stream);
+                                   lambda_erank, nullptr, nullptr, stream);
 }
 
 int gslic_rasterize_backward_adam(const gslic_raster_params* prm, int32_t R, int32_t B, const float* background, const float* means3D,
@@ -454,7 +466,32 @@ int gslic_rasterize_backward_adam(const gslic_raster_params* prm, int32_t R, int
     return rasterize_backward_impl(prm, R, B, background, means3D, dc, shs, colors_precomp, scales, rotations, cov3D_precomp, viewmatrix,
                                    projmatrix, cam_pos, radii, geom_buffer, binning_buffer, img_buffer, sample_buffer, dL_dpix, nullptr,
                                    nullptr, dL_dopacity, nullptr, dL_dmean3D, nullptr, dL_ddc, dL_dsh, dL_dscale, dL_drot, lambda_erank,
-                                   adam, stream);
+                                   adam, nullptr, stream);
+}
+
+int gslic_rasterize_backward_camera(const gslic_raster_params* prm, int32_t R, int32_t B, const float* background, const float* means3D,
+                                    const float* dc, const float* shs, const float* colors_precomp, const float* scales,
+                                    const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                    const float* cam_pos, const int32_t* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
+                                    char* sample_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                    float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_ddc, float* dL_dsh, float* dL_dscale,
+                                    float* dL_drot, float lambda_erank, float* dL_dviewmatrix, float* dL_dprojmatrix, float* dL_dcampos,
+                                    void* stream)
+{
+    if (!dL_dviewmatrix || !dL_dprojmatrix || !dL_dcampos)
+        return set_error(GSLIC_ERR_INVALID_ARG, "gslic_rasterize_backward_camera: a camera-gradient output pointer is NULL");
+    float* const cam[3] = {dL_dviewmatrix, dL_dprojmatrix, dL_dcampos};
+    if (prm && prm->P == 0) {  // nothing rendered: zero gradients
+        hipStream_t s = (hipStream_t)stream;
+        GS_HIP(hipMemsetAsync(dL_dviewmatrix, 0, 16 * sizeof(float), s));
+        GS_HIP(hipMemsetAsync(dL_dprojmatrix, 0, 16 * sizeof(float), s));
+        GS_HIP(hipMemsetAsync(dL_dcampos, 0, 3 * sizeof(float), s));
+        return GSLIC_OK;
+    }
+    return rasterize_backward_impl(prm, R, B, background, means3D, dc, shs, colors_precomp, scales, rotations, cov3D_precomp, viewmatrix,
+                                   projmatrix, cam_pos, radii, geom_buffer, binning_buffer, img_buffer, sample_buffer, dL_dpix, dL_dmean2D,
+                                   dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_ddc, dL_dsh, dL_dscale, dL_drot,
+                                   lambda_erank, nullptr, cam, stream);
 }
 
 int gslic_adam_update(float* param, const float* param_grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible, float lr,

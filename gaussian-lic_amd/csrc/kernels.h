@@ -82,6 +82,8 @@ struct PreprocessBwdArgs {
     const float4* partials;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_ddc, *dL_dsh, *dL_dscale, *dL_drot;
     AdamFusedArgs adam;
+    float* cam_partials;  // optional [ceil(P/64)][32]: per-wave sums of the 27 camera-gradient terms (NULL: not computed)
+    float* cam_out;       // [35] = dL_dviewmatrix[16] | dL_dprojmatrix[16] | dL_dcampos[3]
 };
 int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
 

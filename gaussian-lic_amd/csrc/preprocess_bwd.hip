@@ -45,8 +45,8 @@ struct ShOut {  // what phase B needs to write a Gaussian's dL_dsh row
     bool on;
 };
 
-template <bool LDS_SH>
-__device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so, float* sg);
+template <bool LDS_SH, bool CAM>
+__device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so, float* sg, float* cg);
 
 // Cooperative sink of the 14 small gradients per Gaussian of one block (see lds_g in the kernel): coalesced float4 stores into the
 // gradient tensors that were asked for (gout, group order of lds_g) and / or the in-place Adam update.  Group g of width w: the
@@ -112,7 +112,7 @@ __device__ __forceinline__ void small_groups_sink(const AdamFusedArgs& A, float*
 // LDS_SH (M == 15): the block's 256 x 45 SH floats (contiguous in memory) are staged through LDS with coalesced float4
 // accesses and read row-wise by the owning thread (row stride 45 floats: odd, bank-conflict free); the block's dL_dsh rows go
 // back the same way — instead of 45 strided 4-byte accesses per thread in each direction (measured 2.6x write amplification).
-template <bool LDS_SH, int BS>
+template <bool LDS_SH, int BS, bool CAM>
 __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds_sh[LDS_SH ? BS * 45 : 4];
@@ -157,7 +157,29 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
     float sg[14];
 #pragma unroll
     for (int k = 0; k < 14; k++) sg[k] = 0.f;
-    if (idx < a.P) bwd_phase_a<LDS_SH>(a, idx, M, sh_row, so, LDS_SH ? sg : nullptr);
+    // camera gradient (CAM): 27 sums over the Gaussians — d/dviewmatrix rows 0..2, d/dprojmatrix rows 0, 1, 3, d/dcampos — with the
+    // three matrices treated as the independent inputs they are at this boundary (the reference returns no camera gradient at all:
+    // rasterizer.cpp:181).  Each wave reduces its 64 Gaussians and writes one row of partials; cam_reduce_kernel adds the rows.
+    float cg[CAM ? 27 : 1];
+    if constexpr (CAM) {
+#pragma unroll
+        for (int k = 0; k < 27; k++) cg[k] = 0.f;
+    }
+    if (idx < a.P) bwd_phase_a<LDS_SH, CAM>(a, idx, M, sh_row, so, LDS_SH ? sg : nullptr, cg);
+    if constexpr (CAM) {
+#pragma unroll
+        for (int k = 0; k < 27; k++) {
+            float v = cg[k];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            cg[k] = v;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            float* row = a.cam_partials + 32 * ((size_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6));
+#pragma unroll
+            for (int k = 0; k < 27; k++) row[k] = cg[k];
+        }
+    }
     if constexpr (LDS_SH) {
         __syncthreads();  // every SH row has been consumed: the buffer first takes the 14 small gradients per Gaussian, group-major
         const int t = threadIdx.x;
@@ -256,8 +278,8 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
     }
 }
 
-template <bool LDS_SH>
-__device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so, float* sg)
+template <bool LDS_SH, bool CAM>
+__device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so, float* sg, float* cg)
 {
     const bool visible = a.radii[idx] > 0;
 
@@ -392,6 +414,23 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
     const float dL_dtx = x_grad_mul * -fx * tz2 * dL_dJ02;
     const float dL_dty = y_grad_mul * -fy * tz2 * dL_dJ12;
     const float dL_dtz = -fx * tz2 * dL_dJ00 - fy * tz2 * dL_dJ11 + (2 * fx * t0) * tz3 * dL_dJ02 + (2 * fy * t1) * tz3 * dL_dJ12;
+    if constexpr (CAM) {
+        const float pc[4] = {mx3, my3, mz3, 1.0f};
+        const float gt[3] = {dL_dtx, dL_dty, dL_dtz};
+        // t = V [p, 1]: d/dV[4c + r] = dL/dt_r * p_c
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r = 0; r < 3; r++) cg[3 * c + r] += gt[r] * pc[c];
+        // W = rotation part of V inside T = W J (T0[i] = V[4i] J00 + V[4i+2] J02, T1[i] = V[4i+1] J11 + V[4i+2] J12)
+        const float gT0[3] = {dL_dT00, dL_dT01, dL_dT02}, gT1[3] = {dL_dT10, dL_dT11, dL_dT12};
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            cg[3 * i + 0] += gT0[i] * J00;
+            cg[3 * i + 1] += gT1[i] * J11;
+            cg[3 * i + 2] += gT0[i] * J02 + gT1[i] * J12;
+        }
+    }
     float dmean[3];
     dmean[0] = V[0] * dL_dtx + V[1] * dL_dty + V[2] * dL_dtz;
     dmean[1] = V[4] * dL_dtx + V[5] * dL_dty + V[6] * dL_dtz;
@@ -406,6 +445,17 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
         dmean[0] += (Pm[0] * pw - Pm[3] * mul1) * s_mx + (Pm[1] * pw - Pm[3] * mul2) * s_my;
         dmean[1] += (Pm[4] * pw - Pm[7] * mul1) * s_mx + (Pm[5] * pw - Pm[7] * mul2) * s_my;
         dmean[2] += (Pm[8] * pw - Pm[11] * mul1) * s_mx + (Pm[9] * pw - Pm[11] * mul2) * s_my;
+        if constexpr (CAM) {
+            // p_proj = (hx, hy) * pw, pw = 1 / (hw + 1e-7): d/dPm[4c + r] = dL/dh_r * p_c for r = 0 (x), 1 (y), 3 (w)
+            const float pc[4] = {mx3, my3, mz3, 1.0f};
+            const float ghx = s_mx * pw, ghy = s_my * pw, ghw = -(mul1 * s_mx + mul2 * s_my);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                cg[12 + 3 * c + 0] += ghx * pc[c];
+                cg[12 + 3 * c + 1] += ghy * pc[c];
+                cg[12 + 3 * c + 2] += ghw * pc[c];
+            }
+        }
     }
 
     // ---- SH backward (backward.cu:27-136); skipped entirely when shs == NULL (backward.cu:352) ----
@@ -451,9 +501,11 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
         // dnormvdv (auxiliary.h:119-129)
         const float sum2 = dox * dox + doy * doy + doz * doz;
         const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-        dmean[0] += ((+sum2 - dox * dox) * ddir[0] - doy * dox * ddir[1] - doz * dox * ddir[2]) * invsum32;
-        dmean[1] += (-dox * doy * ddir[0] + (sum2 - doy * doy) * ddir[1] - doz * doy * ddir[2]) * invsum32;
-        dmean[2] += (-dox * doz * ddir[0] - doy * doz * ddir[1] + (sum2 - doz * doz) * ddir[2]) * invsum32;
+        const float sd0 = ((+sum2 - dox * dox) * ddir[0] - doy * dox * ddir[1] - doz * dox * ddir[2]) * invsum32;
+        const float sd1 = (-dox * doy * ddir[0] + (sum2 - doy * doy) * ddir[1] - doz * doy * ddir[2]) * invsum32;
+        const float sd2 = (-dox * doz * ddir[0] - doy * doz * ddir[1] + (sum2 - doz * doz) * ddir[2]) * invsum32;
+        dmean[0] += sd0; dmean[1] += sd1; dmean[2] += sd2;
+        if constexpr (CAM) { cg[24] -= sd0; cg[25] -= sd1; cg[26] -= sd2; }  // dir = p - campos
     }
 
     // ---- Sigma_3D -> scale, quaternion (backward.cu:257-310) ----
@@ -543,14 +595,45 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
     }
 }
 
+// rows of per-wave partials -> the 35 outputs, fixed summation order (bit-reproducible).  grid = 27 blocks, one per term.
+__global__ __launch_bounds__(256) void cam_reduce_kernel(size_t rows, const float* __restrict__ partials, float* __restrict__ out)
+{
+    __shared__ float red[256];
+    const int k = blockIdx.x;
+    float s = 0.f;
+    for (size_t r = threadIdx.x; r < rows; r += 256) s += partials[32 * r + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // term k -> element: view (k < 12): [4c + r], r = k % 3, c = k / 3; proj (12 <= k < 24): rows 0, 1, 3; campos (k >= 24)
+        int dst;
+        if (k < 12) dst = 4 * (k / 3) + (k % 3);
+        else if (k < 24) { const int kk = k - 12; const int r = kk % 3; dst = 16 + 4 * (kk / 3) + (r == 2 ? 3 : r); }
+        else dst = 32 + (k - 24);
+        out[dst] = red[0];
+    }
+}
+
 int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
 {
+    const bool cam = a.cam_partials != nullptr;
+    if (cam) GS_HIP(hipMemsetAsync(a.cam_out, 0, 35 * sizeof(float), s));  // row 3 of the view matrix, row 2 of the projection: untouched terms
     if (a.M == 15 && a.shs && (a.dL_dsh || a.adam.on)) {
         // one wave per workgroup: 64 Gaussians' SH rows (11.25 KiB) + small-group gradients in LDS, the phase barriers are wave-level,
         // and ten workgroups per CU sit in different phases (measured 0.72 ms against 0.75 at 128 and 0.88 at 256 threads)
-        GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64>), dim3(div_up(a.P, 64)), dim3(64), 0, s, a);
+        if (cam) GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64, true>), dim3(div_up(a.P, 64)), dim3(64), 0, s, a);
+        else GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64, false>), dim3(div_up(a.P, 64)), dim3(64), 0, s, a);
     } else {
-        GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<false, 256>), dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+        if (cam) GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<false, 256, true>), dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+        else GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<false, 256, false>), dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+    }
+    if (cam) {
+        const size_t rows = (a.M == 15 && a.shs && (a.dL_dsh || a.adam.on)) ? (size_t)div_up(a.P, 64) : (size_t)div_up(a.P, 256) * 4;
+        GS_LAUNCH(K_PREPROCESS_BWD, cam_reduce_kernel, dim3(27), dim3(256), 0, s, rows, (const float*)a.cam_partials, a.cam_out);
     }
     return GSLIC_OK;
 }

@@ -84,10 +84,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                                  projmatrix, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, dL_dout_color, dc, sh,
                                  degree, campos, geomBuffer, R, binningBuffer, imageBuffer, B, sampleBuffer, lambda_erank, debug,
-                                 raw_params=False, out=None, adam=None):
+                                 raw_params=False, out=None, adam=None, camera_grads=False):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:151-246): returns (dL_dmeans2D, dL_dcolors_precomp,
     dL_dopacities, dL_dmeans3D, dL_dcov3Ds_precomp, dL_ddc, dL_dsh, dL_dscales, dL_drotations).
-    raw_params=True: scales / rotations are raw and dL_dopacities / dL_dscales / dL_drotations are w.r.t. the raw parameters."""
+    raw_params=True: scales / rotations are raw and dL_dopacities / dL_dscales / dL_drotations are w.r.t. the raw parameters.
+    camera_grads=True (gslic_rasterize_backward_camera; no reference counterpart): three more tensors are appended —
+    dL_dviewmatrix [16], dL_dprojmatrix [16], dL_dcampos [3], element order of the inputs."""
     L = _lib.lib()
     dev = means3D.device
     P, H, W = means3D.size(0), dL_dout_color.size(1), dL_dout_color.size(2)
@@ -125,14 +127,21 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         prm = _params(P, degree, M, H, W, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier,
                       False, debug, False, raw_params)
         p = _lib.ptr
-        _lib.check(L.gslic_rasterize_backward(
-            ctypes.byref(prm), int(R), int(B), p(background), p(means3D), p(dc), p(sh_c), p(colors), p(scales), p(rotations),
-            p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos), p(radii.contiguous()),
-            ctypes.c_void_p(geomBuffer.data_ptr()), ctypes.c_void_p(binningBuffer.data_ptr()),
-            ctypes.c_void_p(imageBuffer.data_ptr()), ctypes.c_void_p(sampleBuffer.data_ptr()), p(dL),
-            p(dL_dmeans2D), p(dL_dconic), p(dL_dopacities), p(dL_dcolors), p(dL_dmeans3D), p(dL_dcov3D), p(dL_ddc),
-            p(dL_dsh), p(dL_dscales), p(dL_drotations), float(lambda_erank), _lib.current_stream_ptr()))
-    return (dL_dmeans2D, dL_dcolors, dL_dopacities, dL_dmeans3D, dL_dcov3D, dL_ddc, dL_dsh, dL_dscales, dL_drotations)
+        common = (ctypes.byref(prm), int(R), int(B), p(background), p(means3D), p(dc), p(sh_c), p(colors), p(scales), p(rotations),
+                  p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos), p(radii.contiguous()),
+                  ctypes.c_void_p(geomBuffer.data_ptr()), ctypes.c_void_p(binningBuffer.data_ptr()),
+                  ctypes.c_void_p(imageBuffer.data_ptr()), ctypes.c_void_p(sampleBuffer.data_ptr()), p(dL),
+                  p(dL_dmeans2D), p(dL_dconic), p(dL_dopacities), p(dL_dcolors), p(dL_dmeans3D), p(dL_dcov3D), p(dL_ddc),
+                  p(dL_dsh), p(dL_dscales), p(dL_drotations), float(lambda_erank))
+        if camera_grads:
+            cam = (torch.empty(16, device=dev), torch.empty(16, device=dev), torch.empty(3, device=dev))
+            _lib.check(L.gslic_rasterize_backward_camera(*common, p(cam[0]), p(cam[1]), p(cam[2]), _lib.current_stream_ptr()))
+        else:
+            _lib.check(L.gslic_rasterize_backward(*common, _lib.current_stream_ptr()))
+    elif camera_grads:
+        cam = (torch.zeros(16, device=dev), torch.zeros(16, device=dev), torch.zeros(3, device=dev))
+    res = (dL_dmeans2D, dL_dcolors, dL_dopacities, dL_dmeans3D, dL_dcov3D, dL_ddc, dL_dsh, dL_dscales, dL_drotations)
+    return res + cam if camera_grads else res
 
 
 class GaussianRasterizerFunction(torch.autograd.Function):

@@ -190,6 +190,28 @@ int gslic_rasterize_backward_adam(
     float lambda_erank, const gslic_adam_fused* adam, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * gslic_rasterize_backward_camera — gslic_rasterize_backward plus the gradient w.r.t. the CAMERA inputs (the "cam" of the
+ * north-star; no reference counterpart: the reference's autograd node returns an undefined tensor for the raster settings,
+ * src/rasterizer/rasterizer.cpp:171-182).  viewmatrix, projmatrix and cam_pos are treated as the three independent inputs they
+ * are at this boundary; a host that derives them from a pose chains through its own (tiny) LibTorch graph:
+ *   dL_dviewmatrix [16]  same element order as viewmatrix ([4c+r]); rows 0..2 carry gradient — through t = V [p,1] (cov2D Jacobian,
+ *                        clamp-masked like backward.cu:225-233) and through the rotation part W of T = W J (backward.cu:180-197)
+ *   dL_dprojmatrix [16]  rows 0, 1, 3 — through p_hom = P [p,1] -> mean2D (backward.cu:339-350)
+ *   dL_dcampos     [3]   through the SH view direction normalize(p - campos) (backward.cu:27-136)
+ * All three are sums over the visible Gaussians, reduced in a fixed order (bit-reproducible).  Depth ordering, culling and the
+ * tile assignment are piecewise constant in the camera and contribute nothing, as for every other input.  All device pointers.
+ */
+int gslic_rasterize_backward_camera(
+    const gslic_raster_params* prm, int32_t R, int32_t B,
+    const float* background, const float* means3D, const float* dc, const float* shs, const float* colors_precomp,
+    const float* scales, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos, const int32_t* radii,
+    char* geom_buffer, char* binning_buffer, char* img_buffer, char* sample_buffer, const float* dL_dpix,
+    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+    float* dL_ddc, float* dL_dsh, float* dL_dscale, float* dL_drot, float lambda_erank,
+    float* dL_dviewmatrix, float* dL_dprojmatrix, float* dL_dcampos, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * gslic_adam_update — replaces ADAM::adamUpdate / adamUpdateCUDA (cuda_rasterizer/adam.cu:9-66), reached
  * from adamUpdate (rasterize_points.cu:248-273) <- SparseGaussianAdam::custom_step (optim_utils.h:102-137).
  * In place on param / exp_avg / exp_avg_sq, all [N,M]; rows with visible[g]==0 are left untouched.

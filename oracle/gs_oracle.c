@@ -601,17 +601,25 @@ static inline gmat3 gtranspose(const gmat3* A)
     return o;
 }
 
-void orc_preprocess_backward(int P, int D, int M, const real* means, const int32_t* radii, const real* dc,
+/* cam (optional, [35] doubles = d/dviewmatrix[16] | d/dprojmatrix[16] | d/dcampos[3], element order of the inputs): the gradient
+ * w.r.t. the camera inputs taken as three independent arrays.  The reference computes no such gradient (rasterizer.cpp:171-182
+ * returns an undefined tensor for the raster settings): this is the chain rule through the reference's own forward —
+ * t = V [p,1] and W = rot(V) in computeCov2D (forward.cu:79-118), p_hom = P [p,1] -> mean2D (forward.cu:279-281,299),
+ * dir = p - campos in computeColorFromSH (forward.cu:29-36) — pinned by finite differences of the double-precision forward
+ * (tests/test_camera_grad.py), not by a reference implementation. */
+static void preprocess_backward_impl(int P, int D, int M, const real* means, const int32_t* radii, const real* dc,
                              const real* shs, const uint8_t* clamped, const real* scales, const real* rots,
                              real scale_mod, const real* cov3D, const real* V, const real* Pm, int W, int H,
                              real tanfovx, real tanfovy, real lxn, real lxp, real lyn, real lyp, const real* campos,
                              const real* dL_dmean2D, const real* dL_dconic, const real* dL_dcolor,
                              real* dL_dmeans, real* dL_dcov, real* dL_ddc, real* dL_dsh, real* dL_dscale,
-                             real* dL_drot, real lambda_erank)
+                             real* dL_drot, real lambda_erank, double* cam)
 {
     (void)dc;
     const real fx = (real)W / (RC(2.) * tanfovx), fy = (real)H / (RC(2.) * tanfovy);
-#pragma omp parallel for schedule(dynamic, 1024)
+    double camacc[35];
+    for (int k = 0; k < 35; k++) camacc[k] = 0.0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : camacc[:35])
     for (int idx = 0; idx < P; idx++) {
         if (!(radii[idx] > 0)) continue;
         const real* mean = means + 3 * idx;
@@ -662,6 +670,19 @@ void orc_preprocess_backward(int P, int D, int M, const real* means, const int32
         const real dL_dty = y_grad_mul * -fy * tz2 * dL_dJ12;
         const real dL_dtz = -fx * tz2 * dL_dJ00 - fy * tz2 * dL_dJ11 + (2 * fx * c2.t[0]) * tz3 * dL_dJ02 +
                             (2 * fy * c2.t[1]) * tz3 * dL_dJ12;
+        if (cam) {
+            const real pc[4] = {mean[0], mean[1], mean[2], RC(1.)};
+            const real gt[3] = {dL_dtx, dL_dty, dL_dtz};
+            for (int c = 0; c < 4; c++)
+                for (int r = 0; r < 3; r++) camacc[4 * c + r] += (double)(gt[r] * pc[c]);          /* t = V [p,1] */
+            const real J00 = fx * tz, J11 = fy * tz, J02 = -(fx * c2.t[0]) * tz2, J12 = -(fy * c2.t[1]) * tz2;
+            const real gT0[3] = {dL_dT00, dL_dT01, dL_dT02}, gT1[3] = {dL_dT10, dL_dT11, dL_dT12};
+            for (int i = 0; i < 3; i++) {                                                           /* T = W J */
+                camacc[4 * i + 0] += (double)(gT0[i] * J00);
+                camacc[4 * i + 1] += (double)(gT1[i] * J11);
+                camacc[4 * i + 2] += (double)(gT0[i] * J02 + gT1[i] * J12);
+            }
+        }
         real dmean[3]; /* transformVec4x3Transpose, assignment (backward.cu:252-254) */
         dmean[0] = V[0] * dL_dtx + V[1] * dL_dty + V[2] * dL_dtz;
         dmean[1] = V[4] * dL_dtx + V[5] * dL_dty + V[6] * dL_dtz;
@@ -677,6 +698,15 @@ void orc_preprocess_backward(int P, int D, int M, const real* means, const int32
         dmean[0] += (Pm[0] * pw - Pm[3] * mul1) * g2x + (Pm[1] * pw - Pm[3] * mul2) * g2y;
         dmean[1] += (Pm[4] * pw - Pm[7] * mul1) * g2x + (Pm[5] * pw - Pm[7] * mul2) * g2y;
         dmean[2] += (Pm[8] * pw - Pm[11] * mul1) * g2x + (Pm[9] * pw - Pm[11] * mul2) * g2y;
+        if (cam) {                                                                                  /* p_hom = P [p,1] */
+            const real pc[4] = {mean[0], mean[1], mean[2], RC(1.)};
+            const real ghx = g2x * pw, ghy = g2y * pw, ghw = -(mul1 * g2x + mul2 * g2y);
+            for (int c = 0; c < 4; c++) {
+                camacc[16 + 4 * c + 0] += (double)(ghx * pc[c]);
+                camacc[16 + 4 * c + 1] += (double)(ghy * pc[c]);
+                camacc[16 + 4 * c + 3] += (double)(ghw * pc[c]);
+            }
+        }
 
         if (shs) { /* computeColorFromSH backward, backward.cu:27-136 */
             const real dir_o[3] = {mean[0] - campos[0], mean[1] - campos[1], mean[2] - campos[2]};
@@ -736,9 +766,11 @@ void orc_preprocess_backward(int P, int D, int M, const real* means, const int32
             const real vx = dir_o[0], vy = dir_o[1], vz = dir_o[2];
             const real sum2 = vx * vx + vy * vy + vz * vz;
             const real invsum32 = RC(1.) / r_sqrt(sum2 * sum2 * sum2);
-            dmean[0] += ((+sum2 - vx * vx) * ddir[0] - vy * vx * ddir[1] - vz * vx * ddir[2]) * invsum32;
-            dmean[1] += (-vx * vy * ddir[0] + (sum2 - vy * vy) * ddir[1] - vz * vy * ddir[2]) * invsum32;
-            dmean[2] += (-vx * vz * ddir[0] - vy * vz * ddir[1] + (sum2 - vz * vz) * ddir[2]) * invsum32;
+            const real sd0 = ((+sum2 - vx * vx) * ddir[0] - vy * vx * ddir[1] - vz * vx * ddir[2]) * invsum32;
+            const real sd1 = (-vx * vy * ddir[0] + (sum2 - vy * vy) * ddir[1] - vz * vy * ddir[2]) * invsum32;
+            const real sd2 = (-vx * vz * ddir[0] - vy * vz * ddir[1] + (sum2 - vz * vz) * ddir[2]) * invsum32;
+            dmean[0] += sd0; dmean[1] += sd1; dmean[2] += sd2;
+            if (cam) { camacc[32] -= (double)sd0; camacc[33] -= (double)sd1; camacc[34] -= (double)sd2; }  /* dir = p - campos */
         }
         for (int k = 0; k < 3; k++) dL_dmeans[3 * idx + k] = dmean[k];
 
@@ -790,6 +822,35 @@ void orc_preprocess_backward(int P, int D, int M, const real* means, const int32
             }
         }
     }
+    if (cam)
+        for (int k = 0; k < 35; k++) cam[k] = camacc[k];
+}
+
+void orc_preprocess_backward(int P, int D, int M, const real* means, const int32_t* radii, const real* dc,
+                             const real* shs, const uint8_t* clamped, const real* scales, const real* rots,
+                             real scale_mod, const real* cov3D, const real* V, const real* Pm, int W, int H,
+                             real tanfovx, real tanfovy, real lxn, real lxp, real lyn, real lyp, const real* campos,
+                             const real* dL_dmean2D, const real* dL_dconic, const real* dL_dcolor,
+                             real* dL_dmeans, real* dL_dcov, real* dL_ddc, real* dL_dsh, real* dL_dscale,
+                             real* dL_drot, real lambda_erank)
+{
+    preprocess_backward_impl(P, D, M, means, radii, dc, shs, clamped, scales, rots, scale_mod, cov3D, V, Pm, W, H, tanfovx, tanfovy, lxn, lxp,
+                             lyn, lyp, campos, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmeans, dL_dcov, dL_ddc, dL_dsh, dL_dscale, dL_drot,
+                             lambda_erank, NULL);
+}
+
+/* the same, plus the camera gradient (see preprocess_backward_impl) */
+void orc_preprocess_backward_cam(int P, int D, int M, const real* means, const int32_t* radii, const real* dc,
+                                 const real* shs, const uint8_t* clamped, const real* scales, const real* rots,
+                                 real scale_mod, const real* cov3D, const real* V, const real* Pm, int W, int H,
+                                 real tanfovx, real tanfovy, real lxn, real lxp, real lyn, real lyp, const real* campos,
+                                 const real* dL_dmean2D, const real* dL_dconic, const real* dL_dcolor,
+                                 real* dL_dmeans, real* dL_dcov, real* dL_ddc, real* dL_dsh, real* dL_dscale,
+                                 real* dL_drot, real lambda_erank, double* cam)
+{
+    preprocess_backward_impl(P, D, M, means, radii, dc, shs, clamped, scales, rots, scale_mod, cov3D, V, Pm, W, H, tanfovx, tanfovy, lxn, lxp,
+                             lyn, lyp, campos, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmeans, dL_dcov, dL_ddc, dL_dsh, dL_dscale, dL_drot,
+                             lambda_erank, cam);
 }
 
 /* ================================================================================================

@@ -124,8 +124,9 @@ class Oracle:
         out["num_buckets_ref32"] = 0 if no_color else int(((r[:, 1] - r[:, 0] + 31) // 32).sum())
         return out
 
-    def backward(self, sc, cam, fwd, dL_dpix, lambda_erank=0.0):
-        """Full reference backward (rasterizer_impl.cu:476-581); returns all ten gradient tensors."""
+    def backward(self, sc, cam, fwd, dL_dpix, lambda_erank=0.0, camera_grads=False):
+        """Full reference backward (rasterizer_impl.cu:476-581); returns all ten gradient tensors.  camera_grads=True adds
+        dL_dviewmatrix [16], dL_dprojmatrix [16], dL_dcampos [3] (float64; no reference counterpart, see gs_oracle.c)."""
         W, H = cam["W"], cam["H"]
         P = sc["means"].shape[0]
         M = 0 if sc["shs"] is None or sc["shs"].size == 0 else sc["shs"].shape[1]
@@ -143,14 +144,19 @@ class Oracle:
         means, scales, rots, dc = self.a(sc["means"]), self.a(sc["scales"]), self.a(sc["rots"]), self.a(sc["dc"])
         shs = self.a(sc["shs"]) if M > 0 else None
         view, proj, campos = self.a(cam["view"]), self.a(cam["proj"]), self.a(cam["campos"])
-        self.lib.orc_preprocess_backward(
-            ctypes.c_int(P), ctypes.c_int(int(sc["D"])), ctypes.c_int(M), _ptr(means), _ptr(pre["radii"]), _ptr(dc),
-            _ptr(shs), _ptr(pre["clamped"]), _ptr(scales), _ptr(rots), r(sc.get("scale_modifier", 1.0)),
-            _ptr(pre["cov3D"]), _ptr(view), _ptr(proj), ctypes.c_int(W), ctypes.c_int(H), r(cam["tanfovx"]),
-            r(cam["tanfovy"]), r(cam["limx_neg"]), r(cam["limx_pos"]), r(cam["limy_neg"]), r(cam["limy_pos"]),
-            _ptr(campos), _ptr(g["dL_dmean2D"]), _ptr(g["dL_dconic"]), _ptr(g["dL_dcolor"]), _ptr(g["dL_dmean3D"]),
-            _ptr(g["dL_dcov3D"]), _ptr(g["dL_ddc"]), _ptr(g["dL_dsh"]) if M > 0 else None, _ptr(g["dL_dscale"]),
-            _ptr(g["dL_drot"]), r(lambda_erank))
+        args = (ctypes.c_int(P), ctypes.c_int(int(sc["D"])), ctypes.c_int(M), _ptr(means), _ptr(pre["radii"]), _ptr(dc),
+                _ptr(shs), _ptr(pre["clamped"]), _ptr(scales), _ptr(rots), r(sc.get("scale_modifier", 1.0)),
+                _ptr(pre["cov3D"]), _ptr(view), _ptr(proj), ctypes.c_int(W), ctypes.c_int(H), r(cam["tanfovx"]),
+                r(cam["tanfovy"]), r(cam["limx_neg"]), r(cam["limx_pos"]), r(cam["limy_neg"]), r(cam["limy_pos"]),
+                _ptr(campos), _ptr(g["dL_dmean2D"]), _ptr(g["dL_dconic"]), _ptr(g["dL_dcolor"]), _ptr(g["dL_dmean3D"]),
+                _ptr(g["dL_dcov3D"]), _ptr(g["dL_ddc"]), _ptr(g["dL_dsh"]) if M > 0 else None, _ptr(g["dL_dscale"]),
+                _ptr(g["dL_drot"]), r(lambda_erank))
+        if camera_grads:
+            camg = np.zeros(35, np.float64)
+            self.lib.orc_preprocess_backward_cam(*args, _ptr(camg))
+            g["dL_dviewmatrix"], g["dL_dprojmatrix"], g["dL_dcampos"] = camg[:16].copy(), camg[16:32].copy(), camg[32:].copy()
+        else:
+            self.lib.orc_preprocess_backward(*args)
         g["dL_dconic"] = g["dL_dconic"].reshape(P, 2, 2)
         return g
 
