@@ -1,4 +1,4 @@
-"""Randomised HIP-vs-oracle parity sweep (run on the MI355X: `python tools/parity_sweep.py [n_cases] [seed]`).  Draws scene kind, size,
+"""Randomised HIP-vs-oracle parity sweep (run on the MI355X: `python tests/parity_sweep.py [n_cases] [seed]`).  Draws scene kind, size,
 image shape (ragged on purpose), SH degree and seeds; checks the integer stages bit-exactly and images / gradients with the bars of
 tests/test_parity_gpu.py.  A one-off confidence run, not part of the test suite (the oracle needs seconds per case)."""
 import os
@@ -9,7 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # this file lives in tests/: the oracle is test infrastructure
 
 
 def main(n_cases, seed):
