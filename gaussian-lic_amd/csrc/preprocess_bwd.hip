@@ -559,10 +559,16 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
         const float vd0 = qraw.x * dq.x, vd1 = qraw.y * dq.y, vd2 = qraw.z * dq.z, vd3 = qraw.w * dq.w;
         const float vds = vd0 + vd1 + vd2 + vd3;
         float4 dr;
-        dr.x = ((sum2 - qraw.x * qraw.x) * dq.x - qraw.x * (vds - vd0)) * invsum32;
-        dr.y = ((sum2 - qraw.y * qraw.y) * dq.y - qraw.y * (vds - vd1)) * invsum32;
-        dr.z = ((sum2 - qraw.z * qraw.z) * dq.z - qraw.z * (vds - vd2)) * invsum32;
-        dr.w = ((sum2 - qraw.w * qraw.w) * dq.w - qraw.w * (vds - vd3)) * invsum32;
+        if (sqrtf(sum2) < 1e-12f) {
+            // F::normalize divides by max(||q||, eps): below eps the divisor is the constant eps (its clamp_min passes no gradient), so the
+            // Jacobian is I / eps; the closed form below would be 0 * inf there
+            dr = make_float4(dq.x * 1e12f, dq.y * 1e12f, dq.z * 1e12f, dq.w * 1e12f);
+        } else {
+            dr.x = ((sum2 - qraw.x * qraw.x) * dq.x - qraw.x * (vds - vd0)) * invsum32;
+            dr.y = ((sum2 - qraw.y * qraw.y) * dq.y - qraw.y * (vds - vd1)) * invsum32;
+            dr.z = ((sum2 - qraw.z * qraw.z) * dq.z - qraw.z * (vds - vd2)) * invsum32;
+            dr.w = ((sum2 - qraw.w * qraw.w) * dq.w - qraw.w * (vds - vd3)) * invsum32;
+        }
         dq = dr;
     }
     // ---- sinks: gradient tensors (each optional) and / or the in-place Adam update of this Gaussian's 14 small scalars

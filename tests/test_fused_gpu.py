@@ -88,3 +88,35 @@ def test_adam_inside_backward_is_bit_identical():
     for sa, sb in zip(a.optimizer.state, b.optimizer.state):
         assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
         assert sa["step"] == sb["step"] == 4
+
+
+def test_extreme_parameters_do_not_poison_training():
+    """Saturated opacities, exp(12) / exp(-30) scales, zero and 1e18 quaternions, points at 1e6, on the near plane and at the camera centre:
+    five fused training steps must finish and leave every parameter finite (culled or degenerate Gaussians are skipped, like in the
+    reference: det == 0, opacity < 1/255, z <= 0.2 — forward.cu:287-293, auxiliary.h:158-168)."""
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import trainer
+    from gaussian_lic_amd.camera import synthetic_camera
+    from gaussian_lic_amd.synthetic import gt_image, random_scene
+    dev = torch.device("cuda:0")
+    W, H, P = 320, 192, 20000
+    raw = random_scene(P, W, H, 3, 3)
+    raw["scaling"][:2000] = 12.0
+    raw["scaling"][2000:4000] = -30.0
+    raw["opacity"][4000:6000] = 60.0
+    raw["opacity"][6000:8000] = -60.0
+    raw["rotation"][8000:9000] = 0.0
+    raw["rotation"][9000:10000] *= 1e18
+    raw["xyz"][10000:11000, 2] = 1e6
+    raw["xyz"][11000:12000, 2] = 0.2000001
+    raw["xyz"][12000:13000] = 0.0
+    model = trainer.GaussianModel(raw, dev)
+    model.training_setup()
+    cam = synthetic_camera(W, H).to_device(dev)
+    gt, bg = gt_image(H, W).to(dev), torch.zeros(3, device=dev)
+    for _ in range(5):
+        terms, vis = trainer.training_step_fused(model, cam, gt, bg)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(terms).all()) and int(vis.sum()) > 0
+    for n in ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation"):
+        assert bool(torch.isfinite(getattr(model, n)).all()), n
