@@ -245,3 +245,43 @@ def test_error_conventions_on_device():
     # and the library still works afterwards
     ok = hip_forward(raw, cam)
     assert ok["R"] > 0
+
+
+@pytest.mark.parametrize("case", ["tiny_image", "one_pixel", "one_tile_long_list", "equal_depths"])
+def test_degenerate_shapes(oracle32, case):
+    """Shapes at the edges of the launch geometry: an image smaller than one tile, a single pixel, thousands of Gaussians piled on one
+    tile (one list of ~50 buckets, every sort key of a pass equal), and exactly equal depths (order = Gaussian id)."""
+    from gpu_helpers import hip_backward, hip_forward, npy
+    from gaussian_lic_amd.synthetic import pixel_grad
+    if case == "tiny_image":
+        raw, sc, camd, cam = make_scene("random", 50, 5, 3, 3, 2)
+    elif case == "one_pixel":
+        raw, sc, camd, cam = make_scene("random", 20, 1, 1, 3, 3)
+    else:
+        W, H, P = 48, 32, 3000
+        raw, sc, camd, cam = make_scene("random", P, W, H, 3, 4)
+        g = torch.Generator().manual_seed(1)
+        z = torch.rand(P, generator=g) * 20.0 + 2.0 if case == "one_tile_long_list" else torch.full((P,), 5.0)
+        fx, cx, cy = 0.675 * W, 0.4857 * W, 0.5215 * H
+        u = 8.0 + torch.randn(P, generator=g)            # all inside tile (0, 0)
+        v = 8.0 + torch.randn(P, generator=g)
+        raw["xyz"] = torch.stack([(u - cx) * z / fx, (v - cy) * z / fx, z], 1).float().contiguous()
+        raw["scaling"] = (torch.log(z / fx) + 0.3).unsqueeze(1).repeat(1, 3).float().contiguous()
+        raw["opacity"] = torch.full((P, 1), -3.0)         # faint: the list is consumed to the end
+        from gaussian_lic_amd.synthetic import activate, to_numpy
+        sc = to_numpy(activate(raw))
+    W, H = cam.image_width, cam.image_height
+    ref = oracle32.forward(sc, camd)
+    got = hip_forward(raw, cam, export=("tiles_touched", "point_list", "ranges"))
+    assert got["R"] == ref["num_rendered"]
+    R = got["R"]
+    np.testing.assert_array_equal(npy(got["radii"]), ref["pre"]["radii"])
+    np.testing.assert_array_equal(npy(got["dbg"]["point_list"])[:R].astype(np.uint32), ref["bins"]["point_list"][:R].astype(np.uint32))
+    np.testing.assert_array_equal(npy(got["dbg"]["ranges"]).reshape(-1, 2).astype(np.uint32), ref["bins"]["ranges"].astype(np.uint32))
+    assert_close_flips(npy(got["color"]), ref["color"], 1e-4, "color")
+    dL = pixel_grad(H, W, seed=1)
+    g = hip_backward(got, dL)
+    rg = oracle32.backward(sc, camd, ref, dL.numpy())
+    for k in ("dL_dmean3D", "dL_dopacity", "dL_ddc", "dL_dsh", "dL_dscale"):
+        if rg[k].size and np.abs(rg[k]).max() > 0:
+            assert_close_flips(g[k].reshape(rg[k].shape), rg[k], 1e-4, k, flip_bound=2e-2)
