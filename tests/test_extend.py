@@ -96,3 +96,36 @@ def test_extend_matches_oracle_and_appends_in_place(oracle32):
     k2 = model.extend(cam, torch.from_numpy(pts).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(rsp).to(dev),
                       torch.eye(3), torch.zeros(3), (fx, fy, cx, cy))
     assert 0 <= k2 < k                                                              # pixels covered by the new Gaussians reject more points
+
+
+@pytest.mark.gpu
+def test_extend_edge_cases_and_interleaved_forwards():
+    """extend() with an empty frame and with a frame that lands only outside the image inserts nothing and leaves the model untouched;
+    two forwards issued back to back keep independent scratch, so their backwards can run in any order."""
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import trainer
+    from gpu_helpers import hip_backward, hip_forward
+    from gaussian_lic_amd.synthetic import pixel_grad
+    W, H, P = 160, 120, 3000
+    raw, sc, camd, cam = make_scene("random", P, W, H, 3, 61)
+    dev = torch.device("cuda:0")
+    cam.to_device(dev)
+    model = trainer.GaussianModel(raw, dev)
+    model.training_setup()
+    fx, fy, cx, cy = float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy)
+    before = model.xyz.detach().clone()
+    e3, e1 = torch.empty(0, 3, device=dev), torch.empty(0, device=dev)
+    assert model.extend(cam, e3, e3, e1, torch.eye(3), torch.zeros(3), (fx, fy, cx, cy)) == 0
+    far = torch.tensor([[1e4, 1e4, 1.0], [-1e4, 0.0, 2.0], [0.0, 0.0, -5.0]], device=dev)   # off-image / behind the camera
+    assert model.extend(cam, far, torch.rand(3, 3, device=dev), far[:, 2].abs().contiguous(), torch.eye(3), torch.zeros(3), (fx, fy, cx, cy)) == 0
+    assert model.P == P and torch.equal(model.xyz.detach(), before)
+    # interleaved forwards: A, B, then backward(B), backward(A) == the separate sequences
+    raw2, _, _, cam2 = make_scene("random", 2000, 96, 64, 3, 62)
+    dLa, dLb = pixel_grad(H, W, seed=1), pixel_grad(64, 96, seed=2)
+    fa, fb = hip_forward(raw, cam), hip_forward(raw2, cam2)
+    gb, ga = hip_backward(fb, dLb), hip_backward(fa, dLa)
+    fa2 = hip_forward(raw, cam); ga2 = hip_backward(fa2, dLa)
+    fb2 = hip_forward(raw2, cam2); gb2 = hip_backward(fb2, dLb)
+    for k in ga:
+        np.testing.assert_array_equal(ga[k], ga2[k])
+        np.testing.assert_array_equal(gb[k], gb2[k])
