@@ -39,7 +39,7 @@ EXPORTS = [
     "gslic_last_error", "gslic_geom_bytes", "gslic_img_bytes", "gslic_binning_bytes", "gslic_sample_bytes",
     "gslic_profile_enable", "gslic_profile_reset", "gslic_profile_collect", "gslic_profile_num_kernels",
     "gslic_profile_kernel_name", "gslic_profile_get", "gslic_debug_export", "gslic_extend_select", "gslic_extend_emit", "gslic_loss_partials_count", "gslic_l1_ssim_loss_forward",
-    "gslic_l1_ssim_loss_backward",
+    "gslic_l1_ssim_loss_backward", "gslic_set_math_mode",
 ]
 
 _lib = None
@@ -91,10 +91,17 @@ def lib():
     L.gslic_loss_partials_count.argtypes = [i32, i32, i32, i32]
     L.gslic_l1_ssim_loss_forward.argtypes = [i32, i32, i32, i32, f32, f32] + [vp] * 7 + [vp]
     L.gslic_l1_ssim_loss_backward.argtypes = [i32, i32, i32, i32, f32] + [vp] * 6 + [vp]
-    if L.gslic_abi_version() != 2:
+    L.gslic_set_math_mode.argtypes = [i32]
+    if L.gslic_abi_version() != 3:
         raise GslicError("libgslic_hip.so ABI version mismatch")
     _lib = L
     return L
+
+
+def set_math_mode(strict):
+    """gslic_set_math_mode: True = the blend kernels in the reference's arithmetic (bit-identical image), False = fast (default).
+    Returns the previous mode."""
+    return bool(lib().gslic_set_math_mode(int(bool(strict))))
 
 
 def check(rc):
@@ -113,24 +120,44 @@ def current_stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-class TensorAllocator:
-    """Allocator callback backed by torch's caching allocator — the role of resizeFunctional
-    (rasterize_points.cu:40-48): one growable uint8 tensor per scratch buffer."""
+class _AllocBox:
+    """What the allocator callback closes over: the device and the tensor it handed out.  Deliberately NOT the TensorAllocator itself —
+    a ctypes thunk that referenced a bound method of its owner would form a reference cycle, and the ~1 GB of scratch of a 2M-Gaussian
+    step would stay pinned until the cyclic collector happened to run."""
+    __slots__ = ("device", "tensor")
 
     def __init__(self, device):
         self.device = device
         self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
-        self.cb = ALLOC_FN(self._alloc)
+
+
+class TensorAllocator:
+    """Allocator callback backed by torch's caching allocator — the role of resizeFunctional
+    (rasterize_points.cu:40-48): one growable uint8 tensor per scratch buffer.  Freed by reference counting alone."""
 
     GRANULE = 32 << 20  # large requests are rounded up so that step-to-step drift of R / B (the Gaussians move)
                         # keeps hitting the same cached block instead of forcing a fresh hipMalloc
 
-    def _alloc(self, _ctx, nbytes):
-        n = int(nbytes)
-        if n > (1 << 20):
-            n = (n + self.GRANULE - 1) // self.GRANULE * self.GRANULE
-        self.tensor = torch.empty(n, dtype=torch.uint8, device=self.device)
-        return self.tensor.data_ptr()
+    def __init__(self, device):
+        box = self._box = _AllocBox(device)
+        granule = self.GRANULE
+
+        def _alloc(_ctx, nbytes):
+            n = int(nbytes)
+            if n > (1 << 20):
+                n = (n + granule - 1) // granule * granule
+            box.tensor = torch.empty(n, dtype=torch.uint8, device=box.device)
+            return box.tensor.data_ptr()
+
+        self.cb = ALLOC_FN(_alloc)
+
+    @property
+    def device(self):
+        return self._box.device
+
+    @property
+    def tensor(self):
+        return self._box.tensor
 
 
 # ------------------------------------------------------------------------------------------- profiling

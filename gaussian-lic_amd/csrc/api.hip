@@ -26,6 +26,7 @@ int set_error(int code, const char* fmt, ...)
 
 // ---------------------------------------------------------------------------------------------------------
 bool g_prof_on = false;
+int g_strict_math = (getenv("GSLIC_STRICT_MATH") && atoi(getenv("GSLIC_STRICT_MATH")) != 0) ? 1 : 0;
 static uint32_t g_prof_mask = 0xffffffffu;
 static bool g_prof_cur_on = false;
 static const char* const k_names[K_COUNT] = {
@@ -130,53 +131,92 @@ struct Mailbox {
     uint32_t* dev = nullptr;
     uint32_t seq = 0;
 };
-static thread_local Mailbox t_mbox;
-__global__ void publish_kernel(const uint32_t* __restrict__ v0, const uint32_t* __restrict__ v1, uint32_t* box, uint32_t seq)
+// One mailbox per (thread, device): the device pointer of mapped host memory belongs to the device it was resolved on
+// (hipHostMallocPortable makes the allocation itself visible to every device).  Freed when the thread exits.
+static constexpr int kMaxDevices = 16;
+struct MailboxSet {
+    Mailbox box[kMaxDevices];
+    ~MailboxSet()
+    {
+        for (auto& m : box)
+            if (m.host) (void)hipHostFree(const_cast<uint32_t*>(m.host));
+    }
+};
+static thread_local MailboxSet t_mbox;
+static uint32_t* g_status_word[kMaxDevices];
+uint32_t* device_status_word()
 {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    uint32_t* w = __atomic_load_n(&g_status_word[dev], __ATOMIC_ACQUIRE);
+    if (w) return w;
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess || !p) { (void)hipGetLastError(); return nullptr; }
+    (void)hipMemset(p, 0, 256);
+    uint32_t* expected = nullptr;
+    if (!__atomic_compare_exchange_n(&g_status_word[dev], &expected, static_cast<uint32_t*>(p), false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+        (void)hipFree(p);  // another thread won
+        return expected;
+    }
+    return static_cast<uint32_t*>(p);
+}
+__global__ void publish_kernel(const uint32_t* __restrict__ v0, const uint32_t* __restrict__ v1, uint32_t* status, uint32_t* box, uint32_t seq)
+{
+    const uint32_t st = status ? atomicExch(status, 0u) : 0u;  // bit 0: a bounded spin-wait gave up somewhere upstream
     __hip_atomic_store(box + 0, v0 ? *v0 : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(box + 1, v1 ? *v1 : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(box + 1, (v1 ? (*v1 & 1u) : 0u) | ((st & 3u) << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(box + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// out[0] = *v0, out[1] = (*v1 & 1) | scan-timeout << 1 | scan-overflow << 2
 static int fetch_counts(const uint32_t* v0, const uint32_t* v1, uint32_t out[2], hipStream_t s)
 {
-    Mailbox& m = t_mbox;
+    int dev = 0;
+    GS_HIP(hipGetDevice(&dev));
     static const bool use_mailbox = getenv("GSLIC_NO_MAILBOX") == nullptr;
-    if (use_mailbox && !m.host) {
-        void* h = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && h) {
-            void* d = nullptr;
-            if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
-                m.host = static_cast<volatile uint32_t*>(h);
-                m.dev = static_cast<uint32_t*>(d);
-                m.host[0] = m.host[1] = m.host[2] = 0;
-            } else {
-                (void)hipHostFree(h);
+    uint32_t* const status = device_status_word();
+    if (use_mailbox && dev >= 0 && dev < kMaxDevices) {
+        Mailbox& m = t_mbox.box[dev];
+        if (!m.host) {
+            void* h = nullptr;
+            if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) == hipSuccess && h) {
+                void* d = nullptr;
+                if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
+                    m.host = static_cast<volatile uint32_t*>(h);
+                    m.dev = static_cast<uint32_t*>(d);
+                    m.host[0] = m.host[1] = m.host[2] = 0;
+                } else {
+                    (void)hipHostFree(h);
+                }
             }
+            (void)hipGetLastError();
         }
-        (void)hipGetLastError();
-    }
-    if (use_mailbox && m.host) {
-        const uint32_t seq = ++m.seq ? m.seq : ++m.seq;  // never 0
-        hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, s, v0, v1, m.dev, seq);
-        GS_HIP(hipGetLastError());
-        const auto t0 = std::chrono::steady_clock::now();
-        uint32_t spins = 0;
-        while (__atomic_load_n(const_cast<const uint32_t*>(m.host + 2), __ATOMIC_ACQUIRE) != seq) {
-            if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
-                GS_HIP(hipStreamSynchronize(s));  // slow path: whatever is ahead of the publish kernel in the stream takes long
-                break;
+        if (m.host) {
+            const uint32_t seq = ++m.seq ? m.seq : ++m.seq;  // never 0
+            hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, s, v0, v1, status, m.dev, seq);
+            GS_HIP(hipGetLastError());
+            const auto t0 = std::chrono::steady_clock::now();
+            uint32_t spins = 0;
+            while (__atomic_load_n(const_cast<const uint32_t*>(m.host + 2), __ATOMIC_ACQUIRE) != seq) {
+                if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+                    GS_HIP(hipStreamSynchronize(s));  // slow path: whatever is ahead of the publish kernel in the stream takes long
+                    break;
+                }
             }
+            if (__atomic_load_n(const_cast<const uint32_t*>(m.host + 2), __ATOMIC_ACQUIRE) != seq)
+                return set_error(GSLIC_ERR_HIP, "count mailbox: the publish kernel did not report");
+            out[0] = m.host[0];
+            out[1] = m.host[1];
+            return GSLIC_OK;
         }
-        if (__atomic_load_n(const_cast<const uint32_t*>(m.host + 2), __ATOMIC_ACQUIRE) != seq)
-            return set_error(GSLIC_ERR_HIP, "count mailbox: the publish kernel did not report");
-        out[0] = m.host[0];
-        out[1] = m.host[1];
-        return GSLIC_OK;
     }
+    uint32_t st = 0;
     out[0] = out[1] = 0;
     if (v0) GS_HIP(hipMemcpyAsync(&out[0], v0, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (v1) GS_HIP(hipMemcpyAsync(&out[1], v1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (status) GS_HIP(hipMemcpyAsync(&st, status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     GS_HIP(hipStreamSynchronize(s));
+    if (st) GS_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t), s));
+    out[1] = (out[1] & 1u) | ((st & 3u) << 1);
     return GSLIC_OK;
 }
 
@@ -227,6 +267,12 @@ using namespace gslic;
 extern "C" {
 
 int gslic_abi_version(void) { return GSLIC_ABI_VERSION; }
+int gslic_set_math_mode(int32_t strict)
+{
+    const int old = g_strict_math;
+    g_strict_math = strict != 0;
+    return old;
+}
 const char* gslic_last_error(void) { return g_err; }
 
 size_t gslic_geom_bytes(int32_t P) { size_t b; GeomState::carve(nullptr, (size_t)(P > 0 ? P : 0), &b); return b; }
@@ -306,7 +352,9 @@ int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_
     GS_TRY(scan_u32_chained(geom.tiles_touched, order, geom.point_offsets, (size_t)P, false, geom.scan_state, s));
     uint32_t hostbuf[2] = {0, 0};
     GS_TRY(fetch_counts(geom.point_offsets + (P - 1), geom.flags, hostbuf, s));  // host needs R to size the binning buffer (rasterizer_impl.cu:398)
-    if (prm->prefiltered && hostbuf[1]) return set_error(GSLIC_ERR_PREFILTERED, "a point was culled although prefiltered is set");
+    if (hostbuf[1] & 2u) return set_error(GSLIC_ERR_HIP, "a chained-scan look-back wait timed out (device preempted?): the forward was abandoned");
+    if (hostbuf[1] & 4u) return set_error(GSLIC_ERR_INVALID_ARG, "more than 2^31 (Gaussian, tile) instances");
+    if (prm->prefiltered && (hostbuf[1] & 1u)) return set_error(GSLIC_ERR_PREFILTERED, "a point was culled although prefiltered is set");
     if (hostbuf[0] > 0x7fffffffu) return set_error(GSLIC_ERR_INVALID_ARG, "more than 2^31 (Gaussian, tile) instances");
     const uint32_t R = hostbuf[0];
 
@@ -340,6 +388,7 @@ int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_
     if (!no_color) {
         GS_TRY(launch_bucket_scan(T, img.ranges, img.bucket_offsets, s));
         GS_TRY(fetch_counts(img.bucket_offsets + (T - 1), nullptr, hostbuf, s));  // rasterizer_impl.cu:442
+        if (hostbuf[1] & 2u) return set_error(GSLIC_ERR_HIP, "a sort look-back / chained-scan wait timed out (device preempted?): the forward was abandoned");
         B = hostbuf[0];
         size_t smp_bytes;
         SampleState::carve(nullptr, (size_t)B, &smp_bytes);
@@ -425,10 +474,11 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
     }
     pb.cam_partials = nullptr; pb.cam_out = nullptr;
     if (dL_dcam) {
-        // scratch: the depth-sort ping-pong arrays of the geometry buffer are dead after the forward; their first slot takes the per-wave
-        // partial rows (128 B per 64 Gaussians <= 4 B per Gaussian), the second the 35 reduced terms
+        // scratch: the depth-sort ping-pong arrays of the geometry buffer are dead after the forward.  The per-wave partial rows
+        // (128 B per wave; the generic 256-thread path writes 4 rows per block even when P < 256, i.e. up to 512 * ceil(P / 256) B)
+        // take the two key arrays, which are contiguous and hold max(512, 8 P) bytes; the 35 reduced terms go behind them
         pb.cam_partials = reinterpret_cast<float*>(geom.depth_keys[0]);
-        pb.cam_out = reinterpret_cast<float*>(geom.depth_keys[1]);
+        pb.cam_out = reinterpret_cast<float*>(geom.order[0]);
     }
     GS_TRY(launch_preprocess_bwd(pb, s));
     if (dL_dcam) {
@@ -507,10 +557,17 @@ int gslic_adam_update_groups(const gslic_adam_group* groups, int32_t n_groups, c
 {
     if (n_groups <= 0 || N == 0) return GSLIC_OK;
     if (!groups || !visible) return set_error(GSLIC_ERR_INVALID_ARG, "adam groups: NULL pointer");
-    for (int i = 0; i < n_groups; i++)
-        if (groups[i].M == 0 || !groups[i].param || !groups[i].grad || !groups[i].exp_avg || !groups[i].exp_avg_sq)
-            return set_error(GSLIC_ERR_INVALID_ARG, "adam group %d has a NULL pointer or M == 0", i);
-    return adam_update_groups(groups, n_groups, visible, b1, b2, eps, N, (hipStream_t)stream);
+    // a group with M == 0 (features_rest [P,0,3] at SH degree 0) is a no-op, as adamUpdate is for an empty tensor (adam.cu:48-52)
+    std::vector<gslic_adam_group> live;
+    live.reserve((size_t)n_groups);
+    for (int i = 0; i < n_groups; i++) {
+        if (groups[i].M == 0) continue;
+        if (!groups[i].param || !groups[i].grad || !groups[i].exp_avg || !groups[i].exp_avg_sq)
+            return set_error(GSLIC_ERR_INVALID_ARG, "adam group %d has a NULL pointer", i);
+        live.push_back(groups[i]);
+    }
+    if (live.empty()) return GSLIC_OK;
+    return adam_update_groups(live.data(), (int)live.size(), visible, b1, b2, eps, N, (hipStream_t)stream);
 }
 
 int gslic_fusedssim_forward(int32_t B, int32_t CH, int32_t H, int32_t W, float C1, float C2, const float* img1, const float* img2,

@@ -59,6 +59,7 @@ enum KernelId {
 void prof_begin(int id, hipStream_t s);
 void prof_end(int id, hipStream_t s);
 extern bool g_prof_on;
+extern int g_strict_math;  // gslic_set_math_mode(): 1 = blend kernels in the reference's arithmetic (render.hip), 0 = fast (default)
 
 #define GS_LAUNCH(id, kernel, grid, block, shmem, stream, ...)                                             \
     do {                                                                                                   \
@@ -94,6 +95,11 @@ static inline uint32_t higher_msb(uint32_t n)
     while (bits < 32 && (n >> bits) != 0) ++bits;
     return bits == 0 ? 1 : bits;
 }
+
+// Device status word of the current device (lazily allocated, zero): bit 0 = a chained-scan / look-back spin-wait gave up (the
+// waits are bounded so that a preempted or debugged device never hangs; the prefix sums of that launch are then wrong and
+// the forward reports GSLIC_ERR_HIP instead of using them).  NULL if the allocation failed.
+uint32_t* device_status_word();
 
 // scan.hip ------------------------------------------------------------------------------------------------
 size_t scan_temp_elems(size_t n);  // u32 elements of scratch needed by scan_u32 for n inputs

@@ -130,6 +130,7 @@ struct SortPassArgs {
     const uint32_t* table;       // classic: scanned [256][nblk] histogram; onesweep: gbase[256] of this pass
     unsigned long long* status;  // onesweep: [nblk][256], zeroed
     uint32_t* ticket;            // onesweep: zeroed
+    uint32_t* timeout;           // onesweep: device status word (bit 0 set when a look-back wait gave up)
 };
 
 template <int NV, bool ONESWEEP>
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_scatter_kernel(const SortPass
                             __builtin_amdgcn_s_sleep(1);
                             sv[j] = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
+                        if ((sv[j] >> 62) == 0ull && a.timeout) atomicOr(a.timeout, 1u);  // gave up: offsets of this pass are wrong
                     }
                     excl += sv[j] & OS_VALUE_MASK;
                     if ((sv[j] >> 62) == 2ull) done = true;
@@ -290,7 +292,7 @@ static int sort_impl(const SortBuffers& b, const SortPlan& plan, void* scratch, 
 {
     const unsigned nblk = (unsigned)plan.nblk;
     SortPassArgs a;
-    a.n = plan.n; a.nblk = nblk; a.status = nullptr; a.ticket = nullptr;
+    a.n = plan.n; a.nblk = nblk; a.status = nullptr; a.ticket = nullptr; a.timeout = onesweep ? device_status_word() : nullptr;
     const size_t ssb = scan_state_bytes(plan.hist_elems);
     uint32_t* hist = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + 4 * ssb);
     unsigned long long* status = reinterpret_cast<unsigned long long*>(scratch);

@@ -52,6 +52,12 @@ __device__ __forceinline__ float strip_max_p2(float hA, float hC, float nB, floa
     return best + 1.0e-5f * (fabsf(hA) * DX * DX + fabsf(hC) * DY * DY + fabsf(nB) * DX * DY) + 1.0e-6f;
 }
 
+// STRICT = the reference's arithmetic operation for operation (forward.cu:424-445: absolute pixel coordinates, power in source
+// order without contraction, exp() of the device library, separately rounded products): with bit-identical records the image,
+// final_T and n_contrib then equal the reference kernels' bit for bit.  The default (fast) variant pre-scales the conic by log2(e),
+// works in tile-relative coordinates and uses v_exp_f32 directly; it differs by rounding only, which flips the alpha < 1/255 /
+// T < 1e-4 decisions of a few (pixel, Gaussian) pairs per million (counted in tests/test_fullsize_reference_gpu.py).
+template <bool STRICT>
 __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
 {
     __shared__ float4 s_rec[3 * GS_BUCKET];
@@ -111,6 +117,14 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
             }
         }
         const float lx = (float)(lane & 15), ly = (float)(lane >> 4);
+        if constexpr (STRICT) {  // raw record: absolute mean, unscaled conic
+            if (lane < m) {
+                const uint32_t g = a.point_list[range.x + (uint32_t)(base + lane)];
+                const float4* rp = a.rec + 3 * (size_t)g;
+                const float4 r0 = rp[0], r1 = rp[1];
+                fdx = r0.x; fdy = r0.y; fhA = r0.z; fnB = r0.w; fhC = r1.x;
+            }
+        }
         // the batch's 64 pre-scaled records are parked in LDS and entry j is fetched with three ds_read_b128 at a wave-uniform
         // address (LDS broadcast; the next entry is in flight while this one is blended): ten v_readlane per entry cost VALU
         // issue slots, which is what bounds this kernel — LDS reads do not
@@ -127,6 +141,28 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
             if (smask == 0u) continue;
             const float gdx = e0.x, gdy = e0.y, hA = e0.z, nB = e0.w, hC = e1.x, op = e1.y, colr = e1.z, colg = e1.w, colb = e2.x;
             const uint32_t contributor = (uint32_t)(base + j + 1);
+            if constexpr (STRICT) {
+#pragma clang fp contract(off)
+                const float dxs = gdx - (float)px;  // float2 d = { xy.x - pixf.x, xy.y - pixf.y } (forward.cu:424)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (!(smask & (1u << q))) continue;  // wave-uniform; conservative (no pixel of the strip reaches alpha >= 1/255)
+                    const float dys = gdy - (float)(pyb + 4 * q);
+                    const float power = -0.5f * (hA * dxs * dxs + hC * dys * dys) - nB * dxs * dys;
+                    const float alpha = fminf(0.99f, op * expf(power));
+                    const float test_T = T[q] * (1 - alpha);
+                    if (!(power > 0.0f) && !(alpha < 1.0f / 255.0f) && T[q] > 0.f) {
+                        if (test_T < 0.0001f) {
+                            T[q] = -T[q];
+                        } else {
+                            Cr[q] += colr * alpha * T[q]; Cg[q] += colg * alpha * T[q]; Cb[q] += colb * alpha * T[q];
+                            T[q] = test_T;
+                            last[q] = contributor;
+                        }
+                    }
+                }
+                continue;
+            }
             const float dx = gdx - lx;
             const float pA = (hA * dx) * dx;   // log2(e) * (-1/2 A dx^2)
             const float pB = nB * dx;          // log2(e) * (-B dx)
@@ -252,7 +288,51 @@ typedef float v4f __attribute__((ext_vector_type(4)));
         }                                                                                                            \
     } while (0)
 
+// The same step with the reference's arithmetic operation for operation (backward.cu:538-581, contraction off, exp() and the
+// IEEE divide of the device library, absolute pixel coordinates): the per-instance sums are then the reference's Register_*
+// values up to the order in which a lane meets its pixels.
+#define GS_BWD_BODY_STRICT()                                                                                         \
+    do {                                                                                                             \
+        if (kcmp < tag) {                                                                                            \
+            _Pragma("clang fp contract(off)")                                                                        \
+            const float pixx = (float)(tx0 + (int)((tag >> 4) & 15u)), pixy = (float)(ty0 + (int)((tag >> 8) & 0xffu)); \
+            const float dx = mabs.x - pixx, dy = mabs.y - pixy;                                                      \
+            const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;                                \
+            const float G = expf(power);                                                                             \
+            const float alpha = fminf(0.99f, op * G);                                                                \
+            if (!(power > 0.0f) && !(alpha < 1.0f / 255.0f)) {                                                       \
+                const float4 gr = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(grec) + (tag & 0xffffu)); \
+                const float T = st.z;                                                                                \
+                const float dchannel_dcolor = alpha * T;                                                             \
+                const float alpha_inverse = 1.0f / (1.0f - alpha);                                                   \
+                float dL_dalpha = 0.0f;                                                                              \
+                st.x += T * alpha * col_rg.x; acc_rg.x += dchannel_dcolor * gr.x;                                    \
+                dL_dalpha += ((col_rg.x * T) - alpha_inverse * (-st.x)) * gr.x;                                      \
+                st.y += T * alpha * col_rg.y; acc_rg.y += dchannel_dcolor * gr.y;                                    \
+                dL_dalpha += ((col_rg.y * T) - alpha_inverse * (-st.y)) * gr.y;                                      \
+                st.w += T * alpha * colb; acc_b += dchannel_dcolor * gr.z;                                           \
+                dL_dalpha += ((colb * T) - alpha_inverse * (-st.w)) * gr.z;                                          \
+                st.z = T * (1.0f - alpha);                                                                           \
+                const float dL_dG = op * dL_dalpha;                                                                  \
+                const float gdx = G * dx, gdy = G * dy;                                                              \
+                const float dG_ddelx = -gdx * cA - gdy * cB;                                                         \
+                const float dG_ddely = -gdy * cC - gdx * cB;                                                         \
+                acc_m.x += dL_dG * dG_ddelx * ddelx_dx;                                                              \
+                acc_m.y += dL_dG * dG_ddely * ddely_dy;                                                              \
+                acc_cxy.x += -0.5f * gdx * dx * dL_dG;                                                               \
+                acc_cxy.y += -0.5f * gdx * dy * dL_dG;                                                               \
+                acc_cw += -0.5f * gdy * dy * dL_dG;                                                                  \
+                acc_op += G * dL_dalpha;                                                                             \
+            }                                                                                                        \
+        }                                                                                                            \
+    } while (0)
+#define GS_BWD_STEP_BODY()                                                                                           \
+    do {                                                                                                             \
+        if constexpr (STRICT) GS_BWD_BODY_STRICT(); else GS_BWD_BODY();                                              \
+    } while (0)
+
 static constexpr int BWD_WAVES = 1;  // buckets (waves) per workgroup
+template <bool STRICT>
 __global__ __launch_bounds__(64 * BWD_WAVES) void render_bwd_kernel(RenderBwdArgs a)
 {
     // per-wave LDS: the pixel records of the whole tile (dL/dpixel, by pixel index) and the current chunk's start states
@@ -287,17 +367,19 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void render_bwd_kernel(RenderBwdArg
 
     const int tx0 = (int)(tile % (uint32_t)a.gx) * GS_TILE, ty0 = (int)(tile / (uint32_t)a.gx) * GS_TILE;
     float cA = 0, cB = 0, cC = 0, op = 0, colb = 0;
-    v2f d0 = {0.f, 0.f}, col_rg = {0.f, 0.f};
+    v2f d0 = {0.f, 0.f}, col_rg = {0.f, 0.f}, mabs = {0.f, 0.f};
     if (valid) {
         const uint32_t g = a.point_list[range.x + kit];
         const float4* rp = a.rec + 3 * (size_t)g;
         const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+        mabs.x = r0.x; mabs.y = r0.y;  // STRICT works on absolute coordinates like the reference
         d0.x = r0.x - (float)tx0; d0.y = r0.y - (float)ty0;
         cA = r0.z; cB = r0.w; cC = r1.x; op = r1.y; col_rg.x = r1.z; col_rg.y = r1.w; colb = r2.x;
     }
     const float LOG2E = 1.4426950408889634f;
     const float hA = -0.5f * LOG2E * cA, hC = -0.5f * LOG2E * cC, nB = -LOG2E * cB;
     const v2f cAC = {cA, cC};
+    const float ddelx_dx = (float)(0.5 * a.W), ddely_dy = (float)(0.5 * a.H);  // backward.cu:464-465
     // pixel tag = rel << 16 | py << 8 | 16 px, rel = min(n_contrib - bucket start, 64): the low half is both the byte offset of the pixel's
     // float4 in grec[] (row stride 256 B) and two bytes v_cvt_f32_ubyte0/1 turn into coordinates; kcmp < tag  <=>  lane < rel
     const uint32_t kcmp = ((uint32_t)lane << 16) | 0xffffu;
@@ -347,14 +429,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void render_bwd_kernel(RenderBwdArg
                 const int sl = __builtin_ctzll(active);
                 active &= active - 1;
                 GS_BWD_SHIFT(sl);
-                GS_BWD_BODY();
+                GS_BWD_STEP_BODY();
             }
             if (!active) break;
             {
                 const int sl = __builtin_ctzll(active);
                 active &= active - 1;
                 GS_BWD_SHIFT(sl);
-                GS_BWD_BODY();
+                GS_BWD_STEP_BODY();
             }
         }
         __builtin_amdgcn_wave_barrier();  // init[] is rewritten by the next chunk only after its last read above
@@ -364,27 +446,35 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void render_bwd_kernel(RenderBwdArg
 #pragma unroll 1
     for (int dr = 1; dr < nvalid; dr++) {
         GS_BWD_SHIFT_ZERO();
-        GS_BWD_BODY();
+        GS_BWD_STEP_BODY();
     }
 
     if (valid) {
-        const float sx = -0.5f * (float)a.W, sy = -0.5f * (float)a.H;  // -(...) * ddelx_dx, ddelx_dx = 0.5 W (backward.cu:464-465)
         float4* o = a.partials + 3 * (size_t)slot;
-        o[0] = make_float4(acc_m.x * sx, acc_m.y * sy, -0.5f * acc_cxy.x, -0.5f * acc_cxy.y);
-        o[1] = make_float4(-0.5f * acc_cw, acc_op, acc_rg.x, acc_rg.y);
+        if constexpr (STRICT) {  // every factor was applied term by term, as the reference does
+            o[0] = make_float4(acc_m.x, acc_m.y, acc_cxy.x, acc_cxy.y);
+            o[1] = make_float4(acc_cw, acc_op, acc_rg.x, acc_rg.y);
+        } else {
+            const float sx = -0.5f * (float)a.W, sy = -0.5f * (float)a.H;  // -(...) * ddelx_dx, ddelx_dx = 0.5 W (backward.cu:464-465)
+            o[0] = make_float4(acc_m.x * sx, acc_m.y * sy, -0.5f * acc_cxy.x, -0.5f * acc_cxy.y);
+            o[1] = make_float4(-0.5f * acc_cw, acc_op, acc_rg.x, acc_rg.y);
+        }
         o[2] = make_float4(acc_b, 0.f, 0.f, 0.f);
     }
 }
 
 int launch_render_fwd(const RenderFwdArgs& a, hipStream_t s)
 {
-    GS_LAUNCH(K_RENDER_FWD, render_fwd_kernel, dim3(a.gx * a.gy), dim3(64), 0, s, a);
+    if (g_strict_math) GS_LAUNCH(K_RENDER_FWD, render_fwd_kernel<true>, dim3(a.gx * a.gy), dim3(64), 0, s, a);
+    else GS_LAUNCH(K_RENDER_FWD, render_fwd_kernel<false>, dim3(a.gx * a.gy), dim3(64), 0, s, a);
     return GSLIC_OK;
 }
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s)
 {
     if (a.B <= 0) return GSLIC_OK;
-    GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel, dim3((a.B + BWD_WAVES - 1) / BWD_WAVES), dim3(64 * BWD_WAVES), 0, s, a);
+    const dim3 grid((a.B + BWD_WAVES - 1) / BWD_WAVES), block(64 * BWD_WAVES);
+    if (g_strict_math) GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel<true>, grid, block, 0, s, a);
+    else GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel<false>, grid, block, 0, s, a);
     return GSLIC_OK;
 }
 

@@ -115,7 +115,7 @@ static constexpr size_t SC_MAX_TILES = 1024;
 
 // state: u32 ticket (in word 0) | u64 words[nb], all zero on entry
 __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32_t* in, const uint32_t* __restrict__ gather, uint32_t* out,
-                                                                    size_t n, int exclusive, unsigned long long* state)
+                                                                    size_t n, int exclusive, unsigned long long* state, uint32_t* status)
 {
     __shared__ uint32_t lds[8];
     __shared__ uint32_t s_tile;
@@ -133,16 +133,31 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32
     const uint32_t excl = block256_exclusive_prefix(sum, total, lds);
     if (threadIdx.x == 0) __hip_atomic_store(words + tile, SC_FLAG | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t acc = 0;
+    unsigned long long acc64 = 0;  // the same sum without wrap-around: a total beyond 2^31 is reported, not silently truncated
     for (uint32_t j = threadIdx.x; j < tile; j += SCAN_THREADS) {
         unsigned long long w = __hip_atomic_load(words + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (uint32_t spins = 0; !(w & SC_FLAG) && spins < (1u << 22); ++spins) {  // bounded: never hang the device
             __builtin_amdgcn_s_sleep(1);
             w = __hip_atomic_load(words + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (!(w & SC_FLAG) && status) atomicOr(status, 1u);  // gave up: the sums of this launch are wrong, tell the host
         acc += (uint32_t)w;
+        acc64 += w & 0xffffffffull;
     }
     uint32_t carry;
     block256_exclusive_prefix(acc, carry, lds);
+    if (status) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc64 += (unsigned long long)__shfl_xor((long long)acc64, d, 64);
+        __shared__ unsigned long long s_sum64[SCAN_THREADS / 64];
+        if ((threadIdx.x & 63) == 0) s_sum64[threadIdx.x >> 6] = acc64;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t64 = total;
+            for (int w2 = 0; w2 < SCAN_THREADS / 64; w2++) t64 += s_sum64[w2];
+            if (t64 > 0x7fffffffull) atomicOr(status, 2u);  // bit 1: prefix sum beyond 2^31
+        }
+    }
     uint32_t run = carry + excl;
     const size_t t0 = base + (size_t)threadIdx.x * SCAN_ITEMS;
     uint32_t o[SCAN_ITEMS];
@@ -220,7 +235,7 @@ int scan_u32_chained(const uint32_t* in, const uint32_t* gather, uint32_t* out, 
         return GSLIC_OK;
     }
     GS_LAUNCH(K_SCAN_APPLY, scan_chained_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, out, n, exclusive ? 1 : 0,
-              reinterpret_cast<unsigned long long*>(zeroed_state));
+              reinterpret_cast<unsigned long long*>(zeroed_state), device_status_word());
     return GSLIC_OK;
 }
 

@@ -58,7 +58,7 @@ class SparseGaussianAdam:
             if only is not None and i not in only:
                 continue
             g = grads[i] if grads is not None else prm.grad
-            if g is None:
+            if g is None or prm.numel() == 0:   # an empty group (features_rest [P,0,3] at SH degree 0) is a no-op, as in the reference
                 continue
             st = self._ensure_state(i)
             g = g.contiguous()

@@ -15,6 +15,7 @@ def build(force=False):
     src = os.path.join(HERE, "gslic_torch_shim.cpp")
     deps = [src, os.path.join(PKG, "..", "include", "gslic_hip.h")] + [os.path.join(HERE, "include", p) for p in
                                                                        ("rasterizer/rasterize_points.h", "fused-ssim/ssim.h", "simple-knn/spatial.h")]
+    deps.append(os.path.join(PKG, "libgslic_hip.so"))
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(d) for d in deps):
         return OUT
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
@@ -32,24 +33,34 @@ def build(force=False):
 
 REF_SRC = "/root/reference/src"
 CHECK = os.path.join(PKG, "dropin_check")
+CHECK_GROUPS = os.path.join(PKG, "dropin_check_groups")
 
 
-def build_dropin_check(force=False):
+def build_dropin_check(force=False, groups=False):
     """Compiles the REFERENCE's own host code (rasterizer/rasterizer.cpp + headers, read in place) together with
     dropin_check.cpp and links it against the shim: the drop-in claim, exercised.  Needs /root/reference; the binary stays
-    in-tree (git-ignored) and travels to the GPU box."""
+    in-tree (git-ignored) and travels to the GPU box.  groups=True builds the same program with shim/include ahead of the
+    reference's src/ on the include path, i.e. with this repo's optim_utils.h (one Adam launch per step) instead of the reference's."""
     if not os.path.isdir(REF_SRC):
         return None
+    if groups:
+        return _build_check(CHECK_GROUPS, ["-I", os.path.join(HERE, "include")], force)
+    return _build_check(CHECK, [], force)
+
+
+def _build_check(CHECK, first_includes, force):
     import sysconfig
     import torch
     from torch.utils import cpp_extension
     src = os.path.join(HERE, "dropin_check.cpp")
-    if not force and os.path.exists(CHECK) and os.path.getmtime(CHECK) > max(os.path.getmtime(src), os.path.getmtime(OUT)):
+    newest = max(os.path.getmtime(src), os.path.getmtime(OUT), os.path.getmtime(os.path.join(HERE, "include", "optim_utils.h")))
+    if not force and os.path.exists(CHECK) and os.path.getmtime(CHECK) > newest:
         return CHECK
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
     cmd = ["g++", "-O1", "-std=c++17", "-w", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
     for inc in cpp_extension.include_paths():
         cmd += ["-isystem", inc]
+    cmd += first_includes
     cmd += ["-isystem", sysconfig.get_paths()["include"], "-I", REF_SRC, src, os.path.join(REF_SRC, "rasterizer", "rasterizer.cpp"),
             "-o", CHECK, "-L", PKG, "-lgslic_torch_shim", "-lgslic_hip", "-Wl,-rpath,$ORIGIN", "-L", tlib, "-ltorch", "-ltorch_cpu",
             "-ltorch_hip", "-lc10", "-lc10_hip", f"-Wl,-rpath,{tlib}", "-Wl,--no-as-needed", "-ltorch_hip", "-Wl,--as-needed",
@@ -64,3 +75,4 @@ def build_dropin_check(force=False):
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
     print(build_dropin_check(force="--force" in sys.argv))
+    print(build_dropin_check(force="--force" in sys.argv, groups=True))

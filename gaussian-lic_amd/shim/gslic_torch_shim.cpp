@@ -12,6 +12,8 @@
 #include <c10/util/Exception.h>
 #include <torch/library.h>
 
+#include <vector>
+
 namespace {
 
 // role of resizeFunctional (rasterize_points.cu:40-48): a byte tensor the library may (re)size once
@@ -122,11 +124,43 @@ void adamUpdate(torch::Tensor& param, torch::Tensor& param_grad, torch::Tensor& 
                 torch::Tensor& visible, const float lr, const float b1, const float b2, const float eps, const uint32_t N,
                 const uint32_t M)
 {
-    at::Tensor vis = visible.contiguous();
-    check(gslic_adam_update(param.contiguous().data_ptr<float>(), param_grad.contiguous().data_ptr<float>(),
-                            exp_avg.contiguous().data_ptr<float>(), exp_avg_sq.contiguous().data_ptr<float>(),
+    // in place on param / exp_avg / exp_avg_sq: a .contiguous() copy of a strided tensor would be updated and thrown away
+    // (the reference takes data_ptr of whatever it is given, rasterize_points.cu:262-272)
+    TORCH_CHECK(param.is_contiguous() && exp_avg.is_contiguous() && exp_avg_sq.is_contiguous(),
+                "adamUpdate: param / exp_avg / exp_avg_sq must be contiguous (they are updated in place)");
+    TORCH_CHECK(param.scalar_type() == at::kFloat && exp_avg.scalar_type() == at::kFloat && exp_avg_sq.scalar_type() == at::kFloat,
+                "adamUpdate: fp32 tensors expected");
+    at::Tensor vis = visible.contiguous(), grad = param_grad.contiguous();
+    check(gslic_adam_update(param.data_ptr<float>(), grad.data_ptr<float>(), exp_avg.data_ptr<float>(), exp_avg_sq.data_ptr<float>(),
                             reinterpret_cast<const uint8_t*>(vis.data_ptr<bool>()), lr, b1, b2, eps, N, M, nullptr),
           "gslic_adam_update");
+}
+
+void adamUpdateGroups(std::vector<torch::Tensor>& params, std::vector<torch::Tensor>& grads, std::vector<torch::Tensor>& exp_avgs,
+                      std::vector<torch::Tensor>& exp_avg_sqs, torch::Tensor& visible, const std::vector<double>& lrs, const float b1,
+                      const float b2, const float eps, const uint32_t N)
+{
+    const size_t n = params.size();
+    TORCH_CHECK(grads.size() == n && exp_avgs.size() == n && exp_avg_sqs.size() == n && lrs.size() == n, "adamUpdateGroups: list sizes differ");
+    if (n == 0 || N == 0) return;
+    std::vector<gslic_adam_group> groups(n);
+    std::vector<at::Tensor> keep;  // contiguous gradient copies (if any) must outlive the launch call
+    keep.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+        TORCH_CHECK(params[i].is_contiguous() && exp_avgs[i].is_contiguous() && exp_avg_sqs[i].is_contiguous(),
+                    "adamUpdateGroups: group ", i, ": param / exp_avg / exp_avg_sq must be contiguous (updated in place)");
+        TORCH_CHECK(params[i].numel() % (int64_t)N == 0, "adamUpdateGroups: group ", i, ": numel is not a multiple of N");
+        keep.push_back(grads[i].contiguous());
+        groups[i].param = params[i].data_ptr<float>();
+        groups[i].grad = keep.back().data_ptr<float>();
+        groups[i].exp_avg = exp_avgs[i].data_ptr<float>();
+        groups[i].exp_avg_sq = exp_avg_sqs[i].data_ptr<float>();
+        groups[i].lr = (float)lrs[i];
+        groups[i].M = (uint32_t)(params[i].numel() / (int64_t)N);
+    }
+    at::Tensor vis = visible.contiguous();
+    check(gslic_adam_update_groups(groups.data(), (int32_t)n, reinterpret_cast<const uint8_t*>(vis.data_ptr<bool>()), b1, b2, eps, N, nullptr),
+          "gslic_adam_update_groups");
 }
 
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>

@@ -30,3 +30,5 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 void adamUpdate(torch::Tensor& param, torch::Tensor& param_grad, torch::Tensor& exp_avg, torch::Tensor& exp_avg_sq,
                 torch::Tensor& visible, const float lr, const float b1, const float b2, const float eps, const uint32_t N,
                 const uint32_t M);
+
+#include "adam_groups.h"

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSLIC_ABI_VERSION 2
+#define GSLIC_ABI_VERSION 3
 
 typedef enum gslic_status {
     GSLIC_OK = 0,
@@ -307,6 +307,14 @@ int gslic_extend_emit(
  */
 int gslic_abi_version(void);
 const char* gslic_last_error(void);
+
+/* Arithmetic of the two blend kernels (process-wide; returns the previous mode).  0 (default) = fast: conic pre-scaled by log2(e),
+ * tile-relative coordinates, v_exp_f32 / v_rcp_f32, fused multiply-adds — results within fp32 rounding of the reference
+ * (forward.cu:424-445, backward.cu:538-581), which flips the alpha < 1/255 and T < 1e-4 decisions of a few (pixel, Gaussian)
+ * pairs per million.  1 = strict: the reference's operations in source order, no contraction, the device library's exp() and
+ * IEEE divide — image / final_T / n_contrib are then bit-identical to the reference kernels compiled for the same GPU
+ * (tests/test_fullsize_reference_gpu.py).  Initial value: environment GSLIC_STRICT_MATH=1. */
+int gslic_set_math_mode(int32_t strict);
 
 /* Sizes the four scratch buffers would need, for hosts that prefer to pre-size (bytes incl. slack). */
 size_t gslic_geom_bytes(int32_t P);

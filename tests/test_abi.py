@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in gslic_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names
-    assert _lib.lib().gslic_abi_version() == 2
+    assert _lib.lib().gslic_abi_version() == 3
 
 
 def test_scratch_sizes_and_errors_without_gpu():
@@ -58,3 +58,25 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgslic_hip.so")
     with pytest.raises(_lib.GslicError):
         _lib.lib()
+
+
+def test_tensor_allocator_is_freed_by_refcount_alone():
+    """The scratch of a forward (~1 GB at 2M Gaussians) must die with the last reference, not whenever the cyclic GC runs:
+    the allocator callback may not close a reference cycle over its owner."""
+    import gc
+    import weakref
+    import torch
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import _lib
+    gc.disable()
+    try:
+        a = _lib.TensorAllocator(torch.device("cpu"))
+        ptr = a.cb(None, 1000)
+        assert ptr == a.tensor.data_ptr() and a.tensor.numel() == 1000
+        big = a.cb(None, (1 << 20) + 1)
+        assert big == a.tensor.data_ptr() and a.tensor.numel() == _lib.TensorAllocator.GRANULE
+        wr_box, wr_alloc = weakref.ref(a._box), weakref.ref(a)
+        del a
+        assert wr_alloc() is None and wr_box() is None
+    finally:
+        gc.enable()

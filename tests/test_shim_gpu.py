@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "gaussian-lic_amd", "libgslic_torch_shim.so")
 CHECK = os.path.join(ROOT, "gaussian-lic_amd", "dropin_check")
+CHECK_GROUPS = os.path.join(ROOT, "gaussian-lic_amd", "dropin_check_groups")
 
 
 def _load_shim():
@@ -91,3 +92,33 @@ def test_reference_host_code_drives_the_hip_kernels(tmp_path):
                     ("dc", model.features_dc), ("rest", model.features_rest)):
         got = rd(name, tuple(t.shape))
         assert rel_err(got, t.detach().cpu().numpy()) < 1e-5, name
+    # the same program compiled against this repo's optim_utils.h (one Adam launch per step through adamUpdateGroups, no
+    # grad.clone()) instead of the reference's (six adamUpdate launches): bit-identical parameters and image
+    if os.path.exists(CHECK_GROUPS):
+        first = {n: rd(n, (-1,)).copy() for n in ("image", "xyz", "scaling", "rotation", "opacity", "dc", "rest")}
+        r = subprocess.run([CHECK_GROUPS, d, str(P), str(W), str(H), "3", str(iters)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        for n, a in first.items():
+            np.testing.assert_array_equal(rd(n, (-1,)), a, err_msg=n)
+
+
+def test_shim_adam_rejects_noncontiguous_state():
+    """adamUpdate works in place on param / exp_avg / exp_avg_sq: a strided view must be refused, not silently updated in a temporary
+    copy (the reference takes data_ptr of whatever it is given, rasterize_points.cu:262-272)."""
+    _load_shim()
+    dev = torch.device("cuda:0")
+    N, M = 64, 3
+    base = torch.randn(N, 2 * M, device=dev)
+    param = base[:, :M]                       # non-contiguous view
+    g, m, v = torch.randn(N, M, device=dev), torch.zeros(N, M, device=dev), torch.zeros(N, M, device=dev)
+    vis = torch.ones(N, dtype=torch.bool, device=dev)
+    with pytest.raises(RuntimeError, match="must be contiguous"):
+        torch.ops.gslic.adamUpdate(param, g, m, v, vis, 1e-3, 0.9, 0.999, 1e-15, N, M)
+    # a non-contiguous GRADIENT is only read: accepted, same result as its contiguous copy
+    p1, p2 = torch.randn(N, M, device=dev), None
+    p2 = p1.clone()
+    gbase = torch.randn(N, 2 * M, device=dev)
+    m1, v1, m2, v2 = (torch.zeros(N, M, device=dev) for _ in range(4))
+    torch.ops.gslic.adamUpdate(p1, gbase[:, :M], m1, v1, vis, 1e-3, 0.9, 0.999, 1e-15, N, M)
+    torch.ops.gslic.adamUpdate(p2, gbase[:, :M].contiguous(), m2, v2, vis, 1e-3, 0.9, 0.999, 1e-15, N, M)
+    assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2)
