@@ -124,7 +124,7 @@ class _AllocBox:
     """What the allocator callback closes over: the device and the tensor it handed out.  Deliberately NOT the TensorAllocator itself —
     a ctypes thunk that referenced a bound method of its owner would form a reference cycle, and the ~1 GB of scratch of a 2M-Gaussian
     step would stay pinned until the cyclic collector happened to run."""
-    __slots__ = ("device", "tensor")
+    __slots__ = ("device", "tensor", "__weakref__")
 
     def __init__(self, device):
         self.device = device
