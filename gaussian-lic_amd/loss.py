@@ -93,16 +93,23 @@ def ssim(img1, img2, window_size=11, size_average=True):
     return ssim_map.mean() if size_average else ssim_map.mean(1).mean(1).mean(1)
 
 
-def evaluate_visual_quality(model, cameras, gt_images, bg):
+def evaluate_visual_quality(model, cameras, gt_images, bg, fused=True):
     """PSNR / SSIM over a set of views — the metric part of evaluateVisualQuality (gaussian.cpp:751-789): render, clamp to [0,1],
-    psnr + conv-SSIM per image, averaged.  (LPIPS needs the TorchScript AlexNet blob the reference does not ship.)"""
+    psnr + SSIM per image, averaged over the views.  fused=True evaluates the SSIM map with the fused-SSIM kernel
+    (gslic_fusedssim_forward, train = 0: the same 11-tap sigma-1.5 window with zero padding as loss_utils.h:41-128, separable, one
+    launch) instead of five LibTorch conv2d calls; fused=False is the reference's formulation verbatim.  Returns device scalars
+    (mean PSNR, mean SSIM).  (LPIPS needs the TorchScript AlexNet blob the reference does not ship.)"""
     from .rasterizer import render
     ps, ss = [], []
     with torch.no_grad():
         for cam, gt in zip(cameras, gt_images):
             img = torch.clamp(render(cam, model, bg)[0], 0.0, 1.0)
+            gt = torch.clamp(gt, 0.0, 1.0)                      # gaussian.cpp:759
             ps.append(psnr(img, gt))
-            ss.append(ssim(img.unsqueeze(0), gt.unsqueeze(0)))
+            if fused:
+                ss.append(fusedssim(C1, C2, img.unsqueeze(0).contiguous(), gt.unsqueeze(0).contiguous(), False)[0].mean())
+            else:
+                ss.append(ssim(img.unsqueeze(0), gt.unsqueeze(0)))
     return torch.stack(ps).mean(), torch.stack(ss).mean()
 
 

@@ -70,6 +70,30 @@ def main(outdir):
     np.savez_compressed(os.path.join(outdir, "adam_500x45.npz"), p=p, g=g, m=m, v=v, vis=vis, p1=p1, m1=m1, v1=v1, lr=np.float32(2.5e-3))
     print("adam ok")
     ssim_golden(rk, outdir)
+    knn_golden(rk, outdir)
+
+
+def knn_points(P, seed):
+    """LiDAR-like cloud (clustered depths, the shape GaussianModel::initialize feeds distCUDA2, gaussian.cpp:261) as exact fp32."""
+    rng = np.random.default_rng(seed)
+    d = rng.uniform(2.0, 40.0, P)
+    slope = rng.uniform(-0.7, 0.7, (P, 2))          # only IEEE multiplications below: bit-reproducible on every platform
+    pts = np.stack([d * slope[:, 0], d * slope[:, 1], d], 1)
+    return np.ascontiguousarray(pts, np.float32)
+
+
+KNN_CASES = [("knn_100096", 100096, 31), ("knn_1500", 1500, 32), ("knn_3", 3, 33)]   # the initialisation size; one partial box; < 4 points
+
+
+def knn_golden(rk, outdir):
+    """simple-knn golden vectors from the reference's own kernels (simple_knn.cu through oracle/ref_build/wrap_knn.hip).  The points
+    are regenerated from the seed by knn_points() (numpy Generator streams are platform-independent; fp32 after the cast)."""
+    for name, P, seed in KNN_CASES:
+        pts = knn_points(P, seed)
+        out = rk.knn(pts)
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), P=P, seed=seed, points_sha=np.array(hashlib.sha256(pts.tobytes()).hexdigest()),
+                            mean_dist2=out)
+        print(name, "mean", float(out[np.isfinite(out)].mean()) if np.isfinite(out).any() else None, flush=True)
 
 
 SSIM_CASES = [("ssim_1x3x70x50", 1, 3, 50, 70, 21),      # ragged: neither side a multiple of the 32x32 block
@@ -92,9 +116,9 @@ def ssim_golden(rk, outdir):
 
 if __name__ == "__main__":
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "golden")
-    if len(sys.argv) > 2 and sys.argv[2] == "ssim":   # only the fused-SSIM vectors
+    if len(sys.argv) > 2 and sys.argv[2] in ("ssim", "knn"):   # only the fused-SSIM / simple-knn vectors
         from oracle.ref_build.refkernels import RefKernels
         os.makedirs(out, exist_ok=True)
-        ssim_golden(RefKernels(), out)
+        (ssim_golden if sys.argv[2] == "ssim" else knn_golden)(RefKernels(), out)
     else:
         main(out)

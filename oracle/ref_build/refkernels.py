@@ -97,3 +97,11 @@ class RefKernels:
         assert rc == 0
         return out
 
+    def knn(self, points):
+        """The reference's SimpleKNN::knn (simple_knn.cu:185-221, compiled through wrap_knn.hip): points [P,3] -> mean of the three
+        smallest squared distances to the other points, [P]."""
+        pts = np.ascontiguousarray(points, np.float32)
+        out = np.zeros(pts.shape[0], np.float32)
+        rc = self.lib.ref_knn(int(pts.shape[0]), _p(pts), _p(out))
+        assert rc == 0
+        return out

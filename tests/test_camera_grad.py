@@ -51,7 +51,8 @@ def test_oracle_camera_gradient_matches_finite_differences(oracle64):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("P,W,H,deg,seed", [(3000, 160, 120, 3, 3), (20000, 320, 240, 3, 8), (5000, 70, 50, 0, 9)])
+@pytest.mark.parametrize("P,W,H,deg,seed", [(3000, 160, 120, 3, 3), (20000, 320, 240, 3, 8), (5000, 70, 50, 0, 9),
+                                             (60, 64, 48, 0, 4), (40, 64, 48, 1, 5)])   # P < 64 on the generic path: the partial rows used to overlap the outputs
 def test_hip_camera_gradient_matches_oracle(oracle32, P, W, H, deg, seed):
     from gpu_helpers import hip_forward
     from gaussian_lic_amd import rasterizer as rz

@@ -86,3 +86,38 @@ def test_hip_ssim_matches_golden():
         assert rel_err(got.cpu().numpy(), z[key]) < 1e-4
     g = loss.fusedssim_backward(0.01 ** 2, 0.03 ** 2, ta, tb, tdl, d1, d2, d3)
     assert rel_err(g.cpu().numpy(), z["dL_dimg1"]) < 1e-4
+
+
+@pytest.mark.parametrize("P,seed", [(100096, 31), (1500, 32), (5, 34)])
+def test_hip_knn_matches_reference_kernels(P, seed):
+    """distCUDA2 of the HIP path against the reference's own SimpleKNN::knn (simple_knn.cu:185-221 through wrap_knn.hip) on the same
+    MI355X, same points: exact 3-NN on both sides, so only the rounding of the three squared distances may differ."""
+    import torch
+    from gaussian_lic_amd import knn
+    from oracle.ref_build.make_golden import knn_points
+    rk = _ref()
+    pts = knn_points(P, seed)
+    ref = rk.knn(pts)
+    got = knn.distCUDA2(torch.from_numpy(pts).to("cuda:0")).cpu().numpy()
+    err = np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-30)
+    print(f"\nknn P={P}: max rel err {err.max():.2e}, elements over 1e-5: {int((err > 1e-5).sum())}")
+    assert err.max() < 1e-5
+
+
+def test_hip_knn_matches_golden():
+    import os
+    import torch
+    from gaussian_lic_amd import knn
+    from oracle.ref_build.make_golden import KNN_CASES, knn_points
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, P, seed in KNN_CASES:
+        path = os.path.join(gdir, name + ".npz")
+        if not os.path.exists(path):
+            pytest.skip(f"{name}.npz not generated yet")
+        z = np.load(path)
+        got = knn.distCUDA2(torch.from_numpy(knn_points(P, seed)).to("cuda:0")).cpu().numpy()
+        ref = z["mean_dist2"]
+        if P < 4:
+            assert np.all(~np.isfinite(got) | (got > 1e37)) and np.all(~np.isfinite(ref) | (ref > 1e37))
+        else:
+            assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-5 and (np.abs(got - ref) / np.maximum(ref, 1e-30)).max() < 1e-5
