@@ -8,16 +8,17 @@ Bars (fp32, relative to the tensor's max-abs):
                    logf, <= 1 ulp; this library with a fixed polynomial) and the per-tile lists are bit-exact once those
                    Gaussians are removed from both sides; means2D / depth / conic / opacity bit-exact
   strict mode      image, final_T and n_contrib BIT-IDENTICAL to the reference kernels; gradients <= 1e-4 with ZERO elements over
-  fast mode        <= FAST_OVER_PPM elements per million over 1e-4 (threshold flips of alpha < 1/255 / T < 1e-4, each bounded by
-                   one contribution), none over FLIP_BOUND
+  fast mode        <= FAST_OVER_PPM elements per million over 1e-4.  Every one is a flipped hard cut of the blend: `alpha < 1/255`
+                   (forward.cu:437) or `T (1 - alpha) < 1e-4` (:439), worth at most 1/255 of the colour scale, or — rarer — the sign
+                   of a `power > 0` (:431) that is zero up to rounding (near-singular conic along d), worth a whole contribution.
+                   Measured (profiles/r02_parity_fullsize.json): 2M/1080p 5 of 6.2M colour values, 5M/4K 37 of 24.9M; no gradient
+                   tensor has more than 2 ppm over.  The maximum is printed, not bounded, for this mode.
 Skipped when the checker library was not built (it is built wherever /root/reference is mounted and travels with the snapshot)."""
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-FAST_OVER_PPM = 20.0     # measured: see profiles/r02_parity_fullsize.json
-FLIP_BOUND_IMG = 6e-3    # 1.5/255 of the colour scale: one dropped / added contribution
-FLIP_BOUND_GRAD = 2e-2
+FAST_OVER_PPM = 10.0     # measured <= 2.6 ppm on every tensor of every config: profiles/r02_parity_fullsize.json
 
 
 def _need_ref():
@@ -49,5 +50,4 @@ def test_fullsize_matches_reference_kernels(name):
     st = res["fast"]
     for k in ("color", "final_T") + GRADS:
         assert st[k]["over"] <= max(4, FAST_OVER_PPM * 1e-6 * st[k]["n"]), (k, st[k])
-        assert st[k]["max_rel"] <= (FLIP_BOUND_IMG if k in ("color", "final_T") else FLIP_BOUND_GRAD), (k, st[k])
-    assert st["n_contrib_mismatch"] <= 2e-3 * st["pixels"]
+    assert st["n_contrib_mismatch"] <= max(4, FAST_OVER_PPM * 1e-6 * st["pixels"])
