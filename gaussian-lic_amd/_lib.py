@@ -39,7 +39,7 @@ EXPORTS = [
     "gslic_last_error", "gslic_geom_bytes", "gslic_img_bytes", "gslic_binning_bytes", "gslic_sample_bytes",
     "gslic_profile_enable", "gslic_profile_reset", "gslic_profile_collect", "gslic_profile_num_kernels",
     "gslic_profile_kernel_name", "gslic_profile_get", "gslic_debug_export", "gslic_extend_select", "gslic_extend_emit", "gslic_loss_partials_count", "gslic_l1_ssim_loss_forward",
-    "gslic_l1_ssim_loss_backward", "gslic_set_math_mode", "gslic_set_bwd_chain",
+    "gslic_l1_ssim_loss_backward", "gslic_set_math_mode",
 ]
 
 _lib = None
@@ -92,7 +92,6 @@ def lib():
     L.gslic_l1_ssim_loss_forward.argtypes = [i32, i32, i32, i32, f32, f32] + [vp] * 7 + [vp]
     L.gslic_l1_ssim_loss_backward.argtypes = [i32, i32, i32, i32, f32] + [vp] * 6 + [vp]
     L.gslic_set_math_mode.argtypes = [i32]
-    L.gslic_set_bwd_chain.argtypes = [i32]
     if L.gslic_abi_version() != 3:
         raise GslicError("libgslic_hip.so ABI version mismatch")
     _lib = L
@@ -103,11 +102,6 @@ def set_math_mode(strict):
     """gslic_set_math_mode: True = the blend kernels in the reference's arithmetic (bit-identical image), False = fast (default).
     Returns the previous mode."""
     return bool(lib().gslic_set_math_mode(int(bool(strict))))
-
-
-def set_bwd_chain(k):
-    """gslic_set_bwd_chain: buckets chained per wave in the backward blend kernel (results do not depend on it).  Returns the previous value."""
-    return int(lib().gslic_set_bwd_chain(int(k)))
 
 
 def check(rc):

@@ -267,7 +267,6 @@ using namespace gslic;
 extern "C" {
 
 int gslic_abi_version(void) { return GSLIC_ABI_VERSION; }
-int gslic_set_bwd_chain(int32_t buckets_per_wave) { return set_bwd_chain(buckets_per_wave); }
 int gslic_set_math_mode(int32_t strict)
 {
     const int old = g_strict_math;

@@ -62,7 +62,6 @@ struct RenderBwdArgs {
     float4* partials;
 };
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
-int set_bwd_chain(int k);  // buckets per wave of the chained backward (k <= 0: query only); returns the previous value
 
 struct AdamFusedArgs {
     float *p[6], *m[6], *v[6];  // xyz, features_dc, features_rest, opacity, scaling, rotation

@@ -403,377 +403,201 @@ __global__ __launch_bounds__(64) void render_bwd_strict_kernel(RenderBwdArgs a)
 }
 
 // =========================================================================================================
-// Backward, default (fast) variant: CHAINED buckets.  A wave takes `chain` consecutive global buckets and keeps the 64-deep pipeline
-// full across their boundaries: between the pixels of bucket k and those of bucket k+1 (same tile) it injects one MARKER; the lane a
-// marker reaches stores its nine sums, zeroes them and takes its next Gaussian's parameters from an LDS staging ring — so the 63 drain
-// steps are paid once per run of buckets instead of once per bucket (profiles/r02_bwd_pipeline_model.txt: -18 % steps at chain = 8
-// on the 2M / 1080p scene), and the per-instance results do not depend on `chain` at all (bit-identical for every value).
+// Backward, default (fast) variant: ONE WAVE PER BUCKET, lane = Gaussian, the tile's pixels stream through the lanes.
 //
 // What travels lane -> lane+1 is {T, A, tag}: A = sum_ch ar[ch] * dL/dpixel[ch] replaces the colour vector ar[3] of the reference's
-// formulation (dL/dalpha only ever needs that dot product: dL/dalpha = A' / (1 - alpha) + T * (c . g), A' = A + T alpha (c . g)),
-// three DPP moves per step instead of five.  alpha = min(0.99, exp2(p2 + log2 opacity)) with the SAME operation sequence as
-// render_fwd (identical bits on both sides, so both make the same alpha < 1/255 decisions); the products with G = exp(power) that the
-// reference forms are written on a = opacity * G, and dL/dopacity is divided by the opacity once per instance.
+// formulation (dL/dalpha only ever needs that dot product: dL/dalpha = A' / (1 - alpha) + T (c . g), A' = A + T alpha (c . g)): three
+// DPP moves per step instead of five.  alpha = min(0.99, exp2(p2 + log2 opacity)) with the SAME operation sequence as render_fwd
+// (identical bits on both sides, so both take the same alpha < 1/255 decisions); the products with G = exp(power) that the reference
+// forms are written on a = opacity * G, dL/dopacity is divided by the opacity once per instance, and the conic factors of dL/dmean2D
+// (per-Gaussian constants) are applied once to sum w d instead of in every step.
 //
-// tag = rel << 16 | py << 8 | 16 px for a pixel (rel = min(n_contrib - bucket start, 64) >= 1: the low half is the byte offset of the
-// pixel's float4 in grec[] and two bytes v_cvt_f32_ubyte0/1 turn into coordinates), 0 for an empty slot, 0x80000000 | ring offset for a
-// marker; the comparisons are signed, so `kcmp < tag` (lane < rel) is false for markers and `tag < 0` finds them.
+// The step is STRAIGHT-LINE code: no exec-mask branches.  A (pixel, Gaussian) pair that does not blend (lane >= rel, power > 0,
+// alpha < 1/255, empty slot) runs the same instructions with alpha and w forced to zero, which leaves every sum and the travelling
+// state unchanged bit for bit.  Measured on gfx950 (tools/ubench/issue_rate): a wave64 VALU instruction issues every 2.1-2.4 cycles
+// when all its operands are VGPRs, every 4.2 with an SGPR / literal operand, as a DPP move or as a packed op, every 8 for v_exp / v_rcp,
+// and one wave alone issues at most every 4.3 cycles — so the per-step cost is set by the dependent chain of each wave (SALU, taken
+// branches, LDS round trips) as much as by the VALU count: branch-free, the pixel's constants are fetched from LDS at the top of the
+// step, the next injection is fetched one step ahead and enters through the DPP's `old` operand, and the loop constants live in VGPRs.
+//
+// tag = rel << 16 | py << 8 | 16 px (rel = min(n_contrib - bucket start, 64) >= 1 for an injected pixel: the low half is the byte offset
+// of the pixel's float4 in grec[] and two bytes v_cvt_f32_ubyte0/1 turn into coordinates), 0 for an empty slot; kcmp < tag <=> lane < rel.
 struct BwdLane {
     v2f d0, hAC, col_rg;          // centre relative to the tile origin; log2(e)-scaled conic diagonal {-1/2 A, -1/2 C}; colour r, g
-    float nB, lop, colb, rop;     // log2(e)-scaled -B; log2(opacity); colour b; 1 / opacity (0 for an empty lane)
-    uint32_t slot;                // emission slot the sums go to; 0xffffffff: this lane holds no Gaussian
+    float nB, lop, colb;          // log2(e)-scaled -B; log2(opacity); colour b
 };
 
-static constexpr int CH_RING = 1;  // parameter staging slots (three float4 columns of 64 lanes each): LDS per wave decides the occupancy here
-
-// Injection: the entry of the NEXT step is fetched one step ahead (every lane reads the same LDS address: a broadcast) and enters at
-// lane 0 through the DPP's `old` operand (lane 0 has no source lane and bound_ctrl is off, so it keeps `old`): no exec-mask
-// juggling, and the LDS round trip is off the step's critical path.
-#define GS_CH_PREFETCH(NST, NTAG, sl)                                                                                \
+// DST <- shift(SRC) with lane 0 <- INJ.  The DPP's destination is the register that held the injected value, so two steps per trip
+// with the roles of the two register sets swapped need no copies at all.
+#define GS_BW_SHIFT_INJ(DST, DTAG, INJ, ITAG, SRC, STAG)                                                             \
     do {                                                                                                             \
+        DST.x = shift_old_f(INJ.x, SRC.x); DST.y = shift_old_f(INJ.y, SRC.y);                                        \
+        DTAG = (uint32_t)shift_old_i((int32_t)ITAG, (int32_t)STAG);                                                  \
+    } while (0)
+#define GS_BW_PREFETCH(NST, NTAG, sl)                                                                                \
+    do { /* every lane reads the same LDS address: a broadcast, no exec-mask juggling */                             \
         NST = *reinterpret_cast<const v2f*>(&init[sl]);                                                              \
         NTAG = itags[sl];                                                                                            \
     } while (0)
-// DST <- shift(SRC) with lane 0 <- INJ.  The DPP's destination is the register that held the injected value, so two steps per trip
-// with the roles of the two register sets swapped need no copies at all.
-#define GS_CH_SHIFT_INJ(DST, DTAG, INJ, ITAG, SRC, STAG)                                                             \
+#define GS_BW_BODY(ST, TAG)                                                                                          \
     do {                                                                                                             \
-        DST.x = shift_old_f(INJ.x, SRC.x); DST.y = shift_old_f(INJ.y, SRC.y);                                        \
-        DTAG = shift_old_i(ITAG, STAG);                                                                              \
-        ++step;                                                                                                      \
+        const float4 gr = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(grec) + (TAG & 0xffffu));   \
+        const v2f pxy16 = {(float)(TAG & 0xffu), (float)((TAG >> 8) & 0xffu)}; /* v_cvt_f32_ubyte0 / ubyte1: {16 px, py} */ \
+        const v2f d = GS_PK_FMA(pxy16, kneg, L.d0); /* exact: d0 - {px, py} */                                       \
+        float p2 = __builtin_fmaf(L.hAC.x * d.x, d.x, L.lop); /* the operation sequence of render_fwd */             \
+        p2 = __builtin_fmaf(L.hAC.y * d.y, d.y, p2);                                                                 \
+        p2 = __builtin_fmaf(L.nB * d.x, d.y, p2); /* = log2(e) * power + log2(opacity) */                            \
+        const float araw = __builtin_amdgcn_exp2f(p2); /* opacity * G */                                             \
+        const float amin = fminf(c099, araw);                                                                        \
+        /* lane < n_contrib - bucket start (backward.cu:538), power <= 0, alpha >= 1/255 (:543-546) */               \
+        const bool hit = (kcmp < TAG) & !(p2 > L.lop) & !(amin < c255);                                              \
+        const float alpha = hit ? amin : 0.0f;                                                                       \
+        const float om = 1.0f - alpha;                                                                               \
+        const float rinv = __builtin_amdgcn_rcpf(om);                                                                \
+        const float Ta = ST.x * alpha;                                                                               \
+        float cg = L.col_rg.x * gr.x;                                                                                \
+        cg = __builtin_fmaf(L.col_rg.y, gr.y, cg);                                                                   \
+        cg = __builtin_fmaf(L.colb, gr.z, cg); /* c . dL/dpixel */                                                   \
+        acc_rg = GS_PK_FMA(GS_SPLAT(Ta), ((v2f){gr.x, gr.y}), acc_rg); acc_b = __builtin_fmaf(Ta, gr.z, acc_b);      \
+        ST.y = __builtin_fmaf(Ta, cg, ST.y);                                                                         \
+        const float dLda = __builtin_fmaf(rinv, ST.y, ST.x * cg);                                                    \
+        ST.x *= om;                                                                                                  \
+        const float w = hit ? araw * dLda : 0.0f; /* opacity * G * dL/dalpha = G * dL/dG */                          \
+        const v2f wd = GS_SPLAT(w) * d;                                                                              \
+        acc_S += wd;                                                                                                 \
+        acc_cxy = GS_PK_FMA(GS_SPLAT(wd.x), d, acc_cxy); /* -0.5 applied at the end */                               \
+        acc_cw = __builtin_fmaf(wd.y, d.y, acc_cw);                                                                  \
+        acc_op += w; /* divided by the opacity at the end */                                                         \
     } while (0)
-#define GS_CH_SHIFT_ZERO()                                                                                           \
-    do {                                                                                                             \
-        st.x = shift_zero_f(st.x); st.y = shift_zero_f(st.y);                                                        \
-        tag = (int32_t)shift_zero_u((uint32_t)tag);                                                                  \
-        ++step;                                                                                                      \
-    } while (0)
-// a marker has arrived: this lane's bucket is complete
-#define GS_CH_SWITCH(TAG)                                                                                            \
-    do {                                                                                                             \
-        if (__builtin_expect(TAG < 0, 0)) {                                                                          \
-            float4* cell = reinterpret_cast<float4*>(reinterpret_cast<char*>(&prm[0][0][0]) + ((uint32_t)TAG & 0xffffu)); \
-            const BwdLane done = L;                                                                                  \
-            bwd_take(L, cell, lane);                                                                                 \
-            bwd_park(cell, lane, done, acc_S, acc_cxy, acc_rg, acc_cw, acc_op, acc_b, kx, ky);                       \
-            acc_S = acc_cxy = acc_rg = (v2f){0.f, 0.f}; acc_cw = acc_op = acc_b = 0.f;                               \
-        }                                                                                                            \
-    } while (0)
-#define GS_CH_BODY(ST, TAG)                                                                                          \
-    do {                                                                                                             \
-        if (__builtin_expect(kcmp < TAG, 1)) { /* lane < n_contrib - bucket start: this Gaussian precedes the pixel's last one (backward.cu:538) */ \
-            const uint32_t utag = (uint32_t)TAG;                                                                     \
-            const float4 gr = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(grec) + (utag & 0xffffu)); \
-            const v2f pxy16 = {(float)(utag & 0xffu), (float)((utag >> 8) & 0xffu)}; /* v_cvt_f32_ubyte0 / ubyte1: {16 px, py} */ \
-            const v2f d = GS_PK_FMA(pxy16, ((v2f){-0.0625f, -1.0f}), L.d0); /* exact: d0 - {px, py} */               \
-            float p2 = __builtin_fmaf(L.hAC.x * d.x, d.x, L.lop); /* the operation sequence of render_fwd */         \
-            p2 = __builtin_fmaf(L.hAC.y * d.y, d.y, p2);                                                             \
-            p2 = __builtin_fmaf(L.nB * d.x, d.y, p2); /* = log2(e) * power + log2(opacity) */                        \
-            const float araw = __builtin_amdgcn_exp2f(p2); /* opacity * G */                                         \
-            const float alpha = fminf(0.99f, araw);                                                                  \
-            if (__builtin_expect(!(p2 > L.lop) && !(alpha < (1.0f / 255.0f)), 1)) {                                  \
-                const v2f grxy = {gr.x, gr.y};                                                                       \
-                const float om = 1.0f - alpha;                                                                       \
-                const float rinv = __builtin_amdgcn_rcpf(om);                                                        \
-                const float Ta = ST.x * alpha;                                                                       \
-                float cg = L.col_rg.x * gr.x;                                                                        \
-                cg = __builtin_fmaf(L.col_rg.y, gr.y, cg);                                                           \
-                cg = __builtin_fmaf(L.colb, gr.z, cg); /* c . dL/dpixel */                                           \
-                acc_rg = GS_PK_FMA(GS_SPLAT(Ta), grxy, acc_rg); acc_b = __builtin_fmaf(Ta, gr.z, acc_b);             \
-                ST.y = __builtin_fmaf(Ta, cg, ST.y);                                                                 \
-                const float dLda = __builtin_fmaf(rinv, ST.y, ST.x * cg);                                            \
-                ST.x *= om;                                                                                          \
-                const float w = araw * dLda; /* opacity * G * dL/dalpha = G * dL/dG */                               \
-                const v2f wd = GS_SPLAT(w) * d;                                                                      \
-                acc_S += wd; /* the conic factors of dL/dmean2D are per-Gaussian constants: applied once, at the end */ \
-                acc_cxy = GS_PK_FMA(GS_SPLAT(wd.x), d, acc_cxy); /* -0.5 applied at the end */                       \
-                acc_cw = __builtin_fmaf(wd.y, d.y, acc_cw);                                                          \
-                acc_op += w; /* divided by the opacity at the end */                                                 \
-            }                                                                                                        \
-        }                                                                                                            \
-    } while (0)
-#define GS_CH_STEP_IDLE()   do { GS_CH_SHIFT_ZERO(); GS_CH_SWITCH(tag); GS_CH_BODY(st, tag); } while (0)
 
-// sums of one instance -> its emission slot.  acc_S = sum of w d (w = G dL/dG): dL/dmean2D = -(0.5 W, 0.5 H) o (A S.x + B S.y, C S.y + B S.x)
-// (backward.cu:566-573), written on the log2(e)-scaled conic the lane holds: A = -2 hA / log2 e, B = -nB / log2 e; kx = 0.5 W / log2 e.
-__device__ __forceinline__ void bwd_store(float4* partials, const BwdLane& L, v2f acc_S, v2f acc_cxy, v2f acc_rg, float acc_cw, float acc_op,
-                                          float acc_b, float kx, float ky)
+__global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
 {
-    if (L.slot != 0xffffffffu) {
-        float4* o = partials + 3 * (size_t)L.slot;
+    __shared__ float4 grec[GS_TILE_PIX];   // dL/dpixel of the tile, by pixel index
+    __shared__ float2 init[64];            // start state {T, A} of the current chunk's pixels
+    __shared__ uint32_t itags[64];
+    const int lane = threadIdx.x;
+    const uint32_t bucket = blockIdx.x;
+    const uint32_t tile = a.bucket_to_tile[bucket];
+    const uint2 range = a.ranges[tile];
+    const uint32_t n = range.y - range.x;
+    const uint32_t bbm = (tile == 0) ? 0u : a.bucket_offsets[tile - 1];
+    const uint32_t bstart = (bucket - bbm) * GS_BUCKET;
+    const uint32_t kit = bstart + (uint32_t)lane;  // splat index in tile
+    const bool valid = kit < n;
+    const uint32_t slot = valid ? a.inst_slot[range.x + kit] : 0u;
+
+    // bucket entirely behind every pixel's last contributor (backward.cu:428): gradients are exactly zero
+    if (bstart >= a.max_contrib[tile]) {
+        if (valid) {
+            float4* o = a.partials + 3 * (size_t)slot;
+            o[0] = o[1] = o[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+
+    const int tx0 = (int)(tile % (uint32_t)a.gx) * GS_TILE, ty0 = (int)(tile / (uint32_t)a.gx) * GS_TILE;
+    const float LOG2E = 1.4426950408889634f;
+    BwdLane L;
+    L.d0 = L.hAC = L.col_rg = (v2f){0.f, 0.f};
+    L.nB = L.colb = 0.f;
+    L.lop = -__builtin_inff();  // a lane without a Gaussian: alpha = exp2(-inf) = 0, never blends
+    float rop = 0.f;            // 1 / opacity
+    if (valid) {
+        const uint32_t g = a.point_list[range.x + kit];
+        const float4* rp = a.rec + 3 * (size_t)g;
+        const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+        L.d0.x = r0.x - (float)tx0; L.d0.y = r0.y - (float)ty0;
+        L.hAC.x = -0.5f * LOG2E * r0.z; L.nB = -LOG2E * r0.w; L.hAC.y = -0.5f * LOG2E * r1.x;
+        rop = r1.y > 0.f ? 1.0f / r1.y : 0.f; L.lop = __builtin_amdgcn_logf(r1.y);
+        L.col_rg.x = r1.z; L.col_rg.y = r1.w; L.colb = r2.x;
+    }
+    // loop constants in VGPRs: a literal or SGPR operand doubles the issue cost of the instruction that reads it
+    float c099 = 0.99f, c255 = 1.0f / 255.0f;
+    v2f kneg = {-0.0625f, -1.0f};
+    uint32_t kcmp = ((uint32_t)lane << 16) | 0xffffu;
+    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(kneg), "+v"(kcmp));
+    v2f acc_S = {0.f, 0.f}, acc_cxy = {0.f, 0.f}, acc_rg = {0.f, 0.f};
+    float acc_cw = 0, acc_op = 0, acc_b = 0;
+    const size_t plane = (size_t)a.H * a.W;
+
+    v2f st = {0.f, 0.f}, nst = {0.f, 0.f};  // {T, A}: the state travelling through the lanes, and the injection fetched one step ahead
+    uint32_t tag = 0, ntag = 0;
+
+    // 64-pixel feed chunk (register double buffer: chunk c+1 is in flight while chunk c streams through)
+    float4 ck, pf;
+    float fg0, fg1, fg2;
+    bool inside;
+    auto load_chunk = [&](int c) {
+        const int pidx = c * 64 + lane;
+        ck = a.ckpt[(size_t)bucket * GS_TILE_PIX + pidx];
+        pf = a.pix_final[(size_t)tile * GS_TILE_PIX + pidx];
+        const int px = tx0 + (pidx & 15), py = ty0 + (pidx >> 4);
+        inside = px < a.W && py < a.H;
+        fg0 = fg1 = fg2 = 0.f;
+        if (inside) {
+            const size_t pid = (size_t)py * a.W + px;
+            fg0 = a.dL_dpix[pid]; fg1 = a.dL_dpix[plane + pid]; fg2 = a.dL_dpix[2 * plane + pid];
+        }
+    };
+    load_chunk(0);
+#pragma unroll 1
+    for (int c = 0; c < 4; c++) {
+        // park this chunk in LDS, then start the next chunk's global loads
+        const uint32_t ncp = inside ? __float_as_uint(pf.w) : 0u;
+        const uint32_t pidx = (uint32_t)(c * 64 + lane);
+        const uint32_t rel = ncp > bstart ? (ncp - bstart < 64u ? ncp - bstart : 64u) : 0u;
+        float A0 = (ck.y - pf.x) * fg0;  // ar = checkpoint colour - final colour (backward.cu:522-523), dotted with dL/dpixel
+        A0 = __builtin_fmaf(ck.z - pf.y, fg1, A0);
+        A0 = __builtin_fmaf(ck.w - pf.z, fg2, A0);
+        __builtin_amdgcn_wave_barrier();  // the previous chunk's last read of init[] / itags[] precedes these writes
+        grec[pidx] = make_float4(fg0, fg1, fg2, 0.f);
+        init[lane] = make_float2(ck.x, A0);
+        itags[lane] = (rel << 16) | ((pidx >> 4) << 8) | ((pidx & 15u) << 4);
+        uint64_t active = __ballot(ncp > bstart);  // pixels that reach this bucket; the others contribute nothing here
+        if (c < 3) load_chunk(c + 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (active) {
+            // two steps per trip.  Register sets: on entry (st, tag) holds the state and (nst, ntag) the fetched injection; inside, (st2, tag2)
+            // is the state after the first step (in the registers of nst / ntag) and (nst2, ntag2) the second injection (in those of st / tag)
+            GS_BW_PREFETCH(nst, ntag, __builtin_ctzll(active));
+            for (;;) {
+                v2f st2, nst2;
+                uint32_t tag2, ntag2;
+                active &= active - 1;
+                GS_BW_SHIFT_INJ(st2, tag2, nst, ntag, st, tag);
+                GS_BW_PREFETCH(nst2, ntag2, __builtin_ctzll(active | (1ull << 63)));  // (nothing left: a harmless read of entry 63)
+                GS_BW_BODY(st2, tag2);
+                if (!active) { st = st2; tag = tag2; break; }
+                active &= active - 1;
+                GS_BW_SHIFT_INJ(st, tag, nst2, ntag2, st2, tag2);
+                GS_BW_PREFETCH(nst, ntag, __builtin_ctzll(active | (1ull << 63)));
+                GS_BW_BODY(st, tag);
+                if (!active) break;
+            }
+        }
+    }
+    // drain: the last injected pixel still has to pass the bucket's remaining (valid) lanes
+    const int nvalid = (n - bstart) < (uint32_t)GS_BUCKET ? (int)(n - bstart) : GS_BUCKET;
+#pragma unroll 1
+    for (int dr = 1; dr < nvalid; dr++) {
+        st.x = shift_zero_f(st.x); st.y = shift_zero_f(st.y);
+        tag = shift_zero_u(tag);
+        GS_BW_BODY(st, tag);
+    }
+
+    if (valid) {
+        // acc_S = sum of w d (w = G dL/dG): dL/dmean2D = -(0.5 W, 0.5 H) o (A S.x + B S.y, C S.y + B S.x) (backward.cu:566-573), written on the
+        // log2(e)-scaled conic the lane holds: A = -2 hA / log2 e, B = -nB / log2 e
+        const float kx = 0.5f * (float)a.W / LOG2E, ky = 0.5f * (float)a.H / LOG2E;
         const float gx = __builtin_fmaf(2.0f * L.hAC.x, acc_S.x, L.nB * acc_S.y) * kx;
         const float gy = __builtin_fmaf(2.0f * L.hAC.y, acc_S.y, L.nB * acc_S.x) * ky;
+        float4* o = a.partials + 3 * (size_t)slot;
         o[0] = make_float4(gx, gy, -0.5f * acc_cxy.x, -0.5f * acc_cxy.y);
-        o[1] = make_float4(-0.5f * acc_cw, acc_op * L.rop, acc_rg.x, acc_rg.y);  // acc_op = sum of opacity * G * dL/dalpha (backward.cu:580 sums G * dL/dalpha)
+        o[1] = make_float4(-0.5f * acc_cw, acc_op * rop, acc_rg.x, acc_rg.y);  // acc_op = sum of opacity * G * dL/dalpha (backward.cu:580 sums G * dL/dalpha)
         o[2] = make_float4(acc_b, 0.f, 0.f, 0.f);
     }
 }
-// A lane that meets a marker does not store to global memory (a one-lane store occupies the memory pipeline like a full one: 192 store
-// instructions per bucket boundary instead of 3): it swaps — takes its next parameters out of its three staging cells and parks the
-// finished sums in the same cells; the wave writes a whole slot out (bwd_flush_ring, coalesced) once its marker has passed lane 63.
-__device__ __forceinline__ void bwd_park(float4* c, int lane, const BwdLane& L, v2f acc_S, v2f acc_cxy, v2f acc_rg, float acc_cw, float acc_op,
-                                         float acc_b, float kx, float ky)
-{
-    const float gx = __builtin_fmaf(2.0f * L.hAC.x, acc_S.x, L.nB * acc_S.y) * kx;
-    const float gy = __builtin_fmaf(2.0f * L.hAC.y, acc_S.y, L.nB * acc_S.x) * ky;
-    c[lane] = make_float4(gx, gy, -0.5f * acc_cxy.x, -0.5f * acc_cxy.y);
-    c[64 + lane] = make_float4(-0.5f * acc_cw, acc_op * L.rop, acc_rg.x, acc_rg.y);
-    c[128 + lane] = make_float4(acc_b, __uint_as_float(L.slot), 0.f, 0.f);
-}
-__device__ __forceinline__ void bwd_flush_ring(float4* partials, const float4* c, int lane)
-{
-    const float4 o0 = c[lane], o1 = c[64 + lane], o2 = c[128 + lane];
-    const uint32_t slot = __float_as_uint(o2.y);
-    if (slot != 0xffffffffu) {
-        float4* o = partials + 3 * (size_t)slot;
-        o[0] = o0; o[1] = o1; o[2] = make_float4(o2.x, 0.f, 0.f, 0.f);
-    }
-}
-// staging slot: float4 c0[64] {d0.x, d0.y, hA, hC} | c1[64] {nB, lop, col.r, col.g} | c2[64] {col.b, slot bits, 1/opacity, -}: column-major, so
-// the wave-wide writes are conflict-free and a lane reads its own three entries
-__device__ __forceinline__ void bwd_put(const BwdLane& L, float4* c, int lane)
-{
-    c[lane] = make_float4(L.d0.x, L.d0.y, L.hAC.x, L.hAC.y);
-    c[64 + lane] = make_float4(L.nB, L.lop, L.col_rg.x, L.col_rg.y);
-    c[128 + lane] = make_float4(L.colb, __uint_as_float(L.slot), L.rop, 0.f);
-}
-__device__ __forceinline__ void bwd_take(BwdLane& L, const float4* c, int lane)
-{
-    const float4 p0 = c[lane], p1 = c[64 + lane], p2 = c[128 + lane];
-    L.d0 = (v2f){p0.x, p0.y}; L.hAC = (v2f){p0.z, p0.w};
-    L.nB = p1.x; L.lop = p1.y; L.col_rg = (v2f){p1.z, p1.w};
-    L.colb = p2.x; L.slot = __float_as_uint(p2.y); L.rop = p2.z;
-}
-__device__ __forceinline__ void bwd_empty(BwdLane& L)
-{
-    L.d0 = L.hAC = L.col_rg = (v2f){0.f, 0.f};
-    L.nB = L.colb = L.rop = 0.f;
-    L.lop = -__builtin_inff();  // alpha = exp2(-inf) = 0: never blends
-    L.slot = 0xffffffffu;
-}
-
-__global__ __launch_bounds__(64) void render_bwd_chain_kernel(RenderBwdArgs a, int chain)
-{
-    __shared__ float4 grec[GS_TILE_PIX];          // dL/dpixel of the current tile, by pixel index
-    __shared__ float2 init[64 + 1];               // start state {T, A} of the current chunk's pixels (+1: the marker's entry)
-    __shared__ int32_t itags[64 + 1];
-    __shared__ float4 prm[CH_RING][3][64];        // parameter staging ring
-    const int lane = threadIdx.x;
-    const uint32_t gb0 = blockIdx.x * (uint32_t)chain;
-    const uint32_t nb = ((uint32_t)a.B - gb0) < (uint32_t)chain ? ((uint32_t)a.B - gb0) : (uint32_t)chain;  // <= 64
-    const int32_t kcmp = (int32_t)(((uint32_t)lane << 16) | 0xffffu);
-    const float LOG2E = 1.4426950408889634f;
-    const float kx = 0.5f * (float)a.W / LOG2E, ky = 0.5f * (float)a.H / LOG2E;
-    const size_t plane = (size_t)a.H * a.W;
-
-    // ---- metadata of the chain's buckets, one lane per bucket (two dependent rounds of loads for all of them at once)
-    // (lane j keeps bucket j's tile, list start, list length and first entry; the wave reads them back with v_readlane)
-    bool run_ = false;
-    uint32_t t_ = 0, rx_ = 0, n_ = 0, bs_ = 0;
-    {
-        if ((uint32_t)lane < nb) {
-            t_ = a.bucket_to_tile[gb0 + (uint32_t)lane];
-            const uint2 rg = a.ranges[t_];
-            const uint32_t bbm = (t_ == 0) ? 0u : a.bucket_offsets[t_ - 1];
-            rx_ = rg.x; n_ = rg.y - rg.x; bs_ = (gb0 + (uint32_t)lane - bbm) * GS_BUCKET;
-            run_ = bs_ < a.max_contrib[t_];  // else: entirely behind every pixel's last contributor (backward.cu:428)
-        }
-    }
-    const uint64_t runmask = __ballot(run_);
-    const uint64_t allmask = nb >= 64u ? ~0ull : ((1ull << nb) - 1ull);
-#define GS_META(j, tile_v, rx_v, n_v, bs_v)                                \
-    const uint32_t tile_v = readlane_u(t_, (j));                          \
-    const uint32_t rx_v = readlane_u(rx_, (j));                           \
-    const uint32_t n_v = readlane_u(n_, (j));                             \
-    const uint32_t bs_v = readlane_u(bs_, (j))
-
-    // ---- pass 1: buckets no pixel reaches get exact zeros (independent of the pipeline; their loads overlap freely)
-    for (uint64_t z = allmask & ~runmask; z; z &= z - 1) {
-        const int j = __builtin_ctzll(z);
-        GS_META(j, zt, zrx, zn, zbs);
-        (void)zt;
-        const uint32_t kit = zbs + (uint32_t)lane;
-        if (kit < zn) {
-            float4* o = a.partials + 3 * (size_t)a.inst_slot[zrx + kit];
-            o[0] = o[1] = o[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    if (!runmask) return;
-
-    // ---- pass 2: the running buckets, in order, through one pipeline
-    BwdLane L;
-    bwd_empty(L);
-    v2f acc_S = {0.f, 0.f}, acc_cxy = {0.f, 0.f}, acc_rg = {0.f, 0.f};
-    float acc_cw = 0, acc_op = 0, acc_b = 0;
-    v2f st = {0.f, 0.f};  // {T, A} travelling through the lanes
-    int32_t tag = 0;
-    v2f nst = {0.f, 0.f};  // the next step's injection, fetched one step ahead
-    int32_t ntag = 0;
-    // wave-uniform bookkeeping (steps are counted; the "until" values are step numbers)
-    uint32_t step = 0;
-    uint32_t drain_until = 0;                 // the pipeline is empty (every item past its last lane) once step >= drain_until
-    uint32_t ring_free[CH_RING] = {};         // staging slot r holds parked results of every lane once step >= ring_free[r]
-    bool ring_full[CH_RING] = {};             // ... and they have not been written out yet
-    uint32_t nmark = 0;                       // markers injected so far
-    uint32_t cur_tile = 0xffffffffu;
-    bool live = false;                        // the lanes hold a bucket whose sums have not been stored yet
-
-    uint64_t todo = runmask;
-    int j = __builtin_ctzll(todo);
-    todo &= todo - 1;
-    // this lane's Gaussian of a bucket, ready for the pipeline
-    auto load_gaussian = [&](BwdLane& G, uint32_t tile_, uint32_t rx_v, uint32_t n_v, uint32_t bs_v) {
-        bwd_empty(G);
-        const uint32_t kit = bs_v + (uint32_t)lane;  // splat index in tile
-        if (kit < n_v) {
-            G.slot = a.inst_slot[rx_v + kit];
-            const float4* rp = a.rec + 3 * (size_t)a.point_list[rx_v + kit];
-            const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-            G.d0.x = r0.x - (float)((int)(tile_ % (uint32_t)a.gx) * GS_TILE); G.d0.y = r0.y - (float)((int)(tile_ / (uint32_t)a.gx) * GS_TILE);
-            G.hAC.x = -0.5f * LOG2E * r0.z; G.nB = -LOG2E * r0.w; G.hAC.y = -0.5f * LOG2E * r1.x;
-            G.rop = r1.y > 0.f ? 1.0f / r1.y : 0.f; G.lop = __builtin_amdgcn_logf(r1.y);
-            G.col_rg.x = r1.z; G.col_rg.y = r1.w; G.colb = r2.x;
-        }
-    };
-    float4 p_ck, p_pf;  // register prefetch: the next chunk's per-pixel data is loaded one stage ahead
-    {
-        GS_META(j, t0, rx0, n0, bs0);
-        (void)rx0; (void)n0; (void)bs0;
-        p_ck = a.ckpt[(size_t)(gb0 + (uint32_t)j) * GS_TILE_PIX + lane];
-        p_pf = a.pix_final[(size_t)t0 * GS_TILE_PIX + lane];
-    }
-    for (;;) {
-        GS_META(j, tile, rx, n, bstart);
-        const uint32_t gb = gb0 + (uint32_t)j;
-        const int j2 = todo ? __builtin_ctzll(todo) : -1;
-        const int tx0 = (int)(tile % (uint32_t)a.gx) * GS_TILE, ty0 = (int)(tile / (uint32_t)a.gx) * GS_TILE;
-        const uint32_t nvalid = (n - bstart) < (uint32_t)GS_BUCKET ? (n - bstart) : (uint32_t)GS_BUCKET;
-        const uint32_t tile2 = j2 >= 0 ? readlane_u(t_, j2) : 0u;
-
-        if (tile != cur_tile) {
-            // other tile: its pixels need another grec[].  Let the pipeline run empty, store what the lanes hold, start afresh.
-            while (step < drain_until) GS_CH_STEP_IDLE();
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < CH_RING; r++)
-                if (ring_full[r]) { bwd_flush_ring(a.partials, &prm[r][0][0], lane); ring_full[r] = false; }
-            if (live) bwd_store(a.partials, L, acc_S, acc_cxy, acc_rg, acc_cw, acc_op, acc_b, kx, ky);
-            acc_S = acc_cxy = acc_rg = (v2f){0.f, 0.f}; acc_cw = acc_op = acc_b = 0.f;
-            live = false;
-            cur_tile = tile;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll 2
-            for (int c = 0; c < 4; c++) {
-                const int pidx = c * 64 + lane;
-                const int px = tx0 + (pidx & 15), py = ty0 + (pidx >> 4);
-                float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-                if (px < a.W && py < a.H) {
-                    const size_t pid = (size_t)py * a.W + px;
-                    g0 = a.dL_dpix[pid]; g1 = a.dL_dpix[plane + pid]; g2 = a.dL_dpix[2 * plane + pid];
-                }
-                grec[pidx] = make_float4(g0, g1, g2, 0.f);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (!live) {
-            load_gaussian(L, tile, rx, n, bstart);  // pipeline empty: every lane takes its Gaussian directly
-            live = true;
-        } else {
-            // same tile, pixels of the previous bucket may still be in flight: stage the parameters and send a marker after them
-            const uint32_t r = nmark % CH_RING;
-            while (step < ring_free[r]) GS_CH_STEP_IDLE();  // the slot's previous marker has not reached lane 63 yet (short buckets only)
-            __builtin_amdgcn_wave_barrier();
-            if (ring_full[r]) bwd_flush_ring(a.partials, &prm[r][0][0], lane);  // every lane has parked its previous bucket there
-            __builtin_amdgcn_wave_barrier();
-            {   // (loaded after the waits above: not held in registers across a step loop — registers decide the occupancy here)
-                BwdLane N;
-                load_gaussian(N, tile, rx, n, bstart);
-                bwd_put(N, &prm[r][0][0], lane);
-            }
-            if (lane == 0) { itags[64] = (int32_t)(0x80000000u | (uint32_t)(r * sizeof(prm[0]))); init[64] = make_float2(0.f, 0.f); }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            GS_CH_PREFETCH(nst, ntag, 64);
-            GS_CH_SHIFT_INJ(st, tag, nst, ntag, st, tag); GS_CH_SWITCH(tag); GS_CH_BODY(st, tag);
-            ring_free[r] = step + 63;
-            ring_full[r] = true;
-            drain_until = step + 63;
-            nmark++;
-        }
-
-        // the tile's pixels that reach this bucket, 64 at a time; the next chunk (of this or of the next bucket) is in flight
-#pragma unroll 1
-        for (int c = 0; c < 4; c++) {
-            const float4 ck = p_ck, pf = p_pf;
-            if (c < 3) {
-                p_ck = a.ckpt[(size_t)gb * GS_TILE_PIX + (c + 1) * 64 + lane];
-                p_pf = a.pix_final[(size_t)tile * GS_TILE_PIX + (c + 1) * 64 + lane];
-            } else if (j2 >= 0) {
-                p_ck = a.ckpt[(size_t)(gb0 + (uint32_t)j2) * GS_TILE_PIX + lane];
-                p_pf = a.pix_final[(size_t)tile2 * GS_TILE_PIX + lane];
-            }
-            const int pidx = c * 64 + lane;
-            const int px = tx0 + (pidx & 15), py = ty0 + (pidx >> 4);
-            const bool inside = px < a.W && py < a.H;
-            const uint32_t ncp = inside ? __float_as_uint(pf.w) : 0u;
-            const uint32_t rel = ncp > bstart ? (ncp - bstart < 64u ? ncp - bstart : 64u) : 0u;
-            const float4 gr = grec[pidx];
-            float A0 = (ck.y - pf.x) * gr.x;  // ar = checkpoint colour - final colour (backward.cu:522-523), dotted with dL/dpixel
-            A0 = __builtin_fmaf(ck.z - pf.y, gr.y, A0);
-            A0 = __builtin_fmaf(ck.w - pf.z, gr.z, A0);
-            __builtin_amdgcn_wave_barrier();  // the previous chunk's last lane-0 read of init[] / itags[] precedes these writes
-            init[lane] = make_float2(ck.x, A0);
-            itags[lane] = (int32_t)((rel << 16) | (((uint32_t)pidx >> 4) << 8) | (((uint32_t)pidx & 15u) << 4));
-            uint64_t active = __ballot(ncp > bstart);  // pixels that reach this bucket; the others contribute nothing here
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (active) {
-                // two steps per trip: half the loop-closing branches, and the state ping-pongs between two register sets (a DPP's
-                // destination is the register that held the injected value)
-                // register sets: (st, tag) holds the state and (nst, ntag) the fetched injection on entry to a trip; inside, (st2, tag2) is
-                // the state after the first step (in the registers of nst / ntag) and (nst2, ntag2) the second injection (in those of st / tag)
-                GS_CH_PREFETCH(nst, ntag, __builtin_ctzll(active));
-                for (;;) {
-                    v2f st2, nst2 = {0.f, 0.f};
-                    int32_t tag2, ntag2 = 0;
-                    active &= active - 1;
-                    GS_CH_SHIFT_INJ(st2, tag2, nst, ntag, st, tag);
-                    if (active) GS_CH_PREFETCH(nst2, ntag2, __builtin_ctzll(active));
-                    GS_CH_SWITCH(tag2); GS_CH_BODY(st2, tag2);
-                    if (!active) { st = st2; tag = tag2; break; }
-                    active &= active - 1;
-                    GS_CH_SHIFT_INJ(st, tag, nst2, ntag2, st2, tag2);
-                    if (active) GS_CH_PREFETCH(nst, ntag, __builtin_ctzll(active));
-                    GS_CH_SWITCH(tag); GS_CH_BODY(st, tag);
-                    if (!active) break;
-                }
-                const uint32_t du = step + nvalid - 1;  // the last pixel still has to pass the bucket's remaining (valid) lanes
-                drain_until = du > drain_until ? du : drain_until;
-            }
-        }
-        if (j2 < 0) break;
-        j = j2;
-        todo &= todo - 1;
-    }
-    while (step < drain_until) GS_CH_STEP_IDLE();
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int r = 0; r < CH_RING; r++)
-        if (ring_full[r]) bwd_flush_ring(a.partials, &prm[r][0][0], lane);
-    if (live) bwd_store(a.partials, L, acc_S, acc_cxy, acc_rg, acc_cw, acc_op, acc_b, kx, ky);
-#undef GS_META
-}
-
-static int clamp_chain(int v) { return v < 1 ? 1 : (v > 64 ? 64 : v); }
-static int g_bwd_chain = clamp_chain(getenv("GSLIC_BWD_CHAIN") ? atoi(getenv("GSLIC_BWD_CHAIN")) : 8);
-int set_bwd_chain(int k)
-{
-    const int old = g_bwd_chain;
-    if (k > 0) g_bwd_chain = clamp_chain(k);
-    return old;
-}
-static int bwd_chain_length() { return g_bwd_chain; }
 
 int launch_render_fwd(const RenderFwdArgs& a, hipStream_t s)
 {
@@ -786,10 +610,9 @@ int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s)
     if (a.B <= 0) return GSLIC_OK;
     if (g_strict_math) {
         GS_LAUNCH(K_RENDER_BWD, render_bwd_strict_kernel, dim3(a.B), dim3(64), 0, s, a);
-    } else {
-        const int chain = bwd_chain_length();
-        GS_LAUNCH(K_RENDER_BWD, render_bwd_chain_kernel, dim3((a.B + chain - 1) / chain), dim3(64), 0, s, a, chain);
+        return GSLIC_OK;
     }
+    GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel, dim3(a.B), dim3(64), 0, s, a);
     return GSLIC_OK;
 }
 

@@ -316,11 +316,6 @@ const char* gslic_last_error(void);
  * (tests/test_fullsize_reference_gpu.py).  Initial value: environment GSLIC_STRICT_MATH=1. */
 int gslic_set_math_mode(int32_t strict);
 
-/* Tuning knob of the default (fast) backward blend kernel: the number of consecutive checkpoint buckets one wave chains through
- * its 64-deep pipeline (1..64, initial value 8 or environment GSLIC_BWD_CHAIN; <= 0 only queries).  Results are bit-identical
- * for every value — it only trades pipeline fill/drain steps against load balance.  Returns the previous value. */
-int gslic_set_bwd_chain(int32_t buckets_per_wave);
-
 /* Sizes the four scratch buffers would need, for hosts that prefer to pre-size (bytes incl. slack). */
 size_t gslic_geom_bytes(int32_t P);
 size_t gslic_img_bytes(int32_t width, int32_t height);

@@ -285,31 +285,3 @@ def test_degenerate_shapes(oracle32, case):
     for k in ("dL_dmean3D", "dL_dopacity", "dL_ddc", "dL_dsh", "dL_dscale"):
         if rg[k].size and np.abs(rg[k]).max() > 0:
             assert_close_flips(g[k].reshape(rg[k].shape), rg[k], 1e-4, k, flip_bound=2e-2)
-
-
-@pytest.mark.gpu
-def test_backward_chain_length_does_not_change_results():
-    """The default backward chains `k` consecutive buckets through one wave's pipeline (markers between them): every per-instance sum
-    is accumulated by the same lane in the same order whatever k is, so the gradients must be bit-identical for every k — including
-    tiles whose lists span many buckets, partial last buckets, empty tiles and a wave that crosses tile boundaries."""
-    import torch
-    from gpu_helpers import hip_backward, hip_forward
-    from gaussian_lic_amd import _lib
-    from gaussian_lic_amd.synthetic import pixel_grad
-    for kind, P, W, H, seed in (("random", 60000, 200, 150, 5), ("lidar", 30000, 320, 240, 6), ("random", 3000, 40, 30, 7)):
-        raw, sc, camd, cam = make_scene(kind, P, W, H, 3, seed)
-        dL = pixel_grad(H, W, seed=1)
-        prev = _lib.set_bwd_chain(0)
-        try:
-            base = None
-            for k in (1, 2, 3, 8, 64):
-                _lib.set_bwd_chain(k)
-                f = hip_forward(raw, cam)
-                g = hip_backward(f, dL)
-                if base is None:
-                    base = g
-                else:
-                    for name in g:
-                        np.testing.assert_array_equal(g[name], base[name], err_msg=f"{kind} k={k} {name}")
-        finally:
-            _lib.set_bwd_chain(prev)
