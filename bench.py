@@ -65,8 +65,8 @@ def algorithmic_bytes(kernel, s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=400, help="timed steps (default 400: about one second of GPU time at config 3)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--gaussians", type=int, default=2_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -82,7 +82,10 @@ def main():
                          "steps (instances R 8M -> 3.6M), i.e. the work per step would shrink while it is being timed; 0.01 keeps every step on the "
                          "same workload.  Every kernel still does its full work (Adam updates every visible row)")
     ap.add_argument("--split-adam", action="store_true", help="fused host path with Adam as its own launch (the N > 1 compute path: gradients to the slab, then Adam), on one GPU")
+    ap.add_argument("--graph", action="store_true", help="time the step as ONE hipGraph replay (capacity-mode forward, no host round trip) instead of eager launches; "
+                                                          "single GPU, fused host path.  The default run reports it next to `value` as `graphed`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements of the default run (other host path, graphed step, growth schedule)")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every kernel inside the timed region (adds overhead)")
     args = ap.parse_args()
 
@@ -132,7 +135,12 @@ def main():
         Rcw = torch.from_numpy(cam.world_view_transform[:3, :3].T.copy())
         tcw = torch.from_numpy(cam.world_view_transform[3, :3].copy())
 
+    graphed = dict(gs=None)
+
     def step():
+        if graphed["gs"] is not None:
+            graphed["gs"].step()
+            return None
         if args.mode == "slam":
             slam["it"] += 1
             if slam["it"] % 10 == 0:
@@ -154,6 +162,8 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if args.graph:
+        assert world == 1 and args.mode == "train" and args.host == "fused" and not args.split_adam, "--graph: single GPU, --mode train --host fused"
     # ---- warm-up (untimed); the last warm-up steps double as the per-kernel breakdown pass
     nprof = min(3, args.warmup)
     for _ in range(args.warmup - nprof):
@@ -167,6 +177,10 @@ def main():
     breakdown = _lib.profile_collect() if nprof else {}
     _lib.profile_enable(False)
     dominant = max(breakdown, key=lambda k: breakdown[k][0]) if breakdown else "render_bwd"
+    if args.graph:   # the timed region replays the captured step; per-kernel HIP events cannot be recorded inside a replay
+        graphed["gs"] = trainer.GraphedStep(model, cam, gt, bg, check_every=0)
+        for _ in range(3):
+            step()
 
     # ---- timed region: exactly K steps, dominant kernel bracketed by HIP events on its launch stream
     _lib.profile_reset()
@@ -179,28 +193,47 @@ def main():
     t1 = time.perf_counter()
     timed = _lib.profile_collect()
     _lib.profile_enable(False)
+    if graphed["gs"] is not None:
+        assert graphed["gs"].check() == 0, "a timed step did not fit its capacity buffers"
+        graphed["gs"] = None
     dt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(dt.item())
 
     # ---- the same K steps through the other host path (reported next to `value`, not part of it)
-    other = None
-    if args.mode == "train":
-        host["mode"] = "dropin" if args.host == "fused" else "fused"
+    def timed_loop(fn, n):
         for _ in range(3):
-            step()
+            fn()
         sync_all()
         o0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        for _ in range(n):
+            fn()
         sync_all()
         odt = torch.tensor([time.perf_counter() - o0], dtype=torch.float64, device=dev)
         if world > 1:
             torch.distributed.all_reduce(odt, op=torch.distributed.ReduceOp.MAX)
-        other = {"host": host["mode"], "value": round(args.steps * world / float(odt.item()), 3), "unit": "views/s",
-                 "ms_per_step": round(1e3 * float(odt.item()) / args.steps, 3)}
+        return float(odt.item())
+
+    other, graphed_res, growth = None, None, None
+    n_extra = min(args.steps, 200)
+    if args.mode == "train" and not args.no_extras and not args.graph:
+        host["mode"] = "dropin" if args.host == "fused" else "fused"
+        sec = timed_loop(step, n_extra)
+        other = {"host": host["mode"], "value": round(n_extra * world / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3),
+                 "steps": n_extra}
         host["mode"] = args.host
+        if world == 1 and args.host == "fused" and not args.split_adam:
+            # the same step as ONE hipGraph replay: capacity-mode forward (no host round trip), loss, backward + Adam
+            gs = trainer.GraphedStep(model, cam, gt, bg, check_every=0)
+            sec = timed_loop(gs.step, n_extra)
+            repeated = gs.check()
+            graphed_res = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra,
+                           "host_round_trips_per_step": 0, "steps_repeated_for_capacity": repeated, "capacity_R": gs.bufs.cap_R, "capacity_B": gs.bufs.cap_B}
+            del gs
+        if world == 1 and args.host == "fused":
+            torch.cuda.empty_cache()
+            growth = growth_schedule(args, dev)
 
     # ---- unit counts of this workload (one extra forward, untimed)
     with torch.no_grad():
@@ -232,41 +265,43 @@ def main():
     fused_adam = args.mode in ("train", "slam") and args.host == "fused" and world == 1
     abytes = algorithmic_bytes("preprocess_bwd+adam" if (dominant == "preprocess_bwd" and fused_adam) else dominant, stats)
     achieved = abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None
-    pmc_workload_ok = False
+    # HBM traffic and VALU instruction counts cannot be measured from inside this process (PMC counters need rocprofv3 around it): they are
+    # REPLAYED from the committed profile of the same workload and labelled with the file they come from; null when the workload differs.
+    traffic, traffic_src, sq, sq_src = None, None, None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    pmc_workload_ok = False
     if os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
-            key = f"{dominant}_kernel"
             pmc_workload_ok = pmc.get("workload") == f"{args.scene}-{P}-{W}x{H}"
-            if pmc_workload_ok and key in pmc.get("kernels", {}):
-                traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+            for key in (f"{dominant}_kernel", dominant):
+                if pmc_workload_ok and key in pmc.get("kernels", {}):
+                    traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+                    traffic_src = f"profiles/pmc_traffic.json@{pmc.get('tag', 'untagged')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated on a 1 GiB copy)"
         except Exception:
             traffic = None
     roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, algorithmic_bytes_per_launch=abytes,
-                    avg_launch_ms=round(avg_ms, 4), launches_timed=int(dom_n))
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src, algorithmic_bytes_per_launch=abytes,
+                    avg_launch_ms=round(avg_ms, 4), launches_timed=int(dom_n), timing="HIP events around every launch of the kernel inside the timed region")
     if dominant in ("render_fwd", "render_bwd"):
-        # the blend kernels are VALU-bound, not HBM-bound: also report pair-evaluation throughput
-        # every bucket offers 256 x 64 (pixel, Gaussian) slots; the kernels skip the slots of finished pixels / unreachable strips,
-        # so this is an upper bound of the pairs actually evaluated (no FLOP claim is derived from it)
+        # the blend kernels are VALU-bound, not HBM-bound.  Every bucket offers 256 x 64 (pixel, Gaussian) slots; the
+        # kernels skip finished pixels / unreachable strips, so this is an upper bound of the pairs evaluated (no FLOP claim is derived)
         slots = 256.0 * 64.0 * stats["B"]
         roofline["valu"] = dict(pair_slots_per_launch=slots, gslots_per_s=round(slots / (avg_ms * 1e-3) / 1e9, 2) if avg_ms > 0 else 0,
-                                note="VALU-issue bound (profiles/*_sq_counters.txt); HBM frac above is not the limiter")
-        # issue-slot utilisation from the committed SQ counters of the same workload: VALU instructions per launch x the measured
-        # 4.1 cycles per wave64 instruction (tools/ubench/valu_rate, the fastest kind) / (1024 SIMDs x launch duration x 2.4 GHz)
+                                note="VALU-issue bound, not HBM-bound: see DESIGN.md section 6 (issue cost per instruction class, tools/ubench/issue_rate)")
         try:
             import ast
             import glob
             sq_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.txt")))   # the newest tag sorts last
             for line in (open(sq_files[-1]) if sq_files else []):
                 name, _, rest = line.partition(" ")
-                if name == f"{dominant}_kernel" and pmc_workload_ok:
+                if name.split("<")[0] in (f"{dominant}_kernel", dominant) and pmc_workload_ok:
                     c = ast.literal_eval(rest.strip())
                     insts = c["SQ_INSTS_VALU"] * 32.0   # the extract averages per shader engine; 32 engines
-                    roofline["valu"].update(valu_insts_per_launch=insts,
-                                            issue_frac=round(insts * 4.1 / (1024.0 * c["dur_us"] * 1e-6 * 2.4e9), 3))
+                    roofline["valu"].update(valu_insts_per_launch=insts, counters_source="profiles/" + os.path.basename(sq_files[-1]),
+                                            simd_cycles_per_valu_inst=round(1024.0 * avg_ms * 1e-3 * 2.4e9 / insts, 2) if insts else None,
+                                            simd_cycles_note="launch duration x 1024 SIMDs x 2.4 GHz (nominal) / VALU instructions; a wave64 VALU instruction "
+                                                             "issues every 2.1-2.4 cycles (VGPR operands), 4.2 (SGPR / literal operand, DPP, packed), 8 (exp, rcp)")
         except Exception:
             pass
 
@@ -276,18 +311,27 @@ def main():
         cpu = cpu_baseline(args)
 
     views = args.steps * world
+    if (P, W, H) == (2_000_000, 1920, 1080) and args.scene == "random":
+        config_label = "BASELINE config 3" if world == 1 else "BASELINE config 4"
+    elif (P, W, H) == (500_000, 1920, 1080) and args.scene == "lidar":
+        config_label = "BASELINE config 2"
+    elif (P, W, H) == (5_000_000, 3840, 2160):
+        config_label = "BASELINE config 5 shape" + (" on one GPU" if world == 1 else "")
+    else:
+        config_label = "custom configuration"
     out = {
         "metric": "rendered views/sec (fwd+bwd) at 1080p, 2M Gaussians" if (P == 2_000_000 and (W, H) == (1920, 1080))
         else f"rendered views/sec (fwd+bwd) at {W}x{H}, {P} Gaussians",
         "value": round(views / elapsed, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE config 3: {P} Gaussians ({args.scene} scene, seed 0), {W}x{H}, SH degree 3, "
+        "config": {"workload": f"{config_label}: {P} Gaussians ({args.scene} scene, seed 0), {W}x{H}, SH degree 3, "
                                + ("render fwd + 0.8*L1+0.2*(1-fused-SSIM) + bwd + sparse Adam per view"
                                   if args.mode in ("train", "slam") else "bare render fwd+bwd per view")
                                + (" (fused entry points: activations and loss inside the kernels)" if args.host == "fused" and args.mode != "render"
                                   else " (reference operator API + LibTorch autograd)")
-                               + f"; learning rates x{args.lr_scale:g} (stationary synthetic scene)"
+                               + (f"; learning rates x{args.lr_scale:g} (stationary synthetic scene)" if args.mode != "render" else "")
+                               + ("; step replayed as one hipGraph (capacity-mode forward)" if args.graph else "")
                                + ("; extend() append of a LiDAR frame every 10 steps, timed" if args.mode == "slam" else "")
                                + ("" if world == 1 else f"; {world} views/step, one gradient all-reduce per step"),
                    "mode": args.mode, "host": args.host if args.mode != "render" else "dropin", "parallelism": f"dp{world}" if world > 1 else "single",
@@ -295,6 +339,8 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
         "other_host_path": other,
+        "graphed": graphed_res,
+        "growth_schedule": growth,
         "extend": None if args.mode != "slam" else {"calls": slam["calls"], "inserted": slam["inserted"], "final_gaussians": model.P,
                                                     "ms_per_call": round(slam["ms"] / max(slam["calls"], 1), 3)},
         "kernel_ms_per_step": {k: round(v[0] / max(nprof, 1), 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
@@ -304,30 +350,117 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def growth_schedule(args, dev):
+    """SURVEY.md section 8d, config 3 as written: the map starts at 75 % of --gaussians and grows by five extend() appends of LiDAR frames
+    (one every 20 iterations) over 100 training iterations at the reference's learning rates — the reference's only densification
+    (gaussian.cpp:499-638; it has no pruning).  The starting map leaves the right 30 % of the image uncovered: that is where the frames'
+    points survive the transmittance filter.  Everything inside the loop is timed, the extend() calls included."""
+    from gaussian_lic_amd import trainer
+    from gaussian_lic_amd.camera import synthetic_camera
+    from gaussian_lic_amd.synthetic import gt_image, lidar_scene, random_scene
+    W, H, P = args.width, args.height, args.gaussians
+    big = random_scene(int(P * 1.1), W, H, sh_degree=3, seed=0)
+    u_pix = big["xyz"][:, 0] * (0.675 * W) / big["xyz"][:, 2].abs().clamp_min(0.2) + 0.4857 * W
+    keep = torch.nonzero(u_pix < 0.7 * W).squeeze(1)[:int(0.75 * P)]
+    raw = {k: (v[keep].contiguous() if torch.is_tensor(v) else v) for k, v in big.items()}
+    model = trainer.GaussianModel(raw, dev, capacity=int(1.05 * P))
+    model.training_setup()
+    cam = synthetic_camera(W, H).to_device(dev)
+    gt = gt_image(H, W, seed=2).to(dev)
+    bg = torch.zeros(3, device=dev)
+    Rcw = torch.from_numpy(cam.world_view_transform[:3, :3].T.copy())
+    tcw = torch.from_numpy(cam.world_view_transform[3, :3].copy())
+    intr = (float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy))
+    frames = []
+    for k in range(6):   # one warm-up frame + five timed ones; ~ P/20 of a frame's points fall on the uncovered part
+        f = lidar_scene(int(P / 6), W, H, sh_degree=3, seed=200 + k)
+        frames.append((f["xyz"].to(dev), (f["features_dc"].reshape(-1, 3) * 0.28209479177387814 + 0.5).to(dev), f["xyz"][:, 2].contiguous().to(dev)))
+    P0 = model.P
+    model.extend(cam, *frames[0], Rcw, tcw, intr)     # warm-up: one-off allocations of extend()
+    for _ in range(3):
+        trainer.training_step_fused(model, cam, gt, bg)
+    torch.cuda.synchronize()
+    P1, inserted, ext_ms = model.P, 0, 0.0
+    t0 = time.perf_counter()
+    for it in range(100):
+        if it % 20 == 0:
+            e0 = time.perf_counter()
+            inserted += model.extend(cam, *frames[1 + it // 20], Rcw, tcw, intr)   # (synchronises: the survivor count sizes the append)
+            ext_ms += 1e3 * (time.perf_counter() - e0)
+        trainer.training_step_fused(model, cam, gt, bg)
+    torch.cuda.synchronize()
+    sec = time.perf_counter() - t0
+    return {"workload": f"SURVEY 8d config 3 schedule: {P1} -> {model.P} Gaussians by 5 extend() appends (every 20 iterations), 100 iterations, reference learning rates",
+            "value": round(100.0 / sec, 3), "unit": "views/s", "ms_per_iteration": round(10.0 * sec, 3), "iterations": 100, "appends": 5,
+            "gaussians_start": P1, "gaussians_end": model.P, "inserted": inserted, "extend_ms_per_call": round(ext_ms / 5.0, 3),
+            "gaussians_before_warmup_frame": P0}
+
+
+def _cpu_step(orc, sc, cam, gt, state, lrs):
+    """One training iteration on the CPU oracle: render forward -> 0.8 L1 + 0.2 (1 - SSIM) and its gradient -> render backward -> masked
+    Adam on the six parameter groups: the same work as one bench step (the three elementwise activation chains are left out)."""
+    f = orc.forward(sc, cam)
+    img = f["color"]
+    n = float(img.size)
+    m, d1, d2, d3 = orc.ssim_forward(img[None], gt[None])
+    dL = (0.8 / n) * np.sign(img - gt).astype(np.float32) + orc.ssim_backward(img[None], gt[None], np.full_like(m, -0.2 / n), d1, d2, d3)[0]
+    g = orc.backward(sc, cam, f, dL)
+    vis = f["pre"]["radii"] > 0
+    for key, gname, lr in (("means", "dL_dmean3D", lrs[0]), ("dc", "dL_ddc", lrs[1]), ("shs", "dL_dsh", lrs[2]), ("opac", "dL_dopacity", lrs[3]),
+                           ("scales", "dL_dscale", lrs[4]), ("rots", "dL_drot", lrs[5])):
+        p = state[key]
+        orc.adam(p[0], np.ascontiguousarray(g[gname], np.float32).reshape(p[0].shape), p[1], p[2], vis, lr)
+    return f, g, dL
+
+
 def cpu_baseline(args):
-    """Oracle (oracle/gs_oracle.c, OpenMP) fwd+bwd(+Adam) on the 1/16-scale instance of the bench workload
-    (P/16 Gaussians, W/4 x H/4), a few iterations (~10-30 s of CPU work); value is scaled to full-size views/s by /16."""
+    """The CPU oracle (oracle/gs_oracle.c, a C port of the reference kernels, OpenMP) timed on this box's host cores on the SAME work as
+    `value` (forward + loss + backward + Adam): (a) a bounded 1/16-scale sample with every thread and with ONE thread, (b) one
+    iteration at the full size when the sample says it fits a 40 s budget.  Also the checker on the sample: max errors, not percentiles."""
     from oracle.oracle import Oracle, build
     import gaussian_lic_amd  # noqa: F401
     from gaussian_lic_amd.camera import synthetic_camera
-    from gaussian_lic_amd.synthetic import activate, lidar_scene, pixel_grad, random_scene, to_numpy
+    from gaussian_lic_amd.synthetic import activate, gt_image, lidar_scene, pixel_grad, random_scene, to_numpy
     build()
     orc = Oracle(np.float32)
+    nthreads = orc.max_threads()
+    lrs = [1.6e-6, 2.5e-5, 2.5e-5 / 20.0, 5e-4, 5e-5, 1e-5]   # the reference's rates x 0.01, as the default bench
+
+    def instance(Ps, Ws, Hs):
+        raw = (random_scene if args.scene == "random" else lidar_scene)(Ps, Ws, Hs, sh_degree=3, seed=0)
+        sc = to_numpy(activate(raw))
+        state = {k: (np.ascontiguousarray(sc[k], np.float32), np.zeros_like(sc[k], np.float32), np.zeros_like(sc[k], np.float32))
+                 for k in ("means", "dc", "shs", "opac", "scales", "rots")}
+        for k in state:
+            sc[k] = state[k][0]   # Adam updates the arrays the oracle renders from
+        return raw, sc, state, synthetic_camera(Ws, Hs).as_dict(), gt_image(Hs, Ws, seed=2).numpy()
+
     Ws, Hs, Ps = args.width // 4, args.height // 4, args.gaussians // 16
-    raw = (random_scene if args.scene == "random" else lidar_scene)(Ps, Ws, Hs, sh_degree=3, seed=0)
-    sc = to_numpy(activate(raw))
-    cam = synthetic_camera(Ws, Hs).as_dict()
-    dL = pixel_grad(Hs, Ws).numpy()
+    raw, sc, state, cam, gt = instance(Ps, Ws, Hs)
     iters, t_spent = 0, 0.0
-    t_budget = 12.0
-    while (iters < 2 or t_spent < t_budget) and iters < 50:
+    while (iters < 2 or t_spent < 8.0) and iters < 50:
         t0 = time.perf_counter()
-        f = orc.forward(sc, cam)
-        orc.backward(sc, cam, f, dL)
+        _cpu_step(orc, sc, cam, gt, state, lrs)
         t_spent += time.perf_counter() - t0
         iters += 1
     per_view = t_spent / iters
-    # the oracle as the CHECKER on the same sample (SURVEY.md 8d): PSNR of the HIP image against the oracle image, worst gradient error
+    orc.set_threads(1)
+    t0 = time.perf_counter()
+    _cpu_step(orc, sc, cam, gt, state, lrs)
+    per_view_1 = time.perf_counter() - t0
+    orc.set_threads(nthreads)
+    full = None
+    if 16.0 * per_view * 1.5 < 40.0:   # one full-size iteration (scene generation excluded), only when the sample predicts it fits the budget
+        try:
+            _r, sc_f, st_f, cam_f, gt_f = instance(args.gaussians, args.width, args.height)
+            t0 = time.perf_counter()
+            _cpu_step(orc, sc_f, cam_f, gt_f, st_f, lrs)
+            full = {"ms_per_view": round(1e3 * (time.perf_counter() - t0), 1), "threads": nthreads, "iterations": 1,
+                    "workload": f"{args.gaussians} Gaussians, {args.width}x{args.height}"}
+            del sc_f, st_f
+        except Exception as ex:
+            full = {"error": str(ex)[:200]}
+    # the oracle as the CHECKER on the sample (SURVEY.md 8d): PSNR of the HIP image against the oracle image, maximum gradient error
     parity = None
     try:
         import torch
@@ -335,6 +468,10 @@ def cpu_baseline(args):
         from gaussian_lic_amd.camera import synthetic_camera as _sc
         dev = torch.device("cuda", torch.cuda.current_device())
         camo = _sc(Ws, Hs)
+        scp = to_numpy(activate(raw))
+        dL = pixel_grad(Hs, Ws).numpy()
+        f = orc.forward(scp, cam)
+        ob = orc.backward(scp, cam, f, dL)
         act = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in activate(raw).items()}
         e = torch.empty(0, device=dev)
         vm, pm = torch.from_numpy(camo.world_view_transform).to(dev), torch.from_numpy(camo.full_proj_transform).to(dev)
@@ -346,24 +483,30 @@ def cpu_baseline(args):
         g = rz.rasterize_gaussians_backward(torch.zeros(3, device=dev), act["means"], radii, e, act["scales"], act["rots"], 1.0, e, vm, pm,
                                             float(camo.tanfovx), float(camo.tanfovy), *lim, torch.from_numpy(dL).to(dev), act["dc"], act["shs"],
                                             act["D"], cp, geom, R, binning, img, B, sample, 0.0, False)
-        ob = orc.backward(sc, cam, f, dL)
-        mse = float(np.mean((color.cpu().numpy().astype(np.float64) - f["color"].astype(np.float64)) ** 2))
+        cimg = color.cpu().numpy().astype(np.float64)
+        mse = float(np.mean((cimg - f["color"].astype(np.float64)) ** 2))
+        img_err = np.abs(cimg - f["color"]) / max(float(np.abs(f["color"]).max()), 1e-30)
         names = ["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_ddc", "dL_dsh", "dL_dscale", "dL_drot"]
-        worst = 0.0
+        worst, over, total = 0.0, 0, 0
         for n_, t_ in zip(names, g):
             if n_ in ob and t_ is not None and t_.numel():
                 ref = np.asarray(ob[n_], dtype=np.float64).reshape(-1)
                 got = t_.detach().cpu().numpy().astype(np.float64).reshape(-1)
                 if ref.shape == got.shape and np.abs(ref).max() > 0:
-                    # 99.99th percentile: a handful of alpha < 1/255 threshold flips per million are expected
-                    worst = max(worst, float(np.quantile(np.abs(got - ref), 0.9999) / np.abs(ref).max()))
-        parity = {"psnr_image_vs_oracle_db": round(10.0 * np.log10(1.0 / max(mse, 1e-30)), 1), "grad_err_p9999_rel_maxabs": float(f"{worst:.2e}"),
-                  "instances_equal": int(R) == int(f["num_rendered"])}
+                    err = np.abs(got - ref) / np.abs(ref).max()
+                    worst = max(worst, float(err.max()))
+                    over += int((err > 1e-4).sum()); total += err.size
+        parity = {"psnr_image_vs_oracle_db": round(10.0 * np.log10(1.0 / max(mse, 1e-30)), 1), "image_max_rel_err": float(f"{img_err.max():.2e}"),
+                  "image_elements_over_1e-4": int((img_err > 1e-4).sum()), "grad_max_rel_err": float(f"{worst:.2e}"),
+                  "grad_elements_over_1e-4": over, "grad_elements": total, "instances_equal": int(R) == int(f["num_rendered"]),
+                  "note": "default (fast) arithmetic of the blend kernels; relative to the tensor's max-abs"}
     except Exception as ex:  # the baseline leg must never take the bench line down
         parity = {"error": str(ex)[:200]}
-    return {"value": round(1.0 / (16.0 * per_view), 4), "unit": "views/s", "cores": orc.max_threads(), "kind": "port", "hip_vs_oracle": parity,
-            "sample": f"1/16-scale instance ({Ps} Gaussians, {Ws}x{Hs}, SH degree 3) render fwd+bwd, {iters} iterations, "
-                      f"{per_view * 1e3:.1f} ms/view measured; value = 1/(16 x that) full-size-equivalent views/s"}
+    return {"value": round(1.0 / (16.0 * per_view), 4), "unit": "views/s", "cores": nthreads, "kind": "port", "hip_vs_oracle": parity,
+            "threads_1": {"ms_per_view_sample": round(1e3 * per_view_1, 1), "value": round(1.0 / (16.0 * per_view_1), 5), "unit": "views/s (full-size equivalent)"},
+            "full_size": full,
+            "sample": f"1/16-scale instance ({Ps} Gaussians, {Ws}x{Hs}, SH degree 3): render fwd + 0.8 L1 + 0.2 (1 - SSIM) + bwd + masked Adam, {iters} iterations, "
+                      f"{per_view * 1e3:.1f} ms/view on {nthreads} threads; value = 1/(16 x that) full-size-equivalent views/s"}
 
 
 if __name__ == "__main__":

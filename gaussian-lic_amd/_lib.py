@@ -39,7 +39,7 @@ EXPORTS = [
     "gslic_last_error", "gslic_geom_bytes", "gslic_img_bytes", "gslic_binning_bytes", "gslic_sample_bytes",
     "gslic_profile_enable", "gslic_profile_reset", "gslic_profile_collect", "gslic_profile_num_kernels",
     "gslic_profile_kernel_name", "gslic_profile_get", "gslic_debug_export", "gslic_extend_select", "gslic_extend_emit", "gslic_loss_partials_count", "gslic_l1_ssim_loss_forward",
-    "gslic_l1_ssim_loss_backward", "gslic_set_math_mode",
+    "gslic_l1_ssim_loss_backward", "gslic_set_math_mode", "gslic_rasterize_forward_capacity",
 ]
 
 _lib = None
@@ -72,6 +72,9 @@ def lib():
     L.gslic_rasterize_forward.argtypes = (
         [ctypes.POINTER(RasterParams)] + [ALLOC_FN, vp] * 4 + [vp] * 12 + [vp, vp, vp] +
         [ctypes.POINTER(i32), ctypes.POINTER(i32), vp])
+    L.gslic_rasterize_forward_capacity.argtypes = (
+        [ctypes.POINTER(RasterParams)] + [vp, ctypes.c_size_t] * 4 + [vp] * 12 + [vp, vp, vp] +
+        [ctypes.POINTER(i32), ctypes.POINTER(i32), vp, vp])
     L.gslic_rasterize_backward.argtypes = (
         [ctypes.POINTER(RasterParams), i32, i32] + [vp] * 12 + [vp] * 4 + [vp] + [vp] * 10 + [f32, vp])
     L.gslic_rasterize_backward_adam.argtypes = (

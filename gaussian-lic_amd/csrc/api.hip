@@ -290,9 +290,40 @@ size_t gslic_binning_bytes(int32_t R, int32_t no_color)
 }
 size_t gslic_sample_bytes(int32_t B) { size_t b; SampleState::carve(nullptr, (size_t)(B > 0 ? B : 0), &b); return b; }
 
-int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_alloc, void* geom_ctx, gslic_alloc_fn binning_alloc,
+}  // extern "C"
+
+namespace gslic {
+// Capacity mode (gslic_rasterize_forward_capacity): the four buffers are the caller's, already sized; R and B never travel to the host.
+struct ForwardCapacity {
+    char *geom, *binning, *img, *sample;
+    size_t geom_bytes, binning_bytes, img_bytes, sample_bytes;
+    uint32_t* status_out;  // device [4]: R, B, overflow bits, count of forwards that fitted — written by the last kernel of the forward
+};
+// largest count whose carve fits into `bytes` (the carves are monotonic)
+template <typename F>
+static uint32_t capacity_for(size_t bytes, F bytes_needed)
+{
+    uint64_t lo = 0, hi = 0x7fffffffull;
+    if (bytes_needed(0) > bytes) return 0;
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo + 1) / 2;
+        if (bytes_needed((uint32_t)mid) <= bytes) lo = mid; else hi = mid - 1;
+    }
+    return (uint32_t)lo;
+}
+__global__ void forward_status_kernel(const uint32_t* __restrict__ R, const uint32_t* __restrict__ B, const uint32_t* __restrict__ flags, uint32_t* __restrict__ out)
+{
+    out[0] = *R;
+    out[1] = B ? *B : 0u;
+    const uint32_t st = flags[2] | (flags[0] & 1u ? 4u : 0u);  // 1: instances did not fit, 2: buckets did not fit, 4: prefiltered violation
+    out[2] = st;
+    if (!(st & 3u)) out[3] += 1u;  // forwards completed in capacity (never reset here: the caller zeroes the word once)
+}
+}  // namespace gslic
+
+static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn geom_alloc, void* geom_ctx, gslic_alloc_fn binning_alloc,
                             void* binning_ctx, gslic_alloc_fn img_alloc, void* img_ctx, gslic_alloc_fn sample_alloc,
-                            void* sample_ctx, const float* background, const float* means3D, const float* dc, const float* shs,
+                            void* sample_ctx, const ForwardCapacity* cap, const float* background, const float* means3D, const float* dc, const float* shs,
                             const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
                             const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                             float* out_color, float* out_final_T, int32_t* radii, int32_t* num_rendered, int32_t* num_buckets,
@@ -307,7 +338,7 @@ int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_
     if (P == 0) return GSLIC_OK;  // rasterize_points.cu:110
     if (colors_precomp || cov3D_precomp)
         return set_error(GSLIC_ERR_UNSUPPORTED, "colors_precomp / cov3D_precomp are not supported (the reference host always passes empty tensors)");
-    if (!geom_alloc || !binning_alloc || !img_alloc || (!prm->no_color && !sample_alloc))
+    if (!cap && (!geom_alloc || !binning_alloc || !img_alloc || (!prm->no_color && !sample_alloc)))
         return set_error(GSLIC_ERR_INVALID_ARG, "allocator callback is NULL");
     if (!means3D || !dc || !opacities || !scales || !rotations || !viewmatrix || !projmatrix || !cam_pos || !out_final_T || !radii ||
         (!prm->no_color && !out_color) || (prm->M > 0 && !shs))
@@ -319,11 +350,14 @@ int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_
 
     size_t geom_bytes, img_bytes;
     GeomState::carve(nullptr, (size_t)P, &geom_bytes);
-    char* geom_base = geom_alloc(geom_ctx, geom_bytes);
+    ImageState::carve(nullptr, (size_t)T, &img_bytes);
+    if (cap && (cap->geom_bytes < geom_bytes || cap->img_bytes < img_bytes || !cap->geom || !cap->img || !cap->binning ||
+                (!no_color && !cap->sample) || !cap->status_out))
+        return set_error(GSLIC_ERR_INVALID_ARG, "capacity mode: geometry / image buffer too small (need %zu / %zu bytes) or a NULL buffer", geom_bytes, img_bytes);
+    char* geom_base = cap ? cap->geom : geom_alloc(geom_ctx, geom_bytes);
     if (!geom_base) return set_error(GSLIC_ERR_ALLOC, "geometry allocator returned NULL for %zu bytes", geom_bytes);
     GeomState geom = GeomState::carve(align256(geom_base), (size_t)P, nullptr);
-    ImageState::carve(nullptr, (size_t)T, &img_bytes);
-    char* img_base = img_alloc(img_ctx, img_bytes);
+    char* img_base = cap ? cap->img : img_alloc(img_ctx, img_bytes);
     if (!img_base) return set_error(GSLIC_ERR_ALLOC, "image allocator returned NULL for %zu bytes", img_bytes);
     ImageState img = ImageState::carve(align256(img_base), (size_t)T, nullptr);
 
@@ -351,24 +385,32 @@ int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_
     uint32_t* const order = geom.order[geom.plan.passes & 1];
     GS_TRY(scan_u32_chained(geom.tiles_touched, order, geom.point_offsets, (size_t)P, false, geom.scan_state, s));
     uint32_t hostbuf[2] = {0, 0};
-    GS_TRY(fetch_counts(geom.point_offsets + (P - 1), geom.flags, hostbuf, s));  // host needs R to size the binning buffer (rasterizer_impl.cu:398)
-    if (hostbuf[1] & 2u) return set_error(GSLIC_ERR_HIP, "a chained-scan look-back wait timed out (device preempted?): the forward was abandoned");
-    if (hostbuf[1] & 4u) return set_error(GSLIC_ERR_INVALID_ARG, "more than 2^31 (Gaussian, tile) instances");
-    if (prm->prefiltered && (hostbuf[1] & 1u)) return set_error(GSLIC_ERR_PREFILTERED, "a point was culled although prefiltered is set");
-    if (hostbuf[0] > 0x7fffffffu) return set_error(GSLIC_ERR_INVALID_ARG, "more than 2^31 (Gaussian, tile) instances");
-    const uint32_t R = hostbuf[0];
+    const int end_bit = sort_end_bit(T);
+    const uint32_t* const R_dev = cap ? geom.point_offsets + (P - 1) : nullptr;  // capacity mode: the count stays on the device
+    uint32_t R;
+    if (cap) {
+        // R = the number of instances the caller's binning buffer holds; the kernels stop at the real count (R_dev) and raise
+        // status bit 0 when it does not fit.  No host read (the reference blocks here, rasterizer_impl.cu:398).
+        R = capacity_for(cap->binning_bytes, [&](uint32_t r) { size_t b; BinningState::carve(nullptr, (size_t)r, end_bit, no_color, &b); return b; });
+    } else {
+        GS_TRY(fetch_counts(geom.point_offsets + (P - 1), geom.flags, hostbuf, s));  // host needs R to size the binning buffer (rasterizer_impl.cu:398)
+        if (hostbuf[1] & 2u) return set_error(GSLIC_ERR_HIP, "a chained-scan look-back wait timed out (device preempted?): the forward was abandoned");
+        if (hostbuf[1] & 4u) return set_error(GSLIC_ERR_INVALID_ARG, "more than 2^31 (Gaussian, tile) instances");
+        if (prm->prefiltered && (hostbuf[1] & 1u)) return set_error(GSLIC_ERR_PREFILTERED, "a point was culled although prefiltered is set");
+        if (hostbuf[0] > 0x7fffffffu) return set_error(GSLIC_ERR_INVALID_ARG, "more than 2^31 (Gaussian, tile) instances");
+        R = hostbuf[0];
+    }
 
     size_t bin_bytes;
-    const int end_bit = sort_end_bit(T);
     BinningState::carve(nullptr, (size_t)R, end_bit, no_color, &bin_bytes);
-    char* bin_base = binning_alloc(binning_ctx, bin_bytes);
+    char* bin_base = cap ? cap->binning : binning_alloc(binning_ctx, bin_bytes);
     if (!bin_base) return set_error(GSLIC_ERR_ALLOC, "binning allocator returned NULL for %zu bytes", bin_bytes);
     BinningState bin = BinningState::carve(align256(bin_base), (size_t)R, end_bit, no_color, nullptr);
 
     if (R > 0) {
         KeybuildArgs ka;
         ka.P = P; ka.gx = gx; ka.gy = gy; ka.rec = geom.rec; ka.order = order; ka.offsets = geom.point_offsets;
-        ka.tile_keys = bin.tile_keys[0]; ka.gauss = bin.gauss[0]; ka.gauss_start = geom.gauss_start;
+        ka.tile_keys = bin.tile_keys[0]; ka.gauss = bin.gauss[0]; ka.gauss_start = geom.gauss_start; ka.cap = R; ka.status = geom.flags;
         GS_TRY(launch_keybuild(ka, s));
         DEBUG_SYNC(prm, s);
         // Level 2: stable sort of the instances on the tile id alone (ceil(log2(tiles)/8) digit passes, 2 at 1080p), carrying the
@@ -376,9 +418,9 @@ int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_
         SortBuffers sb;
         for (int i = 0; i < 2; i++) { sb.keys[i] = bin.tile_keys[i]; sb.v0[i] = bin.slots[i]; sb.v1[i] = bin.gauss[i]; }
         sb.v0_identity = true;
-        GS_TRY(radix_sort_u32(sb, bin.plan, bin.sort_scratch, (onesweep_mask() & 2) != 0, K_SORT_HIST, K_SORT_SCATTER, s));
+        GS_TRY(radix_sort_u32(sb, bin.plan, bin.sort_scratch, (onesweep_mask() & 2) != 0, K_SORT_HIST, K_SORT_SCATTER, s, R_dev));
         DEBUG_SYNC(prm, s);
-        GS_TRY(launch_finalize_ranges(R, bin.sorted_tiles(), img.ranges, s));
+        GS_TRY(launch_finalize_ranges(R, R_dev, bin.sorted_tiles(), img.ranges, s));
         DEBUG_SYNC(prm, s);
     }
 
@@ -387,12 +429,16 @@ int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_
     uint32_t B = 0;
     if (!no_color) {
         GS_TRY(launch_bucket_scan(T, img.ranges, img.bucket_offsets, s));
-        GS_TRY(fetch_counts(img.bucket_offsets + (T - 1), nullptr, hostbuf, s));  // rasterizer_impl.cu:442
-        if (hostbuf[1] & 2u) return set_error(GSLIC_ERR_HIP, "a sort look-back / chained-scan wait timed out (device preempted?): the forward was abandoned");
-        B = hostbuf[0];
+        if (cap) {
+            B = capacity_for(cap->sample_bytes, [&](uint32_t b) { size_t n; SampleState::carve(nullptr, (size_t)b, &n); return n; });
+        } else {
+            GS_TRY(fetch_counts(img.bucket_offsets + (T - 1), nullptr, hostbuf, s));  // rasterizer_impl.cu:442
+            if (hostbuf[1] & 2u) return set_error(GSLIC_ERR_HIP, "a sort look-back / chained-scan wait timed out (device preempted?): the forward was abandoned");
+            B = hostbuf[0];
+        }
         size_t smp_bytes;
         SampleState::carve(nullptr, (size_t)B, &smp_bytes);
-        char* smp_base = sample_alloc(sample_ctx, smp_bytes);
+        char* smp_base = cap ? cap->sample : sample_alloc(sample_ctx, smp_bytes);
         if (!smp_base) return set_error(GSLIC_ERR_ALLOC, "sample allocator returned NULL for %zu bytes", smp_bytes);
         smp = SampleState::carve(align256(smp_base), (size_t)B, nullptr);
     }
@@ -401,13 +447,47 @@ int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_
     ra.W = prm->width; ra.H = prm->height; ra.gx = gx; ra.gy = gy; ra.no_color = prm->no_color;
     ra.ranges = img.ranges; ra.point_list = bin.point_list(); ra.rec = geom.rec; ra.bucket_offsets = img.bucket_offsets;
     ra.bucket_to_tile = smp.bucket_to_tile; ra.ckpt = smp.ckpt; ra.pix_final = img.pix_final; ra.max_contrib = img.max_contrib;
-    ra.out_color = out_color; ra.out_final_T = out_final_T;
+    ra.out_color = out_color; ra.out_final_T = out_final_T; ra.capB = B; ra.status = geom.flags;
     GS_TRY(launch_render_fwd(ra, s));
     DEBUG_SYNC(prm, s);
+    if (cap) {
+        hipLaunchKernelGGL(forward_status_kernel, dim3(1), dim3(1), 0, s, (const uint32_t*)(geom.point_offsets + (P - 1)),
+                           no_color ? (const uint32_t*)nullptr : (const uint32_t*)(img.bucket_offsets + (T - 1)), (const uint32_t*)geom.flags,
+                           cap->status_out);
+        GS_HIP(hipGetLastError());
+    }
 
     *num_rendered = (int32_t)R;
     *num_buckets = (int32_t)B;
     return GSLIC_OK;
+}
+
+extern "C" {
+int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_alloc, void* geom_ctx, gslic_alloc_fn binning_alloc,
+                            void* binning_ctx, gslic_alloc_fn img_alloc, void* img_ctx, gslic_alloc_fn sample_alloc,
+                            void* sample_ctx, const float* background, const float* means3D, const float* dc, const float* shs,
+                            const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
+                            const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                            float* out_color, float* out_final_T, int32_t* radii, int32_t* num_rendered, int32_t* num_buckets,
+                            void* stream)
+{
+    return rasterize_forward_impl(prm, geom_alloc, geom_ctx, binning_alloc, binning_ctx, img_alloc, img_ctx, sample_alloc, sample_ctx, nullptr,
+                                  background, means3D, dc, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                                  cam_pos, out_color, out_final_T, radii, num_rendered, num_buckets, stream);
+}
+
+int gslic_rasterize_forward_capacity(const gslic_raster_params* prm, char* geom_buffer, size_t geom_bytes, char* binning_buffer,
+                                     size_t binning_bytes, char* img_buffer, size_t img_bytes, char* sample_buffer, size_t sample_bytes,
+                                     const float* background, const float* means3D, const float* dc, const float* shs,
+                                     const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
+                                     const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                     float* out_color, float* out_final_T, int32_t* radii, int32_t* capacity_R, int32_t* capacity_B,
+                                     uint32_t* status, void* stream)
+{
+    ForwardCapacity cap{geom_buffer, binning_buffer, img_buffer, sample_buffer, geom_bytes, binning_bytes, img_bytes, sample_bytes, status};
+    return rasterize_forward_impl(prm, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &cap, background, means3D, dc, shs,
+                                  colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, out_color,
+                                  out_final_T, radii, capacity_R, capacity_B, stream);
 }
 
 static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, int32_t B, const float* background, const float* means3D,
@@ -452,7 +532,7 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
     rb.W = prm->width; rb.H = prm->height; rb.gx = gx; rb.B = B;
     rb.ranges = img.ranges; rb.point_list = bin.point_list(); rb.inst_slot = bin.inst_slot(); rb.rec = geom.rec;
     rb.bucket_offsets = img.bucket_offsets; rb.bucket_to_tile = smp.bucket_to_tile; rb.ckpt = smp.ckpt; rb.pix_final = img.pix_final;
-    rb.max_contrib = img.max_contrib; rb.dL_dpix = dL_dpix; rb.partials = bin.partials;
+    rb.max_contrib = img.max_contrib; rb.dL_dpix = dL_dpix; rb.partials = bin.partials; rb.status = geom.flags; rb.T = T;
     GS_TRY(launch_render_bwd(rb, s));
     DEBUG_SYNC(prm, s);
 
@@ -472,6 +552,7 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
         for (int g = 0; g < 6; g++) { pb.adam.p[g] = adam->param[g]; pb.adam.m[g] = adam->exp_avg[g]; pb.adam.v[g] = adam->exp_avg_sq[g]; pb.adam.lr[g] = adam->lr[g]; }
         pb.adam.b1 = adam->b1; pb.adam.b2 = adam->b2; pb.adam.eps = adam->eps; pb.adam.on = 1;
     }
+    pb.status = geom.flags;
     pb.cam_partials = nullptr; pb.cam_out = nullptr;
     if (dL_dcam) {
         // scratch: the depth-sort ping-pong arrays of the geometry buffer are dead after the forward.  The per-wave partial rows

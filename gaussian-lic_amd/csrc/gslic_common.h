@@ -132,7 +132,9 @@ struct SortBuffers {
     bool v0_identity;
 };
 size_t sort_scratch_bytes(const SortPlan& plan);
-int radix_sort_u32(const SortBuffers& b, const SortPlan& plan, void* scratch, bool onesweep, int id_hist, int id_scatter, hipStream_t s);
+// n_dev != NULL: the real element count (<= plan.n, which is then the capacity the launches are sized for) is read on the device.
+int radix_sort_u32(const SortBuffers& b, const SortPlan& plan, void* scratch, bool onesweep, int id_hist, int id_scatter, hipStream_t s,
+                   const uint32_t* n_dev = nullptr);
 
 // opaque scratch layouts ----------------------------------------------------------------------------------
 struct GeomState {

@@ -27,9 +27,12 @@ struct KeybuildArgs {
     uint32_t* tile_keys;       // [R] out: tile id per emission slot
     uint32_t* gauss;           // [R] out: Gaussian id per emission slot
     uint32_t* gauss_start;     // [P] out: first emission slot of each visible Gaussian
+    uint32_t cap;              // slots available in tile_keys / gauss (capacity mode; the exact R otherwise)
+    uint32_t* status;          // device status words: [2] |= 1 when an instance did not fit (nothing is written past cap)
 };
 int launch_keybuild(const KeybuildArgs& a, hipStream_t s);
-int launch_finalize_ranges(uint32_t R, const uint32_t* sorted_tiles, uint2* ranges, hipStream_t s);
+// R_dev != NULL: the real instance count is read on the device and R is the capacity the launch is sized for
+int launch_finalize_ranges(uint32_t R, const uint32_t* R_dev, const uint32_t* sorted_tiles, uint2* ranges, hipStream_t s);
 int launch_bucket_scan(int T, const uint2* ranges, uint32_t* bucket_offsets, hipStream_t s);  // scan.hip
 
 struct RenderFwdArgs {
@@ -44,6 +47,8 @@ struct RenderFwdArgs {
     uint32_t* max_contrib;
     float* out_color;
     float* out_final_T;
+    uint32_t capB;             // checkpoint buckets available in bucket_to_tile / ckpt
+    uint32_t* status;          // device status words: [2] |= 2 when the buckets did not fit; a non-zero [2] on entry aborts the kernel
 };
 int launch_render_fwd(const RenderFwdArgs& a, hipStream_t s);
 
@@ -60,6 +65,8 @@ struct RenderBwdArgs {
     const uint32_t* max_contrib;
     const float* dL_dpix;
     float4* partials;
+    const uint32_t* status;    // device status words: a non-zero [2] (capacity overflow in the forward) aborts the kernel
+    int T;                     // tiles: bucket_offsets[T - 1] is the real bucket count (B may be a capacity)
 };
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
 
@@ -82,6 +89,7 @@ struct PreprocessBwdArgs {
     const float4* partials;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_ddc, *dL_dsh, *dL_dscale, *dL_drot;
     AdamFusedArgs adam;
+    const uint32_t* status;  // device status words: a non-zero [2] (capacity overflow in the forward) aborts the kernel (no gradients, no Adam)
     float* cam_partials;  // optional [ceil(P/64)][32]: per-wave sums of the 27 camera-gradient terms (NULL: not computed)
     float* cam_out;       // [35] = dL_dviewmatrix[16] | dL_dprojmatrix[16] | dL_dcampos[3]
 };

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
             if (tile_min_power_p(cA, cB, cC, mx, my, rcpx, rcpy, tx, ty) <= thr) {
                 const uint32_t key = (uint32_t)(ty * a.gx + tx);
                 if (staged) { st[off - wbase] = key; sg[off - wbase] = (uint32_t)idx; }
-                else { a.tile_keys[off] = key; a.gauss[off] = (uint32_t)idx; }
+                else if (off < a.cap) { a.tile_keys[off] = key; a.gauss[off] = (uint32_t)idx; }
                 off++;
             }
             if (++tx == x1) { tx = x0; ++ty; }
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
                 const uint32_t o = soff + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 const uint32_t key = (uint32_t)(ty * a.gx + tx);
                 if (staged) { st[o - wbase] = key; sg[o - wbase] = sidx; }
-                else { a.tile_keys[o] = key; a.gauss[o] = sidx; }
+                else if (o < a.cap) { a.tile_keys[o] = key; a.gauss[o] = sidx; }
             }
             soff += (uint32_t)__popcll(m);
         }
@@ -332,15 +332,21 @@ __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (uint32_t k = (uint32_t)lane; k < wcount; k += 64u) {
-            a.tile_keys[wbase + k] = st[k];
-            a.gauss[wbase + k] = sg[k];
+            if (wbase + k < a.cap) {
+                a.tile_keys[wbase + k] = st[k];
+                a.gauss[wbase + k] = sg[k];
+            }
         }
     }
+    // capacity mode: the instances of this wave do not all fit — report it; every later stage of the step then stands down
+    if (lane == 0 && wcount != 0 && wbase + wcount > a.cap) atomicOr(a.status + 2, 1u);
 }
 
 // tile ranges of the sorted instance list (identifyTileRanges, rasterizer_impl.cu:131-156)
-__global__ __launch_bounds__(256) void finalize_ranges_kernel(uint32_t R, const uint32_t* __restrict__ tiles, uint2* __restrict__ ranges)
+__global__ __launch_bounds__(256) void finalize_ranges_kernel(uint32_t R_cap, const uint32_t* __restrict__ R_dev, const uint32_t* __restrict__ tiles,
+                                                              uint2* __restrict__ ranges)
 {
+    const uint32_t R = R_dev ? (*R_dev < R_cap ? *R_dev : R_cap) : R_cap;
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= R) return;
     const uint32_t tile = tiles[k];
@@ -373,10 +379,10 @@ int launch_keybuild(const KeybuildArgs& a, hipStream_t s)
     GS_LAUNCH(K_KEYBUILD, keybuild_kernel, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
     return GSLIC_OK;
 }
-int launch_finalize_ranges(uint32_t R, const uint32_t* sorted_tiles, uint2* ranges, hipStream_t s)
+int launch_finalize_ranges(uint32_t R, const uint32_t* R_dev, const uint32_t* sorted_tiles, uint2* ranges, hipStream_t s)
 {
     if (R == 0) return GSLIC_OK;
-    GS_LAUNCH(K_FINALIZE_LISTS, finalize_ranges_kernel, dim3((R + 255u) / 256u), dim3(256), 0, s, R, sorted_tiles, ranges);
+    GS_LAUNCH(K_FINALIZE_LISTS, finalize_ranges_kernel, dim3((R + 255u) / 256u), dim3(256), 0, s, R, R_dev, sorted_tiles, ranges);
     return GSLIC_OK;
 }
 }  // namespace gslic

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
     // the 14 small-group gradients of every Gaussian of the block, group-major (xyz | dc | opacity | scale | rotation), for the
     // cooperative float4 Adam below: per-thread 4-byte accesses at stride 12 / 16 B cost this kernel 0.29 ms of 0.86
     float* const lds_g = lds_sh;  // overlays the head of lds_sh between "SH rows consumed" and "dL_dsh rows written" (LDS per wave 15.2 -> 11.6 KB)
+    if (a.status[2] != 0u) return;  // capacity overflow in the forward: nothing of this step is valid — no gradients, no Adam
     const int idx = blockIdx.x * BS + threadIdx.x;
     const int M = a.M;
     lds_vis[threadIdx.x] = (idx < a.P && a.radii[idx] > 0) ? 1 : 0;

@@ -48,10 +48,18 @@ __device__ __forceinline__ uint32_t popc_below(uint64_t mask)
 // Per-block digit histogram.  Order inside the block is irrelevant here, so each thread takes 16 CONTIGUOUS keys as four
 // 16-byte loads.  LDS atomics serialise on equal addresses, and high digits of nearly sorted keys are equal across a whole
 // wave: that case is detected with one ballot and costs one atomic for the wave.
-__global__ __launch_bounds__(RS_THREADS) void sort_hist_kernel(const uint32_t* __restrict__ keys, size_t n, int shift,
-                                                               uint32_t* __restrict__ hist, uint32_t nblk)
+// n_dev != NULL (capacity mode): the element count lives on the device; `n` is then the capacity the launch was sized for.
+__device__ __forceinline__ size_t sort_count(size_t n, const uint32_t* n_dev)
+{
+    if (!n_dev) return n;
+    const size_t m = (size_t)*n_dev;
+    return m < n ? m : n;
+}
+__global__ __launch_bounds__(RS_THREADS) void sort_hist_kernel(const uint32_t* __restrict__ keys, size_t n_cap, const uint32_t* __restrict__ n_dev,
+                                                               int shift, uint32_t* __restrict__ hist, uint32_t nblk)
 {
     __shared__ uint32_t h[256];
+    const size_t n = sort_count(n_cap, n_dev);
     h[threadIdx.x] = 0;
     __syncthreads();
     const size_t t0 = (size_t)blockIdx.x * RS_TILE + (size_t)threadIdx.x * RS_ITEMS;
@@ -85,9 +93,10 @@ __global__ __launch_bounds__(RS_THREADS) void sort_hist_kernel(const uint32_t* _
 }
 
 // digit totals of every pass in one sweep over the keys (onesweep)
-__global__ __launch_bounds__(RS_THREADS) void sort_ghist_kernel(const uint32_t* __restrict__ keys, size_t n, int passes,
-                                                                uint32_t* __restrict__ ghist /*[passes][256], zeroed*/)
+__global__ __launch_bounds__(RS_THREADS) void sort_ghist_kernel(const uint32_t* __restrict__ keys, size_t n_cap, const uint32_t* __restrict__ n_dev,
+                                                                int passes, uint32_t* __restrict__ ghist /*[passes][256], zeroed*/)
 {
+    const size_t n = sort_count(n_cap, n_dev);
     __shared__ uint32_t h[4 * 256];
     for (int i = threadIdx.x; i < passes * 256; i += RS_THREADS) h[i] = 0;
     __syncthreads();
@@ -125,6 +134,7 @@ struct SortPassArgs {
     uint32_t* kout;
     uint32_t* vout[2];
     size_t n;
+    const uint32_t* n_dev;       // capacity mode: the real count (<= n) on the device, NULL otherwise
     int shift;
     uint32_t nblk;
     const uint32_t* table;       // classic: scanned [256][nblk] histogram; onesweep: gbase[256] of this pass
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_scatter_kernel(const SortPass
     for (int w = 0; w < RS_WAVES; w++) cnt[w][tid] = 0;
     __syncthreads();
     const uint32_t tile = ONESWEEP ? s_tile : blockIdx.x;
-    const size_t n = a.n;
+    const size_t n = sort_count(a.n, a.n_dev);
     const int shift = a.shift;
 
     const size_t blk_base = (size_t)tile * RS_TILE;
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_scatter_kernel(const SortPass
     }
     __syncthreads();
 
-    const size_t remain = n - blk_base;
+    const size_t remain = n > blk_base ? n - blk_base : 0;
     const uint32_t nvalid = remain < (size_t)RS_TILE ? (uint32_t)remain : (uint32_t)RS_TILE;
     for (uint32_t j = tid; j < nvalid; j += RS_THREADS) {
         const uint32_t k = skeys[j];
@@ -288,11 +298,12 @@ size_t sort_scratch_bytes(const SortPlan& plan)
 }
 
 template <int NV>
-static int sort_impl(const SortBuffers& b, const SortPlan& plan, void* scratch, bool onesweep, int id_hist, int id_scatter, hipStream_t s)
+static int sort_impl(const SortBuffers& b, const SortPlan& plan, const uint32_t* n_dev, void* scratch, bool onesweep, int id_hist, int id_scatter,
+                     hipStream_t s)
 {
     const unsigned nblk = (unsigned)plan.nblk;
     SortPassArgs a;
-    a.n = plan.n; a.nblk = nblk; a.status = nullptr; a.ticket = nullptr; a.timeout = onesweep ? device_status_word() : nullptr;
+    a.n = plan.n; a.n_dev = n_dev; a.nblk = nblk; a.status = nullptr; a.ticket = nullptr; a.timeout = onesweep ? device_status_word() : nullptr;
     const size_t ssb = scan_state_bytes(plan.hist_elems);
     uint32_t* hist = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + 4 * ssb);
     unsigned long long* status = reinterpret_cast<unsigned long long*>(scratch);
@@ -302,7 +313,7 @@ static int sort_impl(const SortBuffers& b, const SortPlan& plan, void* scratch, 
     if (!onesweep) GS_HIP(hipMemsetAsync(scratch, 0, (size_t)plan.passes * ssb, s));  // one chained-scan state per pass
     if (onesweep) {
         GS_HIP(hipMemsetAsync(scratch, 0, onesweep_bytes(plan), s));
-        GS_LAUNCH(id_hist, sort_ghist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, (const uint32_t*)b.keys[0], plan.n, plan.passes, ghist);
+        GS_LAUNCH(id_hist, sort_ghist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, (const uint32_t*)b.keys[0], plan.n, n_dev, plan.passes, ghist);
         GS_LAUNCH(K_SCAN_SPINE, sort_gbase_kernel, dim3(plan.passes), dim3(256), 0, s, (const uint32_t*)ghist, gbase);
     }
     for (int p = 0; p < plan.passes; p++) {
@@ -316,7 +327,7 @@ static int sort_impl(const SortBuffers& b, const SortPlan& plan, void* scratch, 
             a.table = gbase + p * 256; a.status = status + (size_t)p * plan.nblk * 256; a.ticket = tickets + p;
             GS_LAUNCH(id_scatter, (sort_scatter_kernel<NV, true>), dim3(nblk), dim3(RS_THREADS), 0, s, a);
         } else {
-            GS_LAUNCH(id_hist, sort_hist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, a.kin, plan.n, a.shift, hist, nblk);
+            GS_LAUNCH(id_hist, sort_hist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, a.kin, plan.n, n_dev, a.shift, hist, nblk);
             GS_TRY(scan_u32_chained(hist, nullptr, hist, plan.hist_elems, true, static_cast<char*>(scratch) + (size_t)p * ssb, s));
             a.table = hist;
             GS_LAUNCH(id_scatter, (sort_scatter_kernel<NV, false>), dim3(nblk), dim3(RS_THREADS), 0, s, a);
@@ -325,12 +336,13 @@ static int sort_impl(const SortBuffers& b, const SortPlan& plan, void* scratch, 
     return GSLIC_OK;
 }
 
-int radix_sort_u32(const SortBuffers& b, const SortPlan& plan, void* scratch, bool onesweep, int id_hist, int id_scatter, hipStream_t s)
+int radix_sort_u32(const SortBuffers& b, const SortPlan& plan, void* scratch, bool onesweep, int id_hist, int id_scatter, hipStream_t s,
+                   const uint32_t* n_dev)
 {
     if (plan.n == 0) return GSLIC_OK;
     if (plan.n > 0xffffffffull) return set_error(GSLIC_ERR_INVALID_ARG, "radix sort: more than 2^32 elements");
-    return b.v1[0] ? sort_impl<2>(b, plan, scratch, onesweep, id_hist, id_scatter, s)
-                   : sort_impl<1>(b, plan, scratch, onesweep, id_hist, id_scatter, s);
+    return b.v1[0] ? sort_impl<2>(b, plan, n_dev, scratch, onesweep, id_hist, id_scatter, s)
+                   : sort_impl<1>(b, plan, n_dev, scratch, onesweep, id_hist, id_scatter, s);
 }
 
 }  // namespace gslic

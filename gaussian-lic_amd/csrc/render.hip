@@ -65,15 +65,20 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
     const int tile = blockIdx.x;
     const int lane = threadIdx.x;
     const int tx0 = (tile % a.gx) * GS_TILE, ty0 = (tile / a.gx) * GS_TILE;
+    if (a.status[2] != 0u) return;  // capacity mode: the instance lists did not fit; the host re-runs the step with larger buffers
     const uint2 range = a.ranges[tile];
     const int n = (int)(range.y - range.x);
     const bool color = !a.no_color;
 
     uint32_t bbm = 0;
+    bool fits = true;  // capacity mode: this tile's checkpoints have room in the sample buffer
     if (color) {
         bbm = (tile == 0) ? 0u : a.bucket_offsets[tile - 1];
         const int nb = (n + GS_BUCKET - 1) / GS_BUCKET;
-        for (int b = lane; b < nb; b += 64) a.bucket_to_tile[bbm + b] = (uint32_t)tile;
+        fits = bbm + (uint32_t)nb <= a.capB;
+        if (!fits && lane == 0) atomicOr(a.status + 2, 2u);
+        if (fits)
+            for (int b = lane; b < nb; b += 64) a.bucket_to_tile[bbm + b] = (uint32_t)tile;
     }
 
     const int px = tx0 + (lane & 15);
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
 
     for (int base = 0; base < n; base += GS_BUCKET) {
         if (__all(T[0] < 0.f && T[1] < 0.f && T[2] < 0.f && T[3] < 0.f)) break;
-        if (color) {
+        if (color && fits) {
             float4* ck = a.ckpt + ((size_t)(bbm + (uint32_t)(base / GS_BUCKET)) * GS_TILE_PIX) + lane;
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(64) void render_bwd_strict_kernel(RenderBwdArgs a)
     __shared__ uint32_t itags[64];
     const int lane = threadIdx.x;
     const uint32_t bucket = blockIdx.x;
-    if (bucket >= (uint32_t)a.B) return;
+    if (a.status[2] != 0u || bucket >= a.bucket_offsets[a.T - 1]) return;  // capacity overflow in the forward / B was a capacity
     const uint32_t tile = a.bucket_to_tile[bucket];
     const uint2 range = a.ranges[tile];
     const uint32_t n = range.y - range.x;
@@ -477,6 +482,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     __shared__ uint32_t itags[64];
     const int lane = threadIdx.x;
     const uint32_t bucket = blockIdx.x;
+    if (a.status[2] != 0u || bucket >= a.bucket_offsets[a.T - 1]) return;  // capacity overflow in the forward / B was a capacity
     const uint32_t tile = a.bucket_to_tile[bucket];
     const uint2 range = a.ranges[tile];
     const uint32_t n = range.y - range.x;

@@ -81,6 +81,55 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     return (R.value, B.value, out_color, out_final_T, radii, allocs[0].tensor, allocs[1].tensor, allocs[2].tensor, allocs[3].tensor)
 
 
+class CapacityBuffers:
+    """Caller-owned scratch + outputs of gslic_rasterize_forward_capacity for one (P, W, H): nothing is allocated per step, every
+    address is stable, so the step can be captured in a hipGraph.  cap_R / cap_B: how many instances / checkpoint buckets fit."""
+
+    def __init__(self, P, W, H, cap_R, cap_B, device, no_color=False):
+        L = _lib.lib()
+        self.P, self.W, self.H, self.no_color = int(P), int(W), int(H), bool(no_color)
+        mk = lambda n: torch.empty(int(n), dtype=torch.uint8, device=device)
+        self.geom = mk(L.gslic_geom_bytes(self.P))
+        self.img = mk(L.gslic_img_bytes(self.W, self.H))
+        self.binning = mk(L.gslic_binning_bytes(int(cap_R), int(no_color)))
+        self.sample = mk(L.gslic_sample_bytes(int(cap_B)) if not no_color else 0)
+        self.status = torch.zeros(4, dtype=torch.int32, device=device)
+        self.color = torch.zeros(3, self.H, self.W, dtype=torch.float32, device=device)
+        self.final_T = torch.empty(self.H, self.W, dtype=torch.float32, device=device)
+        self.radii = torch.empty(self.P, dtype=torch.int32, device=device)
+        self.cap_R = self.cap_B = 0   # filled by the first forward (what the library derives from the buffer sizes)
+
+    def read_status(self):
+        """(R, B, overflow bits, forwards that fitted) — synchronises."""
+        r, b, bits, good = (int(v) for v in self.status.cpu().tolist())
+        return r & 0xffffffff, b & 0xffffffff, bits, good & 0xffffffff
+
+
+def rasterize_gaussians_capacity(bufs, background, means3D, opacity, scales, rotations, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+                                 limx_neg, limx_pos, limy_neg, limy_pos, dc, sh, degree, campos, raw_params=False):
+    """gslic_rasterize_forward_capacity: RasterizeGaussiansCUDA without a host round trip, into caller-owned buffers.  The tensors must
+    already be contiguous fp32 (no copies are made: addresses have to be stable for graph capture).  Returns the same 9-tuple as
+    rasterize_gaussians with (cap_R, cap_B) in place of (R, B) — pass them on to rasterize_gaussians_backward unchanged."""
+    L = _lib.lib()
+    P = means3D.size(0)
+    assert P == bufs.P and P > 0
+    M = sh.size(1) if sh is not None and sh.size(0) != 0 else 0
+    for t in (means3D, dc, opacity, scales, rotations, viewmatrix, projmatrix, campos):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    prm = _params(P, degree, M, bufs.H, bufs.W, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier, False, False,
+                  bufs.no_color, raw_params)
+    p = _lib.ptr
+    cR, cB = ctypes.c_int32(0), ctypes.c_int32(0)
+    bp = lambda t: ctypes.c_void_p(t.data_ptr()) if t.numel() else None
+    _lib.check(L.gslic_rasterize_forward_capacity(
+        ctypes.byref(prm), bp(bufs.geom), bufs.geom.numel(), bp(bufs.binning), bufs.binning.numel(), bp(bufs.img), bufs.img.numel(),
+        bp(bufs.sample), bufs.sample.numel(), p(background), p(means3D), p(dc), p(sh if M > 0 else None), None, p(opacity), p(scales),
+        p(rotations), None, p(viewmatrix), p(projmatrix), p(campos), p(bufs.color), p(bufs.final_T), p(bufs.radii), ctypes.byref(cR),
+        ctypes.byref(cB), p(bufs.status), _lib.current_stream_ptr()))
+    bufs.cap_R, bufs.cap_B = cR.value, cB.value
+    return (cR.value, cB.value, bufs.color, bufs.final_T, bufs.radii, bufs.geom, bufs.binning, bufs.img, bufs.sample)
+
+
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                                  projmatrix, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, dL_dout_color, dc, sh,
                                  degree, campos, geomBuffer, R, binningBuffer, imageBuffer, B, sampleBuffer, lambda_erank, debug,

@@ -284,3 +284,116 @@ def render_fwd_bwd(model, camera, dL_dimage, bg):
     for p in model.parameters():
         p.grad = None
     return visible
+
+
+class GraphedStep:
+    """training_step_fused captured in a hipGraph: forward in capacity mode (gslic_rasterize_forward_capacity: no host round trip, the
+    reference blocks twice per forward, rasterizer_impl.cu:398,442) -> loss kernels -> backward with the Adam update inside, replayed
+    with ONE launch per step.  Camera matrices and the ground-truth image are read from static device buffers that `step()` refreshes
+    before the replay.  Single GPU (the N > 1 path has an exchange between backward and Adam and runs eagerly).
+
+    The scratch capacities come from one eager forward (R, B) with `headroom`; the instance / bucket counts of a step stay on the
+    device.  If they outgrow the buffers the step turns itself into a no-op (status bits; no gradients, no Adam) and `check()` —
+    called every `check_every` steps, and by the caller at the end — grows the buffers, re-captures and repeats exactly the steps
+    that did not fit.  extend() changes P: build a new GraphedStep afterwards."""
+
+    def __init__(self, model, camera, gt_image, bg, headroom=1.25, check_every=16):
+        from . import rasterizer as rz
+        assert not _dist_on(), "GraphedStep is the single-GPU path"
+        self.model, self.bg, self.headroom, self.check_every = model, bg, float(headroom), int(check_every)
+        dev = model.device
+        self.H, self.W = int(camera.image_height), int(camera.image_width)
+        self.cam = camera
+        self.view = camera.d_world_view_transform.clone()
+        self.proj = camera.d_full_proj_transform.clone()
+        self.campos = camera.d_camera_center.clone()
+        self.gt = gt_image.clone()
+        self.fl = loss_utils.FusedLoss(LAMBDA_DSSIM)
+        self.e = torch.empty(0, device=dev)
+        # sizes from one eager forward of the current state
+        with torch.no_grad():
+            R, B = rz.rasterize_gaussians(bg, model.xyz.detach(), self.e, model.opacity.detach(), model.scaling.detach(), model.rotation.detach(),
+                                          1.0, self.e, self.view, self.proj, float(camera.tanfovx), float(camera.tanfovy), self.H, self.W,
+                                          float(camera.limx_neg), float(camera.limx_pos), float(camera.limy_neg), float(camera.limy_pos),
+                                          model.features_dc.detach(), model.features_rest.detach(), model.sh_degree, self.campos, False, False,
+                                          False, raw_params=True)[:2]
+        self.cap_R, self.cap_B = int(R * self.headroom) + 65536, int(B * self.headroom) + 1024
+        self.graph, self.bufs = None, None
+        self.steps_issued = 0      # replays since the last check
+        self.good_seen = 0         # value of status[3] at the last check
+        self.recaptures = 0
+        self._capture()
+
+    def _eager(self):
+        from . import rasterizer as rz
+        m, c = self.model, self.cam
+        xyz, dc, rest = m.xyz.detach(), m.features_dc.detach(), m.features_rest.detach()
+        op, sc, rot = m.opacity.detach(), m.scaling.detach(), m.rotation.detach()
+        scal = (float(c.tanfovx), float(c.tanfovy), float(c.limx_neg), float(c.limx_pos), float(c.limy_neg), float(c.limy_pos))
+        (R, B, image, _T, radii, geom, binning, img, sample) = rz.rasterize_gaussians_capacity(
+            self.bufs, self.bg, xyz, op, sc, rot, 1.0, self.view, self.proj, *scal, dc, rest, m.sh_degree, self.campos, raw_params=True)
+        dL_dimage, self.terms = self.fl.forward_backward(image, self.gt)
+        rz.rasterize_gaussians_backward(self.bg, xyz, radii, self.e, sc, rot, 1.0, self.e, self.view, self.proj, scal[0], scal[1], *scal[2:],
+                                        dL_dimage, dc, rest, m.sh_degree, self.campos, geom, R, binning, img, B, sample, m.lambda_erank, False,
+                                        raw_params=True, adam=self._adam)
+
+    def _capture(self):
+        from . import rasterizer as rz
+        dev = self.model.device
+        self.bufs = rz.CapacityBuffers(self.model.P, self.W, self.H, self.cap_R, self.cap_B, dev)
+        self._adam = self.model.optimizer.fused_descriptor()
+        self.good_seen = 0
+        # warm-up on a side stream (allocations of the loss scratch, library one-offs), then capture.  The warm-up and the capture
+        # pass both execute the step, so the parameters are saved and restored around them.
+        names = self.model.NAMES
+        saved = [(self.model._buf[n][:self.model.P].clone(), self.model._m[n][:self.model.P].clone(), self.model._v[n][:self.model.P].clone())
+                 for n in names]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():
+            self._eager()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g), torch.no_grad():
+            self._eager()
+        torch.cuda.synchronize()
+        for n, (p, m1, m2) in zip(names, saved):
+            self.model._buf[n][:self.model.P].copy_(p); self.model._m[n][:self.model.P].copy_(m1); self.model._v[n][:self.model.P].copy_(m2)
+        self.bufs.status.zero_()
+        self.graph = g
+        self.steps_issued = 0
+
+    def step(self, camera=None, gt_image=None):
+        """One optimiser step (replay).  Returns the device tensor [mean L1, mean SSIM] of this step's loss terms."""
+        if camera is not None and camera is not self.cam:
+            self.view.copy_(camera.d_world_view_transform); self.proj.copy_(camera.d_full_proj_transform); self.campos.copy_(camera.d_camera_center)
+            assert (float(camera.tanfovx), float(camera.tanfovy)) == (float(self.cam.tanfovx), float(self.cam.tanfovy)), "intrinsics are baked into the graph"
+        if gt_image is not None and gt_image.data_ptr() != self.gt.data_ptr():
+            self.gt.copy_(gt_image)
+        self.graph.replay()
+        self.steps_issued += 1
+        self.model.optimizer.count_step()
+        if self.check_every and self.steps_issued >= self.check_every:
+            self.check()
+        return self.terms
+
+    def check(self):
+        """Synchronise, read the status words; steps that did not fit were no-ops: grow the buffers, re-capture and repeat them.
+        Returns the number of steps that had to be repeated."""
+        R, B, bits, good = self.bufs.read_status()
+        missed = self.steps_issued - (good - self.good_seen)
+        self.good_seen, self.steps_issued = good, 0
+        if bits & 3 or missed > 0:
+            self.cap_R = max(self.cap_R, int(R * self.headroom) + 65536)
+            self.cap_B = max(self.cap_B, int(B * self.headroom) + 1024) if not (bits & 1) else int(self.cap_B * 1.5) + 1024
+            self.recaptures += 1
+            self._capture()
+            for _ in range(max(missed, 0)):
+                self.graph.replay()
+            self.steps_issued = max(missed, 0)
+        return max(missed, 0)
+
+    @property
+    def visible(self):
+        return self.bufs.radii > 0

@@ -114,6 +114,35 @@ int gslic_rasterize_forward(
     void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * gslic_rasterize_forward_capacity — the same forward with NO host round trip (the reference blocks the host twice to learn R and B,
+ * rasterizer_impl.cu:398,442; gslic_rasterize_forward keeps that contract for the allocator callbacks).  The caller owns the four
+ * scratch buffers and passes their sizes; geom / img must hold gslic_geom_bytes(P) / gslic_img_bytes(W, H), binning and sample are
+ * CAPACITIES: the number of instances / checkpoint buckets they hold is derived from their size (gslic_binning_bytes /
+ * gslic_sample_bytes are monotonic), every launch is sized for that capacity and stops at the real count, which stays on the device.
+ * Nothing in the call allocates, synchronises or copies to the host, so a whole training step can be captured in a hipGraph.
+ *
+ *  capacity_R, capacity_B   host ints: the capacities in use.  Pass THEM as R and B to gslic_rasterize_backward* (the buffer
+ *                           layout depends on them); the backward stops at the real counts on the device.
+ *  status                   DEVICE uint32[4], written by the last kernel of the call: [0] = R, [1] = B (real counts), [2] = bits —
+ *                           1: the instances did not fit into `binning`, 2: the buckets did not fit into `sample`, 4: prefiltered
+ *                           violation — [3] += 1 when bits 1 and 2 are clear (zero the word once; it counts the forwards that fitted).
+ *  On overflow (bit 1 or 2) nothing is written out of bounds, out_color / out_final_T are unspecified, and a following
+ *  gslic_rasterize_backward* on these buffers does NOTHING (no gradients, no Adam update): the host re-runs the step with larger
+ *  buffers once it has seen the bits.  All other arguments as gslic_rasterize_forward; results are bit-identical to it.
+ */
+int gslic_rasterize_forward_capacity(
+    const gslic_raster_params* prm,
+    char* geom_buffer, size_t geom_bytes,
+    char* binning_buffer, size_t binning_bytes,
+    char* img_buffer, size_t img_bytes,
+    char* sample_buffer, size_t sample_bytes,
+    const float* background, const float* means3D, const float* dc, const float* shs, const float* colors_precomp,
+    const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+    float* out_color, float* out_final_T, int32_t* radii,
+    int32_t* capacity_R, int32_t* capacity_B, uint32_t* status, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * gslic_rasterize_backward — replaces CudaRasterizer::Rasterizer::backward (rasterizer_impl.cu:476-581),
  * reached from RasterizeGaussiansBackwardCUDA (rasterize_points.cu:151-246).
  *
