@@ -223,7 +223,7 @@ def main():
         other = {"host": host["mode"], "value": round(n_extra * world / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3),
                  "steps": n_extra}
         host["mode"] = args.host
-        if world == 1 and args.host == "fused" and not args.split_adam:
+        if world == 1 and not trainer._dist_on() and args.host == "fused" and not args.split_adam:
             # the same step as ONE hipGraph replay: capacity-mode forward (no host round trip), loss, backward + Adam
             gs = trainer.GraphedStep(model, cam, gt, bg, check_every=0)
             sec = timed_loop(gs.step, n_extra)
@@ -231,7 +231,7 @@ def main():
             graphed_res = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra,
                            "host_round_trips_per_step": 0, "steps_repeated_for_capacity": repeated, "capacity_R": gs.bufs.cap_R, "capacity_B": gs.bufs.cap_B}
             del gs
-        if world == 1 and args.host == "fused":
+        if world == 1 and not trainer._dist_on() and args.host == "fused":
             torch.cuda.empty_cache()
             growth = growth_schedule(args, dev)
 

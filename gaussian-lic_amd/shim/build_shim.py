@@ -34,6 +34,7 @@ def build(force=False):
 REF_SRC = "/root/reference/src"
 CHECK = os.path.join(PKG, "dropin_check")
 CHECK_GROUPS = os.path.join(PKG, "dropin_check_groups")
+CHECK_DIST = os.path.join(PKG, "dropin_check_dist")
 
 
 def build_dropin_check(force=False, groups=False):
@@ -43,6 +44,9 @@ def build_dropin_check(force=False, groups=False):
     reference's src/ on the include path, i.e. with this repo's optim_utils.h (one Adam launch per step) instead of the reference's."""
     if not os.path.isdir(REF_SRC):
         return None
+    if groups == "dist":   # + the N > 1 exchange step over c10d / RCCL (shim/include/gslic_dist.h) between loss.backward() and step()
+        return _build_check(CHECK_DIST, ["-DGSLIC_DIST", "-DUSE_C10D_NCCL", "-DUSE_ROCM", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(HERE, "include"),
+                                         "-I", os.path.join(HERE, "include", "nccl_fwd"), "-isystem", "/opt/rocm/include"], force)
     if groups:
         return _build_check(CHECK_GROUPS, ["-I", os.path.join(HERE, "include")], force)
     return _build_check(CHECK, [], force)
@@ -53,7 +57,8 @@ def _build_check(CHECK, first_includes, force):
     import torch
     from torch.utils import cpp_extension
     src = os.path.join(HERE, "dropin_check.cpp")
-    newest = max(os.path.getmtime(src), os.path.getmtime(OUT), os.path.getmtime(os.path.join(HERE, "include", "optim_utils.h")))
+    newest = max(os.path.getmtime(src), os.path.getmtime(OUT), os.path.getmtime(os.path.join(HERE, "include", "optim_utils.h")),
+                 os.path.getmtime(os.path.join(HERE, "include", "gslic_dist.h")))
     if not force and os.path.exists(CHECK) and os.path.getmtime(CHECK) > newest:
         return CHECK
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
@@ -76,3 +81,4 @@ if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
     print(build_dropin_check(force="--force" in sys.argv))
     print(build_dropin_check(force="--force" in sys.argv, groups=True))
+    print(build_dropin_check(force="--force" in sys.argv, groups="dist"))

@@ -7,6 +7,10 @@
 #include "rasterizer/rasterizer.h"  // reference
 #include "loss_utils.h"             // reference
 #include "optim_utils.h"            // reference
+#ifdef GSLIC_DIST
+#include "gslic_dist.h"             // the N > 1 exchange step (this repo): RANK / WORLD_SIZE / MASTER_PORT from the environment
+#include <cstdlib>
+#endif
 
 #include <fstream>
 #include <iostream>
@@ -42,8 +46,18 @@ int main(int argc, char** argv)
     torch::Tensor rotation = leaf(load(d + "/rotation.f32", {P, 4})), opacity = leaf(load(d + "/opacity.f32", {P, 1}));
     torch::Tensor dc = leaf(load(d + "/dc.f32", {P, 1, 3}));
     torch::Tensor rest = M > 0 ? leaf(load(d + "/rest.f32", {P, M, 3})) : leaf(torch::zeros({P, 0, 3}, torch::kCUDA));
-    torch::Tensor view = load(d + "/view.f32", {4, 4}), proj = load(d + "/proj.f32", {4, 4}), campos = load(d + "/campos.f32", {3});
-    torch::Tensor gt = load(d + "/gt.f32", {3, H, W});
+#ifdef GSLIC_DIST
+    const int rank = std::getenv("RANK") ? std::atoi(std::getenv("RANK")) : 0, world = std::getenv("WORLD_SIZE") ? std::atoi(std::getenv("WORLD_SIZE")) : 1;
+    const int port = std::getenv("MASTER_PORT") ? std::atoi(std::getenv("MASTER_PORT")) : 29591;
+    const bool sparse = std::getenv("GSLIC_SPARSE_EXCHANGE") && std::atoi(std::getenv("GSLIC_SPARSE_EXCHANGE")) != 0;
+    // one process per GPU: the launcher gives every rank its device through HIP_VISIBLE_DEVICES, so "cuda:0" is this rank's GPU
+    auto pg = gslic::make_rccl_group("127.0.0.1", port, rank, world);
+    const std::string sfx = world > 1 ? "_" + std::to_string(rank) : "";   // rank k renders view k: view_k.f32, proj_k.f32, campos_k.f32, gt_k.f32
+#else
+    const std::string sfx;
+#endif
+    torch::Tensor view = load(d + "/view" + sfx + ".f32", {4, 4}), proj = load(d + "/proj" + sfx + ".f32", {4, 4}), campos = load(d + "/campos" + sfx + ".f32", {3});
+    torch::Tensor gt = load(d + "/gt" + sfx + ".f32", {3, H, W});
     torch::Tensor sc = load(d + "/scalars.f32", {6}).to(torch::kCPU);
     const float* s = sc.data_ptr<float>();
     torch::Tensor bg = torch::zeros({3}, torch::kFloat32).cuda();
@@ -77,11 +91,18 @@ int main(int argc, char** argv)
         auto loss = (1.0 - 0.2) * Ll1 + 0.2 * (1.0 - ssim_value);
         loss.backward();
         auto visible = radii > 0;
+#ifdef GSLIC_DIST
+        // the one exchange of the N-GPU step, between loss.backward() and step() (gaussian.cpp:697-707): SUM of the gradients, OR of the masks
+        visible = gslic::exchange_gradients(*pg, {xyz, dc, rest, opacity, scaling, rotation}, visible, sparse);
+#endif
         opt.set_visibility_and_N(visible, xyz.size(0));
         opt.step();
         opt.zero_grad(true);
         std::cout << "iter " << it << " loss " << loss.item<float>() << " visible " << visible.sum().item<int>() << std::endl;
     }
+#ifdef GSLIC_DIST
+    if (rank != 0) return 0;   // replicas are identical: rank 0 reports
+#endif
     save(d + "/out_image.f32", image);
     save(d + "/out_xyz.f32", xyz); save(d + "/out_scaling.f32", scaling); save(d + "/out_rotation.f32", rotation);
     save(d + "/out_opacity.f32", opacity); save(d + "/out_dc.f32", dc);

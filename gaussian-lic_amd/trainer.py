@@ -183,6 +183,35 @@ def allreduce_slab_async(slab, visible, model):
     return vis.bool(), works
 
 
+def allreduce_slab_sparse(slab, visible, model):
+    """The exchange restricted to the rows some view actually sees: MAX (= OR) of the visibility bytes first, then ONE SUM all-reduce
+    of a compacted slab holding only the rows of the OR-ed mask (every rank derives the same row list from the same mask), scattered
+    back into the full slab.  Rows outside the mask are invisible on every rank: their gradients are exact zeros everywhere and Adam
+    skips them.  Bytes on the links: 4 * 59 * |mask| instead of 4 * 59 * P — a SLAM view sees a fraction of the map, the synthetic
+    8-view rig ~85 % (tools/exchange_bytes.py).  Result identical to allreduce_slab (bit for bit at N = 2; for N > 2 the rank order of
+    the sum may differ per element).  Returns (reduced visibility, rows exchanged)."""
+    vis = visible.to(torch.uint8)
+    torch.distributed.all_reduce(vis, op=torch.distributed.ReduceOp.MAX)
+    mask = vis.bool()
+    idx = mask.nonzero(as_tuple=False).squeeze(1)          # (one host sync: the row count sizes the buffer; the MAX-reduce above already blocked)
+    P, V = slab.P, int(idx.numel())
+    if V == 0:
+        return mask, 0
+    rows = [slab.views[n].view(P, -1) for n in model.NAMES]
+    widths = [r.shape[1] for r in rows]
+    compact = torch.empty(V * sum(widths), device=slab.flat.device, dtype=slab.flat.dtype)
+    parts, off = [], 0
+    for r, w in zip(rows, widths):                          # group-major, like the slab itself
+        part = compact[off:off + V * w].view(V, w)
+        torch.index_select(r, 0, idx, out=part)
+        parts.append(part)
+        off += V * w
+    torch.distributed.all_reduce(compact, op=torch.distributed.ReduceOp.SUM)
+    for r, part in zip(rows, parts):
+        r.index_copy_(0, idx, part)
+    return mask, V
+
+
 def allreduce_gradients(grads, visible):
     """The per-step exchange: SUM of the concatenated gradient slab [P x (11+3K)] and MAX (= OR) of the visibility
     bytes.  One collective each; returns (list of reduced gradient views, reduced visibility)."""
@@ -254,7 +283,11 @@ def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=Tr
             cam.d_camera_center, geom, R, binning, img, B, sample, model.lambda_erank, False, raw_params=True, out=slab.views)
         visible = radii > 0
         if do_step:
-            if _dist_on():
+            if _dist_on() and os.environ.get("GSLIC_SPARSE_EXCHANGE") == "1":
+                visible, _rows = allreduce_slab_sparse(slab, visible, model)   # visible rows only: fewer bytes on the links, one gather / scatter pass
+                model.optimizer.set_visibility_and_N(visible, model.P)
+                model.optimizer.step(slab.grads(model))
+            elif _dist_on():
                 visible, works = allreduce_slab_async(slab, visible, model)
                 model.optimizer.set_visibility_and_N(visible, model.P)
                 grads = slab.grads(model)

@@ -144,3 +144,74 @@ def test_two_ranks_sharing_one_gpu_match_the_summed_gradient_step():
     assert ref.returncode == 0, se[-2000:]
     dref = [l for l in so.splitlines() if l.startswith("DIGEST")][-1].split()[2]
     assert d[0] == dref
+
+
+@pytest.mark.gpu
+def test_two_ranks_sparse_exchange_equals_dense():
+    """The visible-rows-only exchange (GSLIC_SPARSE_EXCHANGE=1: OR the masks, all-reduce the compacted rows, scatter back) on the
+    complete N = 2 step, two processes sharing the GPU: the replicas end bit-identical to the dense-slab trajectory."""
+    def run(rank, sparse, port):
+        env = dict(os.environ)
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("GSLIC_FORCE_DIST", None)
+        if sparse:
+            env["GSLIC_SPARSE_EXCHANGE"] = "1"
+        else:
+            env.pop("GSLIC_SPARSE_EXCHANGE", None)
+        return subprocess.Popen([sys.executable, "-c", TWO_RANK_SNIPPET.format(root=ROOT)], env=env, stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True)
+    digests = []
+    for sparse, port in ((False, "29571"), (True, "29573")):
+        procs = [run(0, sparse, port), run(1, sparse, port)]
+        outs = [p.communicate(timeout=600) for p in procs]
+        for p, (so, se) in zip(procs, outs):
+            assert p.returncode == 0, se[-2000:]
+        d = [[l for l in so.splitlines() if l.startswith("DIGEST")][-1].split()[2] for so, _ in outs]
+        assert d[0] == d[1]
+        digests.append(d[0])
+    assert digests[0] == digests[1]
+
+
+RCCL2_SNIPPET = r"""
+import os, sys, hashlib, torch
+sys.path.insert(0, {root!r})
+import gaussian_lic_amd
+from gaussian_lic_amd import trainer
+from gaussian_lic_amd.camera import synthetic_camera
+from gaussian_lic_amd.synthetic import random_scene, gt_image
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", rank); torch.cuda.set_device(dev)
+torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+W, H, P = 320, 192, 30000
+model = trainer.GaussianModel(random_scene(P, W, H, 3, 5), dev); model.training_setup()
+cam = synthetic_camera(W, H, rank).to_device(dev); gt = gt_image(H, W, seed=2 + rank).to(dev); bg = torch.zeros(3, device=dev)
+for _ in range(3):
+    trainer.training_step_fused(model, cam, gt, bg)
+torch.cuda.synchronize()
+h = hashlib.sha256()
+for t in (model.xyz, model.features_dc, model.features_rest, model.opacity, model.scaling, model.rotation):
+    h.update(t.detach().cpu().numpy().tobytes())
+print("DIGEST", rank, h.hexdigest())
+torch.distributed.barrier(); torch.distributed.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_two_ranks_two_gpus():
+    """The N = 2 step over RCCL proper (one process per GPU, backend nccl).  Needs two devices: skipped on the one-GPU test box, runs
+    wherever the driver has a multi-GPU node.  Both replicas must end bit-identical, and equal to the two-processes-one-GPU gloo run."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (RCCL refuses two ranks on one device)")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ)
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29581", RANK=str(rank), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("GSLIC_FORCE_DIST", None)
+        procs.append(subprocess.Popen([sys.executable, "-c", RCCL2_SNIPPET.format(root=ROOT)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    d = [[l for l in so.splitlines() if l.startswith("DIGEST")][-1].split()[2] for so, _ in outs]
+    assert d[0] == d[1]

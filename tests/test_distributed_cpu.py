@@ -55,6 +55,18 @@ def _worker(rank, world, port, q):
         for i in idx:
             assert torch.equal(slab.grads(_M())[i], red[i])
     assert sorted(seen) == [0, 1, 2, 3, 4, 5] and torch.equal(pvis, rvis)
+    # the visible-rows-only variant: a view's gradient rows are exact zeros where it does not see the Gaussian (what the backward writes)
+    for v, x in zip(slab.grads(_M()), grads):
+        v.copy_(x * vis.view(-1, *([1] * (x.dim() - 1))))
+    dense = [v.clone() for v in slab.grads(_M())]
+    dvis = trainer.allreduce_slab(slab, vis)
+    dense_red = [v.clone() for v in slab.grads(_M())]
+    for v, x in zip(slab.grads(_M()), dense):
+        v.copy_(x)
+    svis2, rows = trainer.allreduce_slab_sparse(slab, vis, _M())
+    assert torch.equal(svis2, dvis) and rows == int(dvis.sum())
+    for a, b in zip(slab.grads(_M()), dense_red):
+        assert torch.equal(a, b)      # bit for bit the dense result (two addends)
     q.put((rank, [r.clone().numpy() for r in red], rvis.numpy(), [x.numpy() for x in grads], vis.numpy()))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

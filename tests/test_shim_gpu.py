@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "gaussian-lic_amd", "libgslic_torch_shim.so")
 CHECK = os.path.join(ROOT, "gaussian-lic_amd", "dropin_check")
 CHECK_GROUPS = os.path.join(ROOT, "gaussian-lic_amd", "dropin_check_groups")
+CHECK_DIST = os.path.join(ROOT, "gaussian-lic_amd", "dropin_check_dist")
 
 
 def _load_shim():
@@ -100,6 +101,16 @@ def test_reference_host_code_drives_the_hip_kernels(tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         for n, a in first.items():
             np.testing.assert_array_equal(rd(n, (-1,)), a, err_msg=n)
+        # and with the N > 1 exchange step compiled in (shim/include/gslic_dist.h: c10d ProcessGroupNCCL = RCCL, all-reduce of the
+        # gradients and of the visibility mask between loss.backward() and step(), gaussian.cpp:697-707) in a group of ONE rank: the
+        # sums are the identity, dense and visible-rows-only alike, so the outputs stay bit-identical
+        if os.path.exists(CHECK_DIST):
+            for sparse, port in (("0", "29601"), ("1", "29603")):
+                env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_PORT=port, GSLIC_SPARSE_EXCHANGE=sparse, HSA_ENABLE_IPC_MODE_LEGACY="0")
+                r = subprocess.run([CHECK_DIST, d, str(P), str(W), str(H), "3", str(iters)], capture_output=True, text=True, timeout=300, env=env)
+                assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+                for n, a in first.items():
+                    np.testing.assert_array_equal(rd(n, (-1,)), a, err_msg=f"{n} (dist, sparse={sparse})")
 
 
 def test_shim_adam_rejects_noncontiguous_state():
@@ -122,3 +133,55 @@ def test_shim_adam_rejects_noncontiguous_state():
     torch.ops.gslic.adamUpdate(p1, gbase[:, :M], m1, v1, vis, 1e-3, 0.9, 0.999, 1e-15, N, M)
     torch.ops.gslic.adamUpdate(p2, gbase[:, :M].contiguous(), m2, v2, vis, 1e-3, 0.9, 0.999, 1e-15, N, M)
     assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+
+
+def test_reference_host_two_ranks_rccl(tmp_path):
+    """The reference's C++ host loop with the exchange step on TWO GPUs (one process per GPU over RCCL, rank k renders view k): the
+    parameters after three steps equal a single-process restatement (gradients of the two views summed, masks OR-ed, one Adam).
+    Skipped on a one-GPU box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    if not os.path.exists(CHECK_DIST):
+        pytest.skip("dropin_check_dist not built (needs /root/reference at build time)")
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import trainer
+    from gaussian_lic_amd.camera import synthetic_camera
+    from gaussian_lic_amd.synthetic import gt_image
+    P, W, H, iters = 30000, 320, 240, 3
+    raw, sc, camd, cam = make_scene("random", P, W, H, 3, 41)
+    d = str(tmp_path)
+    w = lambda name, t: np.ascontiguousarray(t, np.float32).tofile(os.path.join(d, name + ".f32"))
+    for k, n in (("xyz", "xyz"), ("scaling", "scaling"), ("rotation", "rotation"), ("opacity", "opacity"), ("features_dc", "dc"), ("features_rest", "rest")):
+        w(n, raw[k].numpy())
+    cams, gts = [synthetic_camera(W, H, k) for k in range(2)], [gt_image(H, W, seed=2 + k) for k in range(2)]
+    for k in range(2):
+        w(f"view_{k}", cams[k].world_view_transform); w(f"proj_{k}", cams[k].full_proj_transform); w(f"campos_{k}", cams[k].camera_center)
+        w(f"gt_{k}", gts[k].numpy())
+    w("scalars", np.array([cam.tanfovx, cam.tanfovy, cam.limx_neg, cam.limx_pos, cam.limy_neg, cam.limy_pos], np.float32))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_PORT="29611", HIP_VISIBLE_DEVICES=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([CHECK_DIST, d, str(P), str(W), str(H), "3", str(iters)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, so[-2000:] + se[-2000:]
+    dev = torch.device("cuda:0")
+    model = trainer.GaussianModel(raw, dev)
+    model.training_setup()
+    bg = torch.zeros(3, device=dev)
+    for c in cams:
+        c.to_device(dev)
+    for _ in range(iters):
+        acc, vis = None, None
+        for k in range(2):
+            _loss, v = trainer.training_step(model, cams[k], gts[k].to(dev), bg, do_step=False)
+            g = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in model.parameters()]
+            model.optimizer.zero_grad(True)
+            acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+            vis = v if vis is None else (vis | v)
+        model.optimizer.set_visibility_and_N(vis, model.P)
+        model.optimizer.step(acc)
+    rd = lambda name, shape: np.fromfile(os.path.join(d, f"out_{name}.f32"), np.float32).reshape(shape)
+    for name, t in (("xyz", model.xyz), ("scaling", model.scaling), ("rotation", model.rotation), ("opacity", model.opacity),
+                    ("dc", model.features_dc), ("rest", model.features_rest)):
+        assert rel_err(rd(name, tuple(t.shape)), t.detach().cpu().numpy()) < 1e-5, name
