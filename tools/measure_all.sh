@@ -8,28 +8,31 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="timeout 300 python $R/bench.py"
+B="timeout 600 python $R/bench.py"
+X="--no-cpu-baseline --no-extras --steps 100"
 {
-  $B 2>/dev/null | tail -1
-  $B --mode render --no-cpu-baseline 2>/dev/null | tail -1
-  $B --mode slam --no-cpu-baseline 2>/dev/null | tail -1
-  $B --split-adam --no-cpu-baseline 2>/dev/null | tail -1
-  $B --scene lidar --no-cpu-baseline 2>/dev/null | tail -1
-  $B --gaussians 5000000 --width 3840 --height 2160 --no-cpu-baseline --steps 10 2>/dev/null | tail -1
+  $B 2>/dev/null | tail -1                                                   # the driver's default line (config 3), every secondary leg
+  $B --mode render $X 2>/dev/null | tail -1                                  # bare fwd + bwd
+  $B --split-adam $X 2>/dev/null | tail -1                                   # Adam as its own launch (compute path of a rank at N > 1)
+  $B --graph $X 2>/dev/null | tail -1                                        # the step as one hipGraph replay
+  $B --scene lidar --gaussians 500000 $X 2>/dev/null | tail -1               # config 2 at its own size
+  $B --gaussians 5000000 --width 3840 --height 2160 $X --steps 30 2>/dev/null | tail -1   # config 5 shape on one GPU
+  GSLIC_STRICT_MATH=1 $B $X 2>/dev/null | tail -1                            # strict arithmetic of the blend kernels
 } > $OUT/${TAG}_bench_lines.jsonl
 # per-kernel durations
-timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG -- python $R/bench.py --steps 10 --warmup 4 --no-cpu-baseline > /tmp/prof_$TAG.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG -- python $R/bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-extras > /tmp/prof_$TAG.log 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/prof_$TAG -name "*.db" | head -1) $OUT/${TAG}_train_2M_1080p_kernel_stats > /dev/null
 # HBM traffic (separate passes), SQ counters
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf_$TAG -o f -- python $R/tools/pmc_run.py > /tmp/pf.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw_$TAG -o w -- python $R/tools/pmc_run.py > /tmp/pw.log 2>&1
-python $R/tools/pmc_extract.py $(find /tmp/pf_$TAG -name "*.db" | head -1) $(find /tmp/pw_$TAG -name "*.db" | head -1) $OUT/${TAG}_pmc_traffic.json > /dev/null
+python $R/tools/pmc_extract.py $(find /tmp/pf_$TAG -name "*.db" | head -1) $(find /tmp/pw_$TAG -name "*.db" | head -1) $OUT/${TAG}_pmc_traffic.json $TAG > /dev/null
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -d /tmp/sq_$TAG -o sq -- python $R/tools/pmc_run.py > /tmp/sq.log 2>&1
 python $R/tools/pmc_sq_extract.py $(find /tmp/sq_$TAG -name "*.db" | head -1) > $OUT/${TAG}_sq_counters.txt 2>&1
 # L2 hit rate and LDS bank conflicts (the "LDS-hit counters" of the north-star), one pass each
 timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -d /tmp/l2_$TAG -o l2 -- python $R/tools/pmc_run.py > /tmp/l2.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --kernel-trace -d /tmp/lds_$TAG -o lds -- python $R/tools/pmc_run.py > /tmp/lds.log 2>&1
 python $R/tools/pmc_cache_lds.py $(find /tmp/l2_$TAG -name "*.db" | head -1) $(find /tmp/lds_$TAG -name "*.db" | head -1) > $OUT/${TAG}_cache_lds.md 2>&1
-timeout 60 $R/tools/ubench/valu_rate > $OUT/${TAG}_ubench.txt 2>&1
+timeout 60 $R/tools/ubench/issue_rate > $OUT/${TAG}_ubench.txt 2>&1
+timeout 60 $R/tools/ubench/exec_rate >> $OUT/${TAG}_ubench.txt 2>&1
 timeout 60 $R/tools/ubench/hbm_rate >> $OUT/${TAG}_ubench.txt 2>&1
 ls -la $OUT | tail -12

@@ -22,7 +22,7 @@ def per_kernel(db, counter):
     return out
 
 
-def main(fetch_db, write_db, out):
+def main(fetch_db, write_db, out, tag="untagged"):
     f = per_kernel(fetch_db, "FETCH_SIZE")
     w = per_kernel(write_db, "WRITE_SIZE")
     GiB = float(1 << 30)
@@ -30,7 +30,7 @@ def main(fetch_db, write_db, out):
     # counters are in KB (rocprofv3 derived metrics); factors convert the reported value to true bytes on this access pattern
     fetch_factor = GiB / (f[cal][2] * 1024.0)
     write_factor = GiB / (w[cal][2] * 1024.0)
-    res = {"workload": "random-2000000-1920x1080", "calibration_kernel": cal, "fetch_factor": fetch_factor, "write_factor": write_factor,
+    res = {"workload": "random-2000000-1920x1080", "tag": tag, "calibration_kernel": cal, "fetch_factor": fetch_factor, "write_factor": write_factor,
            "note": "bytes = counter_KB * 1024 * factor; factors measured on a 1 GiB torch copy in the same runs (guide: FETCH_SIZE reads 1/2 on wide loads on gfx950)",
            "kernels": {}}
     for k in sorted(set(f) | set(w)):
@@ -53,4 +53,4 @@ def main(fetch_db, write_db, out):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])

@@ -19,6 +19,8 @@ __global__ __launch_bounds__(256) void k(float* out, float a, float b)
         else if (MODE == 7) asm volatile(REP8("v_pk_fma_f32 v[8:9], v[8:9], v[16:17], v[18:19]\n v_pk_fma_f32 v[10:11], v[10:11], v[18:19], v[16:17]\n v_pk_fma_f32 v[12:13], v[12:13], v[16:17], v[18:19]\n v_pk_fma_f32 v[14:15], v[14:15], v[18:19], v[16:17]\n") ::: "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15");
         else if (MODE == 8) asm volatile(REP8("v_pk_mul_f32 v[8:9], v[8:9], v[18:19]\n v_pk_mul_f32 v[10:11], v[10:11], v[16:17]\n v_pk_mul_f32 v[12:13], v[12:13], v[18:19]\n v_pk_mul_f32 v[14:15], v[14:15], v[16:17]\n") ::: "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15");
         else if (MODE == 9) asm volatile(REP8("v_exp_f32 v8, v8\n v_exp_f32 v9, v9\n v_exp_f32 v10, v10\n v_exp_f32 v11, v11\n") ::: "v8", "v9", "v10", "v11");
+        else if (MODE == 11) asm volatile(REP8("v_fma_f32 v8, v8, v16, v17\n v_fma_f32 v9, v9, v16, v17\n v_fma_f32 v10, v10, v16, v17\n v_fma_f32 v11, v11, v16, v17\n") ::: "v8", "v9", "v10", "v11");  // every instruction reads the SAME two multiplicand registers (what round 1's valu_rate did)
+        else if (MODE == 12) asm volatile(REP8("v_fma_f32 v8, v8, v16, v17\n v_fma_f32 v9, v9, v18, v19\n v_fma_f32 v10, v10, v16, v17\n v_fma_f32 v11, v11, v18, v19\n") ::: "v8", "v9", "v10", "v11");  // alternating operand pairs
         else if (MODE == 10) asm volatile(REP8("v_mov_b32_dpp v8, v17 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v9, v18 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v10, v19 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v11, v16 wave_shr:1 row_mask:0xf bank_mask:0xf\n") ::: "v8", "v9", "v10", "v11");
     }
     float r;
@@ -52,6 +54,8 @@ int main()
         run<8>("v_pk_mul_f32", d, w);
         run<9>("v_exp_f32", d, w);
         run<10>("v_mov_b32_dpp wave_shr:1", d, w);
+        run<11>("v_fma_f32, same two source registers in every instruction", d, w);
+        run<12>("v_fma_f32, two alternating source pairs", d, w);
     }
     return 0;
 }
