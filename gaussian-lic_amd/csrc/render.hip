@@ -477,9 +477,9 @@ struct BwdLane {
 
 __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
 {
-    __shared__ float4 grec[GS_TILE_PIX];   // dL/dpixel of the tile, by pixel index
-    __shared__ float2 init[64];            // start state {T, A} of the current chunk's pixels
-    __shared__ uint32_t itags[64];
+    __shared__ float4 grec[GS_TILE_PIX];       // dL/dpixel of the tile, by pixel index
+    __shared__ float2 init[GS_TILE_PIX + 1];   // start state {T, A} of the pixels that reach this bucket, in injection order; [256] = the empty entry
+    __shared__ uint32_t itags[GS_TILE_PIX + 1];
     const int lane = threadIdx.x;
     const uint32_t bucket = blockIdx.x;
     if (a.status[2] != 0u || bucket >= a.bucket_offsets[a.T - 1]) return;  // capacity overflow in the forward / B was a capacity
@@ -502,6 +502,25 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     }
 
     const int tx0 = (int)(tile % (uint32_t)a.gx) * GS_TILE, ty0 = (int)(tile / (uint32_t)a.gx) * GS_TILE;
+    const size_t plane = (size_t)a.H * a.W;
+    // ---- the tile's 256 pixels, four per lane, fetched at once
+    float4 ck[4], pf[4];
+    float fg[4][3];
+    bool inside[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int pidx = c * 64 + lane;
+        ck[c] = a.ckpt[(size_t)bucket * GS_TILE_PIX + pidx];
+        pf[c] = a.pix_final[(size_t)tile * GS_TILE_PIX + pidx];
+        const int px = tx0 + (pidx & 15), py = ty0 + (pidx >> 4);
+        inside[c] = px < a.W && py < a.H;
+        fg[c][0] = fg[c][1] = fg[c][2] = 0.f;
+        if (inside[c]) {
+            const size_t pid = (size_t)py * a.W + px;
+            fg[c][0] = a.dL_dpix[pid]; fg[c][1] = a.dL_dpix[plane + pid]; fg[c][2] = a.dL_dpix[2 * plane + pid];
+        }
+    }
+    // ---- this lane's Gaussian
     const float LOG2E = 1.4426950408889634f;
     BwdLane L;
     L.d0 = L.hAC = L.col_rg = (v2f){0.f, 0.f};
@@ -517,6 +536,63 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
         rop = r1.y > 0.f ? 1.0f / r1.y : 0.f; L.lop = __builtin_amdgcn_logf(r1.y);
         L.col_rg.x = r1.z; L.col_rg.y = r1.w; L.colb = r2.x;
     }
+
+    // ---- injection order.  A pixel injected at position i with rel_i Gaussians of this bucket still in front of its last contributor
+    // occupies the pipeline until step i + rel_i: injecting in DESCENDING order of rel makes max(i + rel_i) — the number of steps — minimal
+    // (the pixels that leave the pipeline early go last, so the drain is short: -12 % steps on the 2M / 1080p scene,
+    // profiles/r02_bwd_pipeline_model.txt).  Four classes of sixteen rel values, pixel order inside a class, get all but 2 % of that:
+    // sixteen ballots kept in scalar registers, popcounts and v_mbcnt — no sort.
+    uint32_t rel[4], key[4], pos[4];
+    uint64_t cm[4][4];   // cm[c][k]: lanes whose pixel of chunk c falls into class k
+    uint32_t ninj = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t ncp = inside[c] ? __float_as_uint(pf[c].w) : 0u;
+        rel[c] = ncp > bstart ? (ncp - bstart < 64u ? ncp - bstart : 64u) : 0u;  // 0: the pixel does not reach this bucket
+        key[c] = rel[c] ? (rel[c] - 1u) >> 4 : 4u;                               // 0..3, 4 = not injected
+#pragma unroll
+        for (int k = 0; k < 4; k++) cm[c][k] = __ballot(key[c] == (uint32_t)k);
+    }
+    {
+        uint32_t run = 0;  // classes in descending order, chunks in ascending order inside a class
+#pragma unroll
+        for (int k = 3; k >= 0; k--)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint64_t m = cm[c][k];
+                if (key[c] == (uint32_t)k) pos[c] = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                run += (uint32_t)__popcll(m);
+            }
+        ninj = run;
+    }
+    uint32_t last = 0;  // number of steps = max over the injected pixels of position + rel
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t e = rel[c] ? pos[c] + rel[c] : 0u;
+        last = e > last ? e : last;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)last, d, 64);
+        last = o > last ? o : last;
+    }
+    const uint32_t nsteps = readlane_u(last, 0);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t pidx = (uint32_t)(c * 64 + lane);
+        grec[pidx] = make_float4(fg[c][0], fg[c][1], fg[c][2], 0.f);
+        if (rel[c]) {
+            float A0 = (ck[c].y - pf[c].x) * fg[c][0];  // ar = checkpoint colour - final colour (backward.cu:522-523), dotted with dL/dpixel
+            A0 = __builtin_fmaf(ck[c].z - pf[c].y, fg[c][1], A0);
+            A0 = __builtin_fmaf(ck[c].w - pf[c].z, fg[c][2], A0);
+            init[pos[c]] = make_float2(ck[c].x, A0);
+            itags[pos[c]] = (rel[c] << 16) | ((pidx >> 4) << 8) | ((pidx & 15u) << 4);
+        }
+    }
+    if (lane == 0) { init[GS_TILE_PIX] = make_float2(0.f, 0.f); itags[GS_TILE_PIX] = 0u; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
     // loop constants in VGPRs: a literal or SGPR operand doubles the issue cost of the instruction that reads it
     float c099 = 0.99f, c255 = 1.0f / 255.0f;
     v2f kneg = {-0.0625f, -1.0f};
@@ -524,72 +600,27 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     asm volatile("" : "+v"(c099), "+v"(c255), "+v"(kneg), "+v"(kcmp));
     v2f acc_S = {0.f, 0.f}, acc_cxy = {0.f, 0.f}, acc_rg = {0.f, 0.f};
     float acc_cw = 0, acc_op = 0, acc_b = 0;
-    const size_t plane = (size_t)a.H * a.W;
+    v2f st = {0.f, 0.f}, nst;  // {T, A}: the state travelling through the lanes, and the injection fetched one step ahead
+    uint32_t tag = 0, ntag;
 
-    v2f st = {0.f, 0.f}, nst = {0.f, 0.f};  // {T, A}: the state travelling through the lanes, and the injection fetched one step ahead
-    uint32_t tag = 0, ntag = 0;
-
-    // 64-pixel feed chunk (register double buffer: chunk c+1 is in flight while chunk c streams through)
-    float4 ck, pf;
-    float fg0, fg1, fg2;
-    bool inside;
-    auto load_chunk = [&](int c) {
-        const int pidx = c * 64 + lane;
-        ck = a.ckpt[(size_t)bucket * GS_TILE_PIX + pidx];
-        pf = a.pix_final[(size_t)tile * GS_TILE_PIX + pidx];
-        const int px = tx0 + (pidx & 15), py = ty0 + (pidx >> 4);
-        inside = px < a.W && py < a.H;
-        fg0 = fg1 = fg2 = 0.f;
-        if (inside) {
-            const size_t pid = (size_t)py * a.W + px;
-            fg0 = a.dL_dpix[pid]; fg1 = a.dL_dpix[plane + pid]; fg2 = a.dL_dpix[2 * plane + pid];
-        }
-    };
-    load_chunk(0);
-#pragma unroll 1
-    for (int c = 0; c < 4; c++) {
-        // park this chunk in LDS, then start the next chunk's global loads
-        const uint32_t ncp = inside ? __float_as_uint(pf.w) : 0u;
-        const uint32_t pidx = (uint32_t)(c * 64 + lane);
-        const uint32_t rel = ncp > bstart ? (ncp - bstart < 64u ? ncp - bstart : 64u) : 0u;
-        float A0 = (ck.y - pf.x) * fg0;  // ar = checkpoint colour - final colour (backward.cu:522-523), dotted with dL/dpixel
-        A0 = __builtin_fmaf(ck.z - pf.y, fg1, A0);
-        A0 = __builtin_fmaf(ck.w - pf.z, fg2, A0);
-        __builtin_amdgcn_wave_barrier();  // the previous chunk's last read of init[] / itags[] precedes these writes
-        grec[pidx] = make_float4(fg0, fg1, fg2, 0.f);
-        init[lane] = make_float2(ck.x, A0);
-        itags[lane] = (rel << 16) | ((pidx >> 4) << 8) | ((pidx & 15u) << 4);
-        uint64_t active = __ballot(ncp > bstart);  // pixels that reach this bucket; the others contribute nothing here
-        if (c < 3) load_chunk(c + 1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (active) {
-            // two steps per trip.  Register sets: on entry (st, tag) holds the state and (nst, ntag) the fetched injection; inside, (st2, tag2)
-            // is the state after the first step (in the registers of nst / ntag) and (nst2, ntag2) the second injection (in those of st / tag)
-            GS_BW_PREFETCH(nst, ntag, __builtin_ctzll(active));
-            for (;;) {
-                v2f st2, nst2;
-                uint32_t tag2, ntag2;
-                active &= active - 1;
-                GS_BW_SHIFT_INJ(st2, tag2, nst, ntag, st, tag);
-                GS_BW_PREFETCH(nst2, ntag2, __builtin_ctzll(active | (1ull << 63)));  // (nothing left: a harmless read of entry 63)
-                GS_BW_BODY(st2, tag2);
-                if (!active) { st = st2; tag = tag2; break; }
-                active &= active - 1;
-                GS_BW_SHIFT_INJ(st, tag, nst2, ntag2, st2, tag2);
-                GS_BW_PREFETCH(nst, ntag, __builtin_ctzll(active | (1ull << 63)));
-                GS_BW_BODY(st, tag);
-                if (!active) break;
-            }
-        }
-    }
-    // drain: the last injected pixel still has to pass the bucket's remaining (valid) lanes
-    const int nvalid = (n - bstart) < (uint32_t)GS_BUCKET ? (int)(n - bstart) : GS_BUCKET;
-#pragma unroll 1
-    for (int dr = 1; dr < nvalid; dr++) {
-        st.x = shift_zero_f(st.x); st.y = shift_zero_f(st.y);
-        tag = shift_zero_u(tag);
+    // ---- the pipeline: nsteps steps, two per trip.  Register sets: on entry (st, tag) holds the state and (nst, ntag) the fetched injection;
+    // inside, (st2, tag2) is the state after the first step (in the registers of nst / ntag) and (nst2, ntag2) the second injection (in those
+    // of st / tag).  Past the last pixel the empty entry is injected: the drain needs no code of its own.
+    uint32_t sidx = 0;
+    GS_BW_PREFETCH(nst, ntag, 0);
+    for (;;) {
+        v2f st2, nst2;
+        uint32_t tag2, ntag2;
+        GS_BW_SHIFT_INJ(st2, tag2, nst, ntag, st, tag);
+        ++sidx;
+        GS_BW_PREFETCH(nst2, ntag2, sidx < ninj ? sidx : (uint32_t)GS_TILE_PIX);
+        GS_BW_BODY(st2, tag2);
+        if (sidx >= nsteps) break;
+        GS_BW_SHIFT_INJ(st, tag, nst2, ntag2, st2, tag2);
+        ++sidx;
+        GS_BW_PREFETCH(nst, ntag, sidx < ninj ? sidx : (uint32_t)GS_TILE_PIX);
         GS_BW_BODY(st, tag);
+        if (sidx >= nsteps) break;
     }
 
     if (valid) {

@@ -39,6 +39,25 @@ print(f"useful (pixel,gaussian) pairs {pairs_useful/1e6:.1f}M = {100*pairs_usefu
 kk = np.array([k for k, r in zip(b_k, b_run) if r])
 print("injected pixels per running bucket: mean %.0f  p10 %d  p50 %d  p90 %d;  buckets with < 32 px: %.1f%%, < 64 px: %.1f%%" % (
     kk.mean(), np.percentile(kk, 10), np.percentile(kk, 50), np.percentile(kk, 90), 100 * (kk < 32).mean(), 100 * (kk < 64).mean()))
+# what ordering the injected pixels by descending remaining depth (rel) would save: a pixel injected at position i needs i + rel_i steps
+sorted_steps = 0
+for t in range(len(n)):
+    for b in range(nb[t]):
+        if b * 64 >= mc[t]: continue
+        rel = np.clip(tiles[t] - b * 64, 0, 64)
+        rel = np.sort(rel[rel > 0])[::-1]
+        sorted_steps += int((np.arange(rel.size) + rel).max())
+print(f"steps with the pixels of a bucket injected in descending order of their remaining depth: {sorted_steps/1e6:.2f}M ({100*sorted_steps/steps_compact:.0f}% of current)")
+for width in (4, 8, 16, 32):   # coarse classes of `width` consecutive rel values, pixel-index order inside a class
+    cs = 0
+    for t in range(len(n)):
+        for b in range(nb[t]):
+            if b * 64 >= mc[t]: continue
+            rel = np.clip(tiles[t] - b * 64, 0, 64)
+            rel = rel[rel > 0]
+            order = np.argsort(-((rel - 1) // width), kind="stable")
+            cs += int((np.arange(rel.size) + rel[order]).max())
+    print(f"  ... in {64 // width} classes of {width} rel values: {cs/1e6:.2f}M ({100*cs/steps_compact:.0f}% of current)")
 B = tot_buckets
 for K in (1, 2, 4, 8, 16, 32):
     steps = 0; waves = 0; longest = 0; pads = 0; boundaries = 0
