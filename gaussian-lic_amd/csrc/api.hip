@@ -428,7 +428,7 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
     memset(&smp, 0, sizeof(smp));
     uint32_t B = 0;
     if (!no_color) {
-        GS_TRY(launch_bucket_scan(T, img.ranges, img.bucket_offsets, s));
+        GS_TRY(launch_bucket_scan(T, img.ranges, img.bucket_offsets, img.max_contrib, s));
         if (cap) {
             B = capacity_for(cap->sample_bytes, [&](uint32_t b) { size_t n; SampleState::carve(nullptr, (size_t)b, &n); return n; });
         } else {

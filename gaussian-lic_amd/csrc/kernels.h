@@ -33,7 +33,7 @@ struct KeybuildArgs {
 int launch_keybuild(const KeybuildArgs& a, hipStream_t s);
 // R_dev != NULL: the real instance count is read on the device and R is the capacity the launch is sized for
 int launch_finalize_ranges(uint32_t R, const uint32_t* R_dev, const uint32_t* sorted_tiles, uint2* ranges, hipStream_t s);
-int launch_bucket_scan(int T, const uint2* ranges, uint32_t* bucket_offsets, hipStream_t s);  // scan.hip
+int launch_bucket_scan(int T, const uint2* ranges, uint32_t* bucket_offsets, uint32_t* max_contrib /* zeroed */, hipStream_t s);  // scan.hip
 
 struct RenderFwdArgs {
     int W, H, gx, gy, no_color;

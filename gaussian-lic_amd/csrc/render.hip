@@ -58,11 +58,16 @@ __device__ __forceinline__ float strip_max_p2(float hA, float hC, float nB, floa
 // final_T and n_contrib then equal the reference kernels' bit for bit.  The default (fast) variant pre-scales the conic by log2(e),
 // works in tile-relative coordinates and uses v_exp_f32 directly; it differs by rounding only, which flips the alpha < 1/255 /
 // T < 1e-4 decisions of a few (pixel, Gaussian) pairs per million (counted in tests/test_fullsize_reference_gpu.py).
-template <bool STRICT>
+// SPLIT = waves per tile (1, 2 or 4; blockIdx.y): each takes 4 / SPLIT of the tile's four 16x4 strips.  The kernel's duration is set by its
+// longest tiles (one wave alone on a SIMD issues a VALU instruction every 4.3 cycles, half the rate of a busy SIMD), so the default
+// splits every tile over two waves: +9 % instructions (the per-entry setup is repeated), half the latency of a long tile.
+template <bool STRICT, int SPLIT>
 __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
 {
+    constexpr int QN = 4 / SPLIT;          // strips (= pixels per lane) of this wave
     __shared__ float4 s_rec[3 * GS_BUCKET];
     const int tile = blockIdx.x;
+    const int q0 = (int)blockIdx.y * QN;   // first strip of this wave
     const int lane = threadIdx.x;
     const int tx0 = (tile % a.gx) * GS_TILE, ty0 = (tile / a.gx) * GS_TILE;
     if (a.status[2] != 0u) return;  // capacity mode: the instance lists did not fit; the host re-runs the step with larger buffers
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
         const int nb = (n + GS_BUCKET - 1) / GS_BUCKET;
         fits = bbm + (uint32_t)nb <= a.capB;
         if (!fits && lane == 0) atomicOr(a.status + 2, 2u);
-        if (fits)
+        if (fits && q0 == 0)
             for (int b = lane; b < nb; b += 64) a.bucket_to_tile[bbm + b] = (uint32_t)tile;
     }
 
@@ -85,24 +90,36 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
     const int pyb = ty0 + (lane >> 4);
     // The sign of T carries the `done` flag (forward.cu:352,439-443): T > 0 = still blending, T < 0 = finished with
     // transmittance |T| (T never reaches 0: blending stops below 1e-4).  One register and no flag bookkeeping per pixel.
-    float T[4], Cr[4], Cg[4], Cb[4];
-    uint32_t last[4];
+    float T[QN], Cr[QN], Cg[QN], Cb[QN];
+    uint32_t last[QN];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int py = pyb + 4 * q;
+    for (int q = 0; q < QN; q++) {
+        const int py = pyb + 4 * (q0 + q);
         T[q] = (px < a.W && py < a.H) ? 1.0f : -1.0f;
         Cr[q] = Cg[q] = Cb[q] = 0.0f;
         last[q] = 0;
     }
     const float LOG2E = 1.4426950408889634f;
+    // loop constants in VGPRs (a literal or SGPR operand doubles the issue cost of the instruction that reads it: tools/ubench/issue_rate)
+    float c099 = 0.99f, c255 = 1.0f / 255.0f, c1e4 = 0.0001f;
+    float lyq[QN];
+#pragma unroll
+    for (int q = 0; q < QN; q++) {
+        lyq[q] = (float)((lane >> 4) + 4 * (q0 + q));
+        asm volatile("" : "+v"(lyq[q]));
+    }
+    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(c1e4));
 
     for (int base = 0; base < n; base += GS_BUCKET) {
-        if (__all(T[0] < 0.f && T[1] < 0.f && T[2] < 0.f && T[3] < 0.f)) break;
+        bool alldone = true;
+#pragma unroll
+        for (int q = 0; q < QN; q++) alldone = alldone && (T[q] < 0.f);
+        if (__all(alldone)) break;
         if (color && fits) {
             float4* ck = a.ckpt + ((size_t)(bbm + (uint32_t)(base / GS_BUCKET)) * GS_TILE_PIX) + lane;
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (T[q] > 0.f) ck[q * 64] = make_float4(T[q], Cr[q], Cg[q], Cb[q]);
+            for (int q = 0; q < QN; q++)
+                if (T[q] > 0.f) ck[(q0 + q) * 64] = make_float4(T[q], Cr[q], Cg[q], Cb[q]);
         }
         const int m = (n - base) < GS_BUCKET ? (n - base) : GS_BUCKET;
         // each lane fetches one record and pre-scales its conic: exponent in base 2, relative to this lane-independent tile origin
@@ -140,21 +157,20 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
         s_rec[3 * lane + 2] = make_float4(fb, __uint_as_float(fmask), 0.f, 0.f);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        float4 n0 = s_rec[0], n1 = s_rec[1], n2 = s_rec[2];
-        for (int j = 0; j < m; j++) {
-            const float4 e0 = n0, e1 = n1, e2 = n2;
-            if (j + 1 < m) { n0 = s_rec[3 * (j + 1)]; n1 = s_rec[3 * (j + 1) + 1]; n2 = s_rec[3 * (j + 1) + 2]; }
-            const uint32_t smask = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(e2.y));
-            if (smask == 0u) continue;
+        // one list entry against this lane's four pixels.  STRICT: the reference's arithmetic with its branches.  Default: straight-line
+        // code — a pixel the entry does not blend into (finished, power > 0, alpha < 1/255) runs the same instructions with weight 0,
+        // which leaves its colour, transmittance and last contributor unchanged bit for bit; only the per-strip skip (wave-uniform) branches
+        auto blend_entry = [&](const float4 e0, const float4 e1, const float4 e2, const uint32_t contributor) {
+            const uint32_t smask = ((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(e2.y)) >> q0) & ((1u << QN) - 1u);  // this wave's strips
+            if (smask == 0u) return;
             const float gdx = e0.x, gdy = e0.y, hA = e0.z, nB = e0.w, hC = e1.x, op = e1.y, colr = e1.z, colg = e1.w, colb = e2.x;
-            const uint32_t contributor = (uint32_t)(base + j + 1);
             if constexpr (STRICT) {
 #pragma clang fp contract(off)
                 const float dxs = gdx - (float)px;  // float2 d = { xy.x - pixf.x, xy.y - pixf.y } (forward.cu:424)
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < QN; q++) {
                     if (!(smask & (1u << q))) continue;  // wave-uniform; conservative (no pixel of the strip reaches alpha >= 1/255)
-                    const float dys = gdy - (float)(pyb + 4 * q);
+                    const float dys = gdy - (float)(pyb + 4 * (q0 + q));
                     const float power = -0.5f * (hA * dxs * dxs + hC * dys * dys) - nB * dxs * dys;
                     const float alpha = fminf(0.99f, op * expf(power));
                     const float test_T = T[q] * (1 - alpha);
@@ -168,40 +184,49 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
                         }
                     }
                 }
-                continue;
-            }
-            // e1.y holds log2(opacity) here.  The operation sequence below is repeated verbatim by the backward (GS_CH_BODY), so both
-            // sides compute bit-identical alphas and take the same alpha < 1/255 decisions for every (pixel, entry) pair
-            const float lop = op;
-            const float dx = gdx - lx;
-            const float pA = __builtin_fmaf(hA * dx, dx, lop);  // log2(e) * (-1/2 A dx^2) + log2(opacity)
-            const float pB = nB * dx;                           // log2(e) * (-B dx)
+            } else {
+                // e1.y holds log2(opacity) here.  The operation sequence below is repeated verbatim by the backward (GS_BW_BODY), so both
+                // sides compute bit-identical alphas and take the same alpha < 1/255 decisions for every (pixel, entry) pair
+                const float lop = op;
+                const float dx = gdx - lx;
+                const float pA = __builtin_fmaf(hA * dx, dx, lop);  // log2(e) * (-1/2 A dx^2) + log2(opacity)
+                const float pB = nB * dx;                           // log2(e) * (-B dx)
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (!(smask & (1u << q))) continue;  // wave-uniform
-                const float dy = gdy - (ly + (float)(4 * q));  // one rounding, as d0.y - py in the backward
-                const float p2 = __builtin_fmaf(pB, dy, __builtin_fmaf(hC * dy, dy, pA));  // log2(e) * power + log2(opacity)
-                const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(p2));
-                const float test_T = T[q] * (1.0f - alpha);  // negative (so < 1e-4) once the pixel is done
-                if (!(p2 > lop) && !(alpha < (1.0f / 255.0f)) && T[q] > 0.f) {
-                    if (test_T < 0.0001f) {
-                        T[q] = -T[q];  // done; this entry is NOT applied (forward.cu:438-443)
-                    } else {
-                        const float w = alpha * T[q];
-                        Cr[q] = __builtin_fmaf(colr, w, Cr[q]); Cg[q] = __builtin_fmaf(colg, w, Cg[q]); Cb[q] = __builtin_fmaf(colb, w, Cb[q]);
-                        T[q] = test_T;
-                        last[q] = contributor;
-                    }
+                for (int q = 0; q < QN; q++) {
+                    if (!(smask & (1u << q))) continue;  // wave-uniform
+                    const float dy = gdy - lyq[q];  // one rounding, as d0.y - py in the backward
+                    const float p2 = __builtin_fmaf(pB, dy, __builtin_fmaf(hC * dy, dy, pA));  // log2(e) * power + log2(opacity)
+                    const float alpha = fminf(c099, __builtin_amdgcn_exp2f(p2));
+                    const float test_T = T[q] * (1.0f - alpha);  // negative (so < 1e-4) once the pixel is done
+                    const bool ok = (T[q] > 0.f) & !(p2 > lop) & !(alpha < c255);   // forward.cu:431,437 on a live pixel
+                    const bool stop = ok & (test_T < c1e4);                         // done; this entry is NOT applied (forward.cu:438-443)
+                    const bool app = ok & !stop;
+                    const float w = app ? alpha * T[q] : 0.0f;
+                    Cr[q] = __builtin_fmaf(colr, w, Cr[q]); Cg[q] = __builtin_fmaf(colg, w, Cg[q]); Cb[q] = __builtin_fmaf(colb, w, Cb[q]);
+                    const float Tn = app ? test_T : T[q];
+                    T[q] = stop ? -Tn : Tn;
+                    last[q] = app ? contributor : last[q];
                 }
             }
+        };
+        // two entries per trip: the records alternate between two register sets, each fetched (LDS broadcast) while the other is blended
+        float4 a0 = s_rec[0], a1 = s_rec[1], a2 = s_rec[2], b0, b1, b2;
+        for (int j = 0; j < m; j += 2) {
+            const int jb = (j + 1 < m) ? j + 1 : j;   // (no second entry: a harmless re-read)
+            b0 = s_rec[3 * jb]; b1 = s_rec[3 * jb + 1]; b2 = s_rec[3 * jb + 2];
+            blend_entry(a0, a1, a2, (uint32_t)(base + j + 1));
+            if (j + 1 >= m) break;
+            const int ja = (j + 2 < m) ? j + 2 : j;
+            a0 = s_rec[3 * ja]; a1 = s_rec[3 * ja + 1]; a2 = s_rec[3 * ja + 2];
+            blend_entry(b0, b1, b2, (uint32_t)(base + j + 2));
         }
     }
 
     uint32_t mymax = 0;
     const size_t plane = (size_t)a.H * a.W;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int py = pyb + 4 * q;
+    for (int q = 0; q < QN; q++) {
+        const int py = pyb + 4 * (q0 + q);
         if (px < a.W && py < a.H) {
             const size_t pid = (size_t)py * a.W + px;
             a.out_final_T[pid] = fabsf(T[q]);
@@ -212,7 +237,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
             }
         }
         if (color) {
-            a.pix_final[(size_t)tile * GS_TILE_PIX + q * 64 + lane] = make_float4(Cr[q], Cg[q], Cb[q], __uint_as_float(last[q]));
+            a.pix_final[(size_t)tile * GS_TILE_PIX + (q0 + q) * 64 + lane] = make_float4(Cr[q], Cg[q], Cb[q], __uint_as_float(last[q]));
             mymax = last[q] > mymax ? last[q] : mymax;
         }
     }
@@ -222,7 +247,10 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
             const uint32_t o = (uint32_t)__shfl_xor((int)mymax, d, 64);
             mymax = o > mymax ? o : mymax;
         }
-        if (lane == 0) a.max_contrib[tile] = mymax;
+        if (lane == 0) {
+            if constexpr (SPLIT == 1) a.max_contrib[tile] = mymax;
+            else atomicMax(a.max_contrib + tile, mymax);  // zeroed by bucket_scan_kernel
+        }
     }
 }
 
@@ -638,8 +666,12 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
 
 int launch_render_fwd(const RenderFwdArgs& a, hipStream_t s)
 {
-    if (g_strict_math) GS_LAUNCH(K_RENDER_FWD, render_fwd_kernel<true>, dim3(a.gx * a.gy), dim3(64), 0, s, a);
-    else GS_LAUNCH(K_RENDER_FWD, render_fwd_kernel<false>, dim3(a.gx * a.gy), dim3(64), 0, s, a);
+    static const int split = [] { const char* e = getenv("GSLIC_FWD_SPLIT"); const int v = e ? atoi(e) : 2; return (v == 1 || v == 4) ? v : 2; }();
+    const unsigned T = (unsigned)(a.gx * a.gy);
+    if (g_strict_math) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 1>), dim3(T), dim3(64), 0, s, a);
+    else if (split == 1) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<false, 1>), dim3(T), dim3(64), 0, s, a);
+    else if (split == 4) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<false, 4>), dim3(T, 4), dim3(64), 0, s, a);
+    else GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<false, 2>), dim3(T, 2), dim3(64), 0, s, a);
     return GSLIC_OK;
 }
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s)

@@ -180,7 +180,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32
 
 // tiles' bucket counts and their inclusive scan in one single-block launch (rasterizer_impl.cu:433-441): T is the tile count of an
 // image, a few thousand
-__global__ __launch_bounds__(SCAN_THREADS) void bucket_scan_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ bucket_offsets)
+__global__ __launch_bounds__(SCAN_THREADS) void bucket_scan_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ bucket_offsets,
+                                                                   uint32_t* __restrict__ max_contrib)
 {
     __shared__ uint32_t lds[8];
     uint32_t carry = 0;
@@ -199,14 +200,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void bucket_scan_kernel(int T, const 
 #pragma unroll
         for (int i = 0; i < SCAN_ITEMS; i++) {
             run += v[i];
-            if (t0 + i < T) bucket_offsets[t0 + i] = run;
+            if (t0 + i < T) { bucket_offsets[t0 + i] = run; max_contrib[t0 + i] = 0u; }  // (render_fwd's waves of a tile combine their maxima with atomicMax)
         }
         carry += total;
     }
 }
-int launch_bucket_scan(int T, const uint2* ranges, uint32_t* bucket_offsets, hipStream_t s)
+int launch_bucket_scan(int T, const uint2* ranges, uint32_t* bucket_offsets, uint32_t* max_contrib, hipStream_t s)
 {
-    GS_LAUNCH(K_BUCKET_COUNT, bucket_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, T, ranges, bucket_offsets);
+    GS_LAUNCH(K_BUCKET_COUNT, bucket_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, T, ranges, bucket_offsets, max_contrib);
     return GSLIC_OK;
 }
 
