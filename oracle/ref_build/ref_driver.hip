@@ -23,7 +23,10 @@ struct Ctx {
     template <typename T> T* dev(const T* host, size_t n)
     {
         void* p = nullptr;
-        if (hipMalloc(&p, n * sizeof(T) + 256) != hipSuccess) return nullptr;
+        // generous slack behind EVERY array: the reference's kernels read past the end of several of them (SURVEY.md section 5 lists the known
+        // cases; a layout-dependent GPU page fault in its backward showed there are more), and a checker must not take the test process down
+        if (hipMalloc(&p, n * sizeof(T) + ((size_t)2 << 20)) != hipSuccess) return nullptr;
+        (void)hipMemset(static_cast<char*>(p) + n * sizeof(T), 0, (size_t)2 << 20);
         allocs.push_back(p);
         if (host && n) hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice);
         else if (n) hipMemset(p, 0, n * sizeof(T));
@@ -32,7 +35,7 @@ struct Ctx {
     char* scratch(size_t n)
     {
         void* p = nullptr;
-        const size_t pad = (size_t)4 << 20;  // the reference's backward reads past the last tile/bucket
+        const size_t pad = (size_t)16 << 20;  // the reference's backward reads past the last tile/bucket
         if (hipMalloc(&p, n + pad) != hipSuccess) return nullptr;
         hipMemset(p, 0, n + pad);
         allocs.push_back(p);
@@ -60,7 +63,7 @@ int ref_forward(void* vc, int P, int D, int M, int W, int H, const float* means,
     c.opac = c.dev(opac, P); c.scales = c.dev(scales, (size_t)3 * P); c.rots = c.dev(rots, (size_t)4 * P);
     c.view = c.dev(view, 16); c.proj = c.dev(proj, 16); c.campos = c.dev(campos, 3);
     c.bg = c.dev<float>(nullptr, 3);
-    c.out_color = c.dev<float>(nullptr, (size_t)3 * W * H + (size_t)W * 64);
+    c.out_color = c.dev<float>(nullptr, (size_t)3 * W * H);
     c.out_T = c.dev<float>(nullptr, (size_t)W * H);
     c.radii = c.dev<int>(nullptr, P);
     std::function<char*(size_t)> fg = [&](size_t n) { return c.geom = c.scratch(n); };
@@ -111,7 +114,7 @@ int ref_backward(void* vc, const float* dL_dpix, float lambda_erank, float* dL_d
 {
     Ctx& c = *(Ctx*)vc;
     const size_t P = c.P;
-    float* d_pix = c.dev(dL_dpix, (size_t)3 * c.W * c.H + (size_t)c.W * 64);
+    float* d_pix = c.dev(dL_dpix, (size_t)3 * c.W * c.H);  // (exactly the host array: a longer copy reads past the caller's buffer; the slack behind it comes from dev())
     float *g2 = c.dev<float>(nullptr, 3 * P), *gc = c.dev<float>(nullptr, 4 * P), *go = c.dev<float>(nullptr, P), *gcol = c.dev<float>(nullptr, 3 * P);
     float *g3 = c.dev<float>(nullptr, 3 * P), *gcov = c.dev<float>(nullptr, 6 * P), *gdc = c.dev<float>(nullptr, 3 * P);
     float *gsh = c.dev<float>(nullptr, 3 * (size_t)c.M * P + 4), *gs = c.dev<float>(nullptr, 3 * P), *gr = c.dev<float>(nullptr, 4 * P);
