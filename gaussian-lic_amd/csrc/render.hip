@@ -462,19 +462,25 @@ struct BwdLane {
 
 // DST <- shift(SRC) with lane 0 <- INJ.  The DPP's destination is the register that held the injected value, so two steps per trip
 // with the roles of the two register sets swapped need no copies at all.
-#define GS_BW_SHIFT_INJ(DST, DTAG, INJ, ITAG, SRC, STAG)                                                             \
-    do {                                                                                                             \
-        DST.x = shift_old_f(INJ.x, SRC.x); DST.y = shift_old_f(INJ.y, SRC.y);                                        \
-        DTAG = (uint32_t)shift_old_i((int32_t)ITAG, (int32_t)STAG);                                                  \
+// (T, A, tag) <- shift of the current state with lane 0 <- the fetched injection.  Written as asm so that the destination IS the register
+// that held the injection (with the builtin the compiler copied it first); bound_ctrl off: lane 0 has no source lane and keeps the
+// destination's value.  s_nop 1: a DPP source written by the preceding VALU instruction needs two wait states.
+#define GS_BW_SHIFT_INJ(IT, IA, ITAG, ST, SA, STAG)                                                                  \
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                           \
+                 "v_mov_b32_dpp %1, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                       \
+                 "v_mov_b32_dpp %2, %5 wave_shr:1 row_mask:0xf bank_mask:0xf"                                           \
+                 : "+v"(IT), "+v"(IA), "+v"(ITAG) : "v"(ST), "v"(SA), "v"(STAG))
+#define GS_BW_PREFETCH(NT, NA, NTAG)                                                                                 \
+    do { /* every lane reads the same LDS address (a broadcast); the two addresses live in VGPRs and advance by one entry per step */ \
+        const float2 f2_ = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(init) + ainit);            \
+        NT = f2_.x; NA = f2_.y;                                                                                      \
+        NTAG = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(itags) + atag);                      \
+        ainit += 8u; atag += 4u;                                                                                     \
     } while (0)
-#define GS_BW_PREFETCH(NST, NTAG, sl)                                                                                \
-    do { /* every lane reads the same LDS address: a broadcast, no exec-mask juggling */                             \
-        NST = *reinterpret_cast<const v2f*>(&init[sl]);                                                              \
-        NTAG = itags[sl];                                                                                            \
-    } while (0)
-#define GS_BW_BODY(ST, TAG)                                                                                          \
+#define GS_BW_BODY(T_, A_, TAG)                                                                                      \
     do {                                                                                                             \
         const float4 gr = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(grec) + (TAG & 0xffffu));   \
+        __builtin_amdgcn_sched_barrier(0); /* keep the LDS reads at the top of the step: their round trips run under the exponent arithmetic */ \
         const v2f pxy16 = {(float)(TAG & 0xffu), (float)((TAG >> 8) & 0xffu)}; /* v_cvt_f32_ubyte0 / ubyte1: {16 px, py} */ \
         const v2f d = GS_PK_FMA(pxy16, kneg, L.d0); /* exact: d0 - {px, py} */                                       \
         float p2 = __builtin_fmaf(L.hAC.x * d.x, d.x, L.lop); /* the operation sequence of render_fwd */             \
@@ -487,14 +493,14 @@ struct BwdLane {
         const float alpha = hit ? amin : 0.0f;                                                                       \
         const float om = 1.0f - alpha;                                                                               \
         const float rinv = __builtin_amdgcn_rcpf(om);                                                                \
-        const float Ta = ST.x * alpha;                                                                               \
+        const float Ta = T_ * alpha;                                                                                 \
         float cg = L.col_rg.x * gr.x;                                                                                \
         cg = __builtin_fmaf(L.col_rg.y, gr.y, cg);                                                                   \
         cg = __builtin_fmaf(L.colb, gr.z, cg); /* c . dL/dpixel */                                                   \
         acc_rg = GS_PK_FMA(GS_SPLAT(Ta), ((v2f){gr.x, gr.y}), acc_rg); acc_b = __builtin_fmaf(Ta, gr.z, acc_b);      \
-        ST.y = __builtin_fmaf(Ta, cg, ST.y);                                                                         \
-        const float dLda = __builtin_fmaf(rinv, ST.y, ST.x * cg);                                                    \
-        ST.x *= om;                                                                                                  \
+        A_ = __builtin_fmaf(Ta, cg, A_);                                                                             \
+        const float dLda = __builtin_fmaf(rinv, A_, T_ * cg);                                                        \
+        T_ *= om;                                                                                                    \
         const float w = hit ? araw * dLda : 0.0f; /* opacity * G * dL/dalpha = G * dL/dG */                          \
         const v2f wd = GS_SPLAT(w) * d;                                                                              \
         acc_S += wd;                                                                                                 \
@@ -506,8 +512,8 @@ struct BwdLane {
 __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
 {
     __shared__ float4 grec[GS_TILE_PIX];       // dL/dpixel of the tile, by pixel index
-    __shared__ float2 init[GS_TILE_PIX + 1];   // start state {T, A} of the pixels that reach this bucket, in injection order; [256] = the empty entry
-    __shared__ uint32_t itags[GS_TILE_PIX + 1];
+    __shared__ float2 init[GS_TILE_PIX + 64];  // start state {T, A} of the pixels that reach this bucket, in injection order, then 64 empty entries
+    __shared__ uint32_t itags[GS_TILE_PIX + 64];
     const int lane = threadIdx.x;
     const uint32_t bucket = blockIdx.x;
     if (a.status[2] != 0u || bucket >= a.bucket_offsets[a.T - 1]) return;  // capacity overflow in the forward / B was a capacity
@@ -617,7 +623,8 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
             itags[pos[c]] = (rel[c] << 16) | ((pidx >> 4) << 8) | ((pidx & 15u) << 4);
         }
     }
-    if (lane == 0) { init[GS_TILE_PIX] = make_float2(0.f, 0.f); itags[GS_TILE_PIX] = 0u; }
+    init[ninj + (uint32_t)lane] = make_float2(0.f, 0.f);   // what is injected while the last pixels drain (at most 63 steps)
+    itags[ninj + (uint32_t)lane] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -628,27 +635,22 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     asm volatile("" : "+v"(c099), "+v"(c255), "+v"(kneg), "+v"(kcmp));
     v2f acc_S = {0.f, 0.f}, acc_cxy = {0.f, 0.f}, acc_rg = {0.f, 0.f};
     float acc_cw = 0, acc_op = 0, acc_b = 0;
-    v2f st = {0.f, 0.f}, nst;  // {T, A}: the state travelling through the lanes, and the injection fetched one step ahead
-    uint32_t tag = 0, ntag;
-
-    // ---- the pipeline: nsteps steps, two per trip.  Register sets: on entry (st, tag) holds the state and (nst, ntag) the fetched injection;
-    // inside, (st2, tag2) is the state after the first step (in the registers of nst / ntag) and (nst2, ntag2) the second injection (in those
-    // of st / tag).  Past the last pixel the empty entry is injected: the drain needs no code of its own.
-    uint32_t sidx = 0;
-    GS_BW_PREFETCH(nst, ntag, 0);
+    // {T, A, tag}: the state travelling through the lanes (set 1) and the injection fetched one step ahead (set 2); a step shifts set 1
+    // into set 2 (whose lane 0 holds the injection), so the sets swap roles every step: two steps per trip, no register copies.
+    float T1 = 0.f, A1 = 0.f, T2, A2;
+    uint32_t tag1 = 0, tag2;
+    uint32_t sidx = 0, ainit = 0, atag = 0;   // (byte offsets of the next entry; past the last pixel the empty entries follow: the drain needs no code of its own)
+    asm volatile("" : "+v"(ainit), "+v"(atag));
+    GS_BW_PREFETCH(T2, A2, tag2);
     for (;;) {
-        v2f st2, nst2;
-        uint32_t tag2, ntag2;
-        GS_BW_SHIFT_INJ(st2, tag2, nst, ntag, st, tag);
-        ++sidx;
-        GS_BW_PREFETCH(nst2, ntag2, sidx < ninj ? sidx : (uint32_t)GS_TILE_PIX);
-        GS_BW_BODY(st2, tag2);
-        if (sidx >= nsteps) break;
-        GS_BW_SHIFT_INJ(st, tag, nst2, ntag2, st2, tag2);
-        ++sidx;
-        GS_BW_PREFETCH(nst, ntag, sidx < ninj ? sidx : (uint32_t)GS_TILE_PIX);
-        GS_BW_BODY(st, tag);
-        if (sidx >= nsteps) break;
+        GS_BW_SHIFT_INJ(T2, A2, tag2, T1, A1, tag1);   // set 2 = state
+        GS_BW_PREFETCH(T1, A1, tag1);
+        GS_BW_BODY(T2, A2, tag2);
+        if (++sidx >= nsteps) break;
+        GS_BW_SHIFT_INJ(T1, A1, tag1, T2, A2, tag2);   // set 1 = state
+        GS_BW_PREFETCH(T2, A2, tag2);
+        GS_BW_BODY(T1, A1, tag1);
+        if (++sidx >= nsteps) break;
     }
 
     if (valid) {
