@@ -101,14 +101,14 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
     }
     const float LOG2E = 1.4426950408889634f;
     // loop constants in VGPRs (a literal or SGPR operand doubles the issue cost of the instruction that reads it: tools/ubench/issue_rate)
-    float c099 = 0.99f, c255 = 1.0f / 255.0f, c1e4 = 0.0001f;
+    float c099 = 0.99f, c255 = 1.0f / 255.0f, c1e4 = 0.0001f, ninf = -__builtin_inff();
     float lyq[QN];
 #pragma unroll
     for (int q = 0; q < QN; q++) {
         lyq[q] = (float)((lane >> 4) + 4 * (q0 + q));
         asm volatile("" : "+v"(lyq[q]));
     }
-    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(c1e4));
+    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(c1e4), "+v"(ninf));
 
     for (int base = 0; base < n; base += GS_BUCKET) {
         bool alldone = true;
@@ -160,7 +160,10 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
         // one list entry against this lane's four pixels.  STRICT: the reference's arithmetic with its branches.  Default: straight-line
         // code — a pixel the entry does not blend into (finished, power > 0, alpha < 1/255) runs the same instructions with weight 0,
         // which leaves its colour, transmittance and last contributor unchanged bit for bit; only the per-strip skip (wave-uniform) branches
+        uint32_t vcontrib = (uint32_t)base, vone = 1u;
+        asm volatile("" : "+v"(vcontrib), "+v"(vone));
         auto blend_entry = [&](const float4 e0, const float4 e1, const float4 e2, const uint32_t contributor) {
+            vcontrib += vone;  // == contributor, kept in a VGPR (an SGPR operand doubles the issue cost of the select that reads it)
             const uint32_t smask = ((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(e2.y)) >> q0) & ((1u << QN) - 1u);  // this wave's strips
             if (smask == 0u) return;
             const float gdx = e0.x, gdy = e0.y, hA = e0.z, nB = e0.w, hC = e1.x, op = e1.y, colr = e1.z, colg = e1.w, colb = e2.x;
@@ -196,16 +199,16 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
                     if (!(smask & (1u << q))) continue;  // wave-uniform
                     const float dy = gdy - lyq[q];  // one rounding, as d0.y - py in the backward
                     const float p2 = __builtin_fmaf(pB, dy, __builtin_fmaf(hC * dy, dy, pA));  // log2(e) * power + log2(opacity)
-                    const float alpha = fminf(c099, __builtin_amdgcn_exp2f(p2));
+                    const float alpha = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(p2), ninf, c099);  // min(0.99, .) in one instruction, as GS_BW_BODY
                     const float test_T = T[q] * (1.0f - alpha);  // negative (so < 1e-4) once the pixel is done
                     const bool ok = (T[q] > 0.f) & !(p2 > lop) & !(alpha < c255);   // forward.cu:431,437 on a live pixel
                     const bool stop = ok & (test_T < c1e4);                         // done; this entry is NOT applied (forward.cu:438-443)
                     const bool app = ok & !stop;
                     const float w = app ? alpha * T[q] : 0.0f;
                     Cr[q] = __builtin_fmaf(colr, w, Cr[q]); Cg[q] = __builtin_fmaf(colg, w, Cg[q]); Cb[q] = __builtin_fmaf(colb, w, Cb[q]);
-                    const float Tn = app ? test_T : T[q];
-                    T[q] = stop ? -Tn : Tn;
-                    last[q] = app ? contributor : last[q];
+                    const float Tdone = stop ? -T[q] : T[q];
+                    T[q] = app ? test_T : Tdone;
+                    last[q] = app ? vcontrib : last[q];
                 }
             }
         };
@@ -487,7 +490,7 @@ struct BwdLane {
         p2 = __builtin_fmaf(L.hAC.y * d.y, d.y, p2);                                                                 \
         p2 = __builtin_fmaf(L.nB * d.x, d.y, p2); /* = log2(e) * power + log2(opacity) */                            \
         const float araw = __builtin_amdgcn_exp2f(p2); /* opacity * G */                                             \
-        const float amin = fminf(c099, araw);                                                                        \
+        const float amin = __builtin_amdgcn_fmed3f(araw, ninf, c099); /* min(0.99, .) without the canonicalising v_max fminf costs */ \
         /* lane < n_contrib - bucket start (backward.cu:538), power <= 0, alpha >= 1/255 (:543-546) */               \
         const bool hit = (kcmp < TAG) & !(p2 > L.lop) & !(amin < c255);                                              \
         const float alpha = hit ? amin : 0.0f;                                                                       \
@@ -629,10 +632,10 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     __builtin_amdgcn_wave_barrier();
 
     // loop constants in VGPRs: a literal or SGPR operand doubles the issue cost of the instruction that reads it
-    float c099 = 0.99f, c255 = 1.0f / 255.0f;
+    float c099 = 0.99f, c255 = 1.0f / 255.0f, ninf = -__builtin_inff();
     v2f kneg = {-0.0625f, -1.0f};
     uint32_t kcmp = ((uint32_t)lane << 16) | 0xffffu;
-    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(kneg), "+v"(kcmp));
+    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(ninf), "+v"(kneg), "+v"(kcmp));
     v2f acc_S = {0.f, 0.f}, acc_cxy = {0.f, 0.f}, acc_rg = {0.f, 0.f};
     float acc_cw = 0, acc_op = 0, acc_b = 0;
     // {T, A, tag}: the state travelling through the lanes (set 1) and the injection fetched one step ahead (set 2); a step shifts set 1
