@@ -482,7 +482,7 @@ struct BwdLane {
     } while (0)
 #define GS_BW_BODY(T_, A_, TAG)                                                                                      \
     do {                                                                                                             \
-        const float4 gr = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(grec) + (TAG & 0xffffu));   \
+        const float4 gr = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(grec) + (TAG & kmask));     \
         __builtin_amdgcn_sched_barrier(0); /* keep the LDS reads at the top of the step: their round trips run under the exponent arithmetic */ \
         const v2f pxy16 = {(float)(TAG & 0xffu), (float)((TAG >> 8) & 0xffu)}; /* v_cvt_f32_ubyte0 / ubyte1: {16 px, py} */ \
         const v2f d = GS_PK_FMA(pxy16, kneg, L.d0); /* exact: d0 - {px, py} */                                       \
@@ -490,10 +490,10 @@ struct BwdLane {
         p2 = __builtin_fmaf(L.hAC.y * d.y, d.y, p2);                                                                 \
         p2 = __builtin_fmaf(L.nB * d.x, d.y, p2); /* = log2(e) * power + log2(opacity) */                            \
         const float araw = __builtin_amdgcn_exp2f(p2); /* opacity * G */                                             \
-        const float amin = __builtin_amdgcn_fmed3f(araw, ninf, c099); /* min(0.99, .) without the canonicalising v_max fminf costs */ \
-        /* lane < n_contrib - bucket start (backward.cu:538), power <= 0, alpha >= 1/255 (:543-546) */               \
-        const bool hit = (kcmp < TAG) & !(p2 > L.lop) & !(amin < c255);                                              \
-        const float alpha = hit ? amin : 0.0f;                                                                       \
+        /* lane < n_contrib - bucket start (backward.cu:538), power <= 0, alpha >= 1/255 (:543-546; min(0.99, a) < 1/255 iff a < 1/255) */ \
+        const bool hit = (kcmp < TAG) & !(p2 > L.lop) & !(araw < c255);                                              \
+        const float ah = hit ? araw : 0.0f; /* one select masks both alpha and the gradient weight */                \
+        const float alpha = __builtin_amdgcn_fmed3f(ah, ninf, c099); /* min(0.99, .) without the canonicalising v_max fminf costs */ \
         const float om = 1.0f - alpha;                                                                               \
         const float rinv = __builtin_amdgcn_rcpf(om);                                                                \
         const float Ta = T_ * alpha;                                                                                 \
@@ -504,7 +504,7 @@ struct BwdLane {
         A_ = __builtin_fmaf(Ta, cg, A_);                                                                             \
         const float dLda = __builtin_fmaf(rinv, A_, T_ * cg);                                                        \
         T_ *= om;                                                                                                    \
-        const float w = hit ? araw * dLda : 0.0f; /* opacity * G * dL/dalpha = G * dL/dG */                          \
+        const float w = ah * dLda; /* opacity * G * dL/dalpha = G * dL/dG (dLda is finite: alpha <= 0.99) */         \
         const v2f wd = GS_SPLAT(w) * d;                                                                              \
         acc_S += wd;                                                                                                 \
         acc_cxy = GS_PK_FMA(GS_SPLAT(wd.x), d, acc_cxy); /* -0.5 applied at the end */                               \
@@ -634,8 +634,8 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     // loop constants in VGPRs: a literal or SGPR operand doubles the issue cost of the instruction that reads it
     float c099 = 0.99f, c255 = 1.0f / 255.0f, ninf = -__builtin_inff();
     v2f kneg = {-0.0625f, -1.0f};
-    uint32_t kcmp = ((uint32_t)lane << 16) | 0xffffu;
-    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(ninf), "+v"(kneg), "+v"(kcmp));
+    uint32_t kcmp = ((uint32_t)lane << 16) | 0xffffu, kmask = 0xffffu;
+    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(ninf), "+v"(kneg), "+v"(kcmp), "+v"(kmask));
     v2f acc_S = {0.f, 0.f}, acc_cxy = {0.f, 0.f}, acc_rg = {0.f, 0.f};
     float acc_cw = 0, acc_op = 0, acc_b = 0;
     // {T, A, tag}: the state travelling through the lanes (set 1) and the injection fetched one step ahead (set 2); a step shifts set 1
@@ -686,7 +686,8 @@ int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s)
         GS_LAUNCH(K_RENDER_BWD, render_bwd_strict_kernel, dim3(a.B), dim3(64), 0, s, a);
         return GSLIC_OK;
     }
-    GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel, dim3(a.B), dim3(64), 0, s, a);
+    static const int lds_pad = [] { const char* e = getenv("GSLIC_BWD_LDS_PAD"); return e ? atoi(e) : 0; }();  // occupancy experiments only
+    GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel, dim3(a.B), dim3(64), (size_t)lds_pad, s, a);
     return GSLIC_OK;
 }
 
