@@ -215,7 +215,7 @@ def main():
             torch.distributed.all_reduce(odt, op=torch.distributed.ReduceOp.MAX)
         return float(odt.item())
 
-    other, graphed_res, growth = None, None, None
+    other, graphed_res, growth, cpp_host = None, None, None, None
     n_extra = min(args.steps, 200)
     if args.mode == "train" and not args.no_extras and not args.graph:
         host["mode"] = "dropin" if args.host == "fused" else "fused"
@@ -232,6 +232,7 @@ def main():
                            "host_round_trips_per_step": 0, "steps_repeated_for_capacity": repeated, "capacity_R": gs.bufs.cap_R, "capacity_B": gs.bufs.cap_B}
             del gs
         if world == 1 and not trainer._dist_on() and args.host == "fused":
+            cpp_host = cpp_fused_host(args, model, cam, gt, n_extra)
             torch.cuda.empty_cache()
             growth = growth_schedule(args, dev)
 
@@ -340,6 +341,7 @@ def main():
         "cpu_baseline": cpu,
         "other_host_path": other,
         "graphed": graphed_res,
+        "cpp_fused_host": cpp_host,
         "growth_schedule": growth,
         "extend": None if args.mode != "slam" else {"calls": slam["calls"], "inserted": slam["inserted"], "final_gaussians": model.P,
                                                     "ms_per_call": round(slam["ms"] / max(slam["calls"], 1), 3)},
@@ -348,6 +350,37 @@ def main():
     print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def cpp_fused_host(args, model, cam, gt, n):
+    """The fused step driven from C++ (gaussian-lic_amd/shim/include/gslic_fused.h, program fused_check): the current map, camera and
+    target are handed over as files, the program runs n timed steps in its own process on the same GPU and reports its own clock."""
+    import shutil
+    import subprocess
+    import tempfile
+    import numpy as np
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gaussian-lic_amd", "fused_check")
+    if not os.path.exists(exe):
+        return None
+    d = tempfile.mkdtemp(prefix="gslic_cpp_host_")
+    try:
+        w = lambda name, t: np.ascontiguousarray(t, np.float32).tofile(os.path.join(d, name + ".f32"))
+        for name, t in (("xyz", model.xyz), ("scaling", model.scaling), ("rotation", model.rotation), ("opacity", model.opacity),
+                        ("dc", model.features_dc), ("rest", model.features_rest)):
+            w(name, t.detach().cpu().numpy())
+        w("view", cam.world_view_transform); w("proj", cam.full_proj_transform); w("campos", cam.camera_center)
+        w("gt", gt.cpu().numpy())
+        w("scalars", np.array([cam.tanfovx, cam.tanfovy, cam.limx_neg, cam.limx_pos, cam.limy_neg, cam.limy_pos], np.float32))
+        r = subprocess.run([exe, d, str(model.P), str(args.width), str(args.height), "3", "1", str(n), str(args.lr_scale)], capture_output=True,
+                           text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("views_per_s")]
+        if r.returncode != 0 or not line:
+            return {"error": (r.stdout[-300:] + r.stderr[-300:]).strip()}
+        tok = line[0].split()
+        return {"host": "C++ (LibTorch tensors + C-ABI, no autograd graph)", "value": round(float(tok[1]), 3), "unit": "views/s",
+                "ms_per_step": round(float(tok[3]), 3), "steps": n}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def growth_schedule(args, dev):

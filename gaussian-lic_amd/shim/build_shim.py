@@ -77,8 +77,38 @@ def _build_check(CHECK, first_includes, force):
     return CHECK
 
 
+CHECK_FUSED = os.path.join(PKG, "fused_check")
+
+
+def build_fused_check(force=False):
+    """fused_check: the fused training step from C++ (shim/include/gslic_fused.h + fused_check.cpp) — LibTorch and libgslic_hip.so only,
+    no reference source, so it builds anywhere this repository does."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension
+    src = os.path.join(HERE, "fused_check.cpp")
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "include", "gslic_fused.h")),
+                 os.path.getmtime(os.path.join(PKG, "..", "include", "gslic_hip.h")), os.path.getmtime(os.path.join(PKG, "libgslic_hip.so")))
+    if not force and os.path.exists(CHECK_FUSED) and os.path.getmtime(CHECK_FUSED) > newest:
+        return CHECK_FUSED
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ["g++", "-O1", "-std=c++17", "-w", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    for inc in cpp_extension.include_paths():
+        cmd += ["-isystem", inc]
+    cmd += ["-isystem", sysconfig.get_paths()["include"], "-I", os.path.join(HERE, "include"), src, "-o", CHECK_FUSED, "-L", PKG, "-lgslic_hip",
+            "-Wl,-rpath,$ORIGIN", "-L", tlib, "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", f"-Wl,-rpath,{tlib}",
+            "-Wl,--no-as-needed", "-ltorch_hip", "-Wl,--as-needed",
+            "-L", os.path.join(sysconfig.get_config_var("LIBDIR") or "/usr/lib"), f"-lpython{sysconfig.get_python_version()}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout[-3000:] + r.stderr[-6000:])
+        raise RuntimeError("fused_check build failed")
+    return CHECK_FUSED
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
     print(build_dropin_check(force="--force" in sys.argv))
     print(build_dropin_check(force="--force" in sys.argv, groups=True))
     print(build_dropin_check(force="--force" in sys.argv, groups="dist"))
+    print(build_fused_check(force="--force" in sys.argv))

@@ -1,0 +1,150 @@
+// gslic_fused.h — the fused training step for the reference's C++ host (header-only: LibTorch + include/gslic_hip.h).
+//
+// What optimize()'s loop body does per view (src/gaussian.cpp:674-716) —
+//     render() -> l1_loss + fused_ssim -> loss.backward() -> set_visibility_and_N() -> SparseGaussianAdam::step()
+// — as four C-ABI calls with no autograd graph, no LibTorch elementwise launch and no gradient tensor:
+//     gslic_rasterize_forward (raw_params = 1: sigmoid / exp / normalize of gaussian.cpp:147-175 inside the kernels)
+//     gslic_l1_ssim_loss_forward / _backward (loss_utils.h:30-33,130-193; the loss of gaussian.cpp:685-691)
+//     gslic_rasterize_backward_adam (backward + the masked Adam of optim_utils.h:102-137 in the per-Gaussian kernel)
+// The arithmetic equals the operator path's up to fp32 rounding (tests/test_fused_gpu.py); the C++ and the Python host
+// (gaussian-lic_amd/trainer.py:training_step_fused) issue the same calls, so their parameters agree bit for bit
+// (tests/test_shim_gpu.py::test_fused_cpp_host).  Single GPU: with N > 1 the gradients must exist for the exchange (gslic_dist.h).
+//
+//   gslic::FusedStep fs({xyz_, features_dc_, features_rest_, opacity_, scaling_, rotation_},
+//                       {1.6e-4f, 2.5e-3f, 2.5e-3f / 20, 5e-2f, 5e-3f, 1e-3f}, sh_degree_);
+//   for (view : keyframes) { auto terms = fs.step(cam, gt_image); }        // terms = device [mean |img - gt|, mean ssim]
+//   float loss = fs.loss_value(terms);                                     // only when the host wants the number (one sync)
+#pragma once
+#include <torch/torch.h>
+
+#include <array>
+#include <vector>
+
+#include "../../../include/gslic_hip.h"
+
+namespace gslic {
+
+// the fields of Camera that reach the rasterizer (src/camera.h:38-110, renderer.cpp:28-50)
+struct FusedCamera {
+    int image_width = 0, image_height = 0;
+    float tanfovx = 0, tanfovy = 0, limx_neg = 0, limx_pos = 0, limy_neg = 0, limy_pos = 0;
+    torch::Tensor world_view_transform, full_proj_transform, camera_center;  // device fp32 [4,4] (stored transposed, camera.h:86,109), [4,4], [3]
+};
+
+class FusedStep {
+public:
+    // params: the six raw leaf tensors in the group order of trainingSetup (gaussian.cpp:399-418); updated IN PLACE.
+    FusedStep(std::array<torch::Tensor, 6> params, std::array<float, 6> lrs, int sh_degree, float lambda_dssim = 0.2f,
+              float lambda_erank = 0.0f, float b1 = 0.9f, float b2 = 0.999f, float eps = 1e-15f)
+        : prm_(std::move(params)), lrs_(lrs), deg_(sh_degree), lambda_dssim_(lambda_dssim), lambda_erank_(lambda_erank), b1_(b1), b2_(b2), eps_(eps)
+    {
+        for (int i = 0; i < 6; i++) {
+            TORCH_CHECK(prm_[i].is_cuda() && prm_[i].scalar_type() == torch::kFloat32 && prm_[i].is_contiguous(),
+                        "FusedStep: parameter group ", i, " must be a contiguous fp32 device tensor (it is updated in place)");
+            m_[i] = torch::zeros_like(prm_[i].detach());   // SparseGaussianAdam creates its state as zeros on the first step (optim_utils.h:116-123)
+            v_[i] = torch::zeros_like(prm_[i].detach());
+        }
+        auto bytes = torch::TensorOptions().dtype(torch::kByte).device(prm_[0].device());
+        for (auto& s : scratch_) s = torch::empty({0}, bytes);
+        bg_ = torch::zeros({3}, prm_[0].options().requires_grad(false));
+    }
+
+    // continue from a SparseGaussianAdam (exp_avg / exp_avg_sq of group i), e.g. when switching an existing map over
+    void adopt_state(int group, torch::Tensor exp_avg, torch::Tensor exp_avg_sq)
+    {
+        TORCH_CHECK(exp_avg.sizes() == prm_[group].sizes() && exp_avg_sq.sizes() == prm_[group].sizes() && exp_avg.is_contiguous() &&
+                    exp_avg_sq.is_contiguous(), "FusedStep::adopt_state: shape / layout mismatch");
+        m_[group] = std::move(exp_avg);
+        v_[group] = std::move(exp_avg_sq);
+    }
+    // after densificationPostfix (gaussian.cpp:444-487) replaced the tensors: new parameters, moments extended with zeros by the host
+    void rebind(std::array<torch::Tensor, 6> params, std::array<torch::Tensor, 6> exp_avg, std::array<torch::Tensor, 6> exp_avg_sq)
+    {
+        prm_ = std::move(params); m_ = std::move(exp_avg); v_ = std::move(exp_avg_sq);
+    }
+    void set_lr(int group, float lr) { lrs_[group] = lr; }
+
+    // One optimisation step on one view.  Returns the device tensor [mean |image - gt|, mean ssim]; nothing synchronises.
+    torch::Tensor step(const FusedCamera& cam, const torch::Tensor& gt_image)
+    {
+        torch::NoGradGuard ng;
+        const int64_t P = prm_[0].size(0);
+        const int W = cam.image_width, H = cam.image_height;
+        TORCH_CHECK(gt_image.is_contiguous() && gt_image.dim() == 3 && gt_image.size(1) == H && gt_image.size(2) == W, "gt_image must be contiguous [3,H,W]");
+        gslic_raster_params rp{};
+        rp.P = (int32_t)P; rp.D = deg_; rp.M = prm_[2].numel() ? (int32_t)prm_[2].size(1) : 0; rp.width = W; rp.height = H;
+        rp.tan_fovx = cam.tanfovx; rp.tan_fovy = cam.tanfovy;
+        rp.limx_neg = cam.limx_neg; rp.limx_pos = cam.limx_pos; rp.limy_neg = cam.limy_neg; rp.limy_pos = cam.limy_pos;
+        rp.scale_modifier = 1.0f; rp.raw_params = 1;
+        auto fo = prm_[0].options().requires_grad(false);
+        if (!image_.defined() || image_.size(1) != H || image_.size(2) != W) {
+            image_ = torch::empty({3, H, W}, fo);
+            final_T_ = torch::empty({H, W}, fo);
+            for (auto& d : dm_) d = torch::empty({3, H, W}, fo);
+            dL_dimage_ = torch::empty({3, H, W}, fo);
+            partials_ = torch::empty({gslic_loss_partials_count(1, 3, H, W)}, fo);
+        }
+        if (!radii_.defined() || radii_.size(0) != P) radii_ = torch::empty({P}, fo.dtype(torch::kInt32));
+        torch::Tensor terms = torch::empty({2}, fo);
+        const float *xyz = f(prm_[0]), *dc = f(prm_[1]), *rest = f(prm_[2]), *op = f(prm_[3]), *sc = f(prm_[4]), *rot = f(prm_[5]);
+        const float *view = f(cam.world_view_transform), *proj = f(cam.full_proj_transform), *cpos = f(cam.camera_center);
+        int32_t R = 0, B = 0;
+        check(gslic_rasterize_forward(&rp, grow_cb, &scratch_[0], grow_cb, &scratch_[1], grow_cb, &scratch_[2], grow_cb, &scratch_[3], f(bg_), xyz, dc,
+                                      rest, nullptr, op, sc, rot, nullptr, view, proj, cpos, image_.data_ptr<float>(), final_T_.data_ptr<float>(),
+                                      radii_.data_ptr<int32_t>(), &R, &B, nullptr),
+              "gslic_rasterize_forward");
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;   // loss_utils.h:187-188
+        check(gslic_l1_ssim_loss_forward(1, 3, H, W, C1, C2, f(image_), f(gt_image), dm_[0].data_ptr<float>(), dm_[1].data_ptr<float>(),
+                                         dm_[2].data_ptr<float>(), partials_.data_ptr<float>(), terms.data_ptr<float>(), nullptr),
+              "gslic_l1_ssim_loss_forward");
+        check(gslic_l1_ssim_loss_backward(1, 3, H, W, lambda_dssim_, f(image_), f(gt_image), f(dm_[0]), f(dm_[1]), f(dm_[2]),
+                                          dL_dimage_.data_ptr<float>(), nullptr),
+              "gslic_l1_ssim_loss_backward");
+        gslic_adam_fused ad{};
+        for (int i = 0; i < 6; i++) {
+            const bool on = prm_[i].numel() != 0;   // features_rest is [P,0,3] at SH degree 0: an empty group is a no-op, as in the reference
+            ad.param[i] = on ? prm_[i].data_ptr<float>() : nullptr;
+            ad.exp_avg[i] = on ? m_[i].data_ptr<float>() : nullptr;
+            ad.exp_avg_sq[i] = on ? v_[i].data_ptr<float>() : nullptr;
+            ad.lr[i] = lrs_[i];
+        }
+        ad.b1 = b1_; ad.b2 = b2_; ad.eps = eps_;
+        check(gslic_rasterize_backward_adam(&rp, R, B, f(bg_), xyz, dc, rest, nullptr, sc, rot, nullptr, view, proj, cpos, radii_.data_ptr<int32_t>(),
+                                            cptr(scratch_[0]), cptr(scratch_[1]), cptr(scratch_[2]), cptr(scratch_[3]), f(dL_dimage_), nullptr, nullptr,
+                                            nullptr, nullptr, nullptr, nullptr, lambda_erank_, &ad, nullptr),
+              "gslic_rasterize_backward_adam");
+        return terms;
+    }
+
+    float loss_value(const torch::Tensor& terms) const   // (1 - lambda) L1 + lambda (1 - SSIM), gaussian.cpp:685-691; synchronises
+    {
+        torch::Tensor t = terms.to(torch::kCPU);
+        return (1.0f - lambda_dssim_) * t[0].item<float>() + lambda_dssim_ * (1.0f - t[1].item<float>());
+    }
+    const torch::Tensor& image() const { return image_; }                 // last render [3,H,W]
+    torch::Tensor visible() const { return radii_ > 0; }                  // render_pkg's visibility filter (renderer.cpp:86)
+    const torch::Tensor& exp_avg(int group) const { return m_[group]; }
+    const torch::Tensor& exp_avg_sq(int group) const { return v_[group]; }
+
+private:
+    static const float* f(const torch::Tensor& t) { return t.numel() ? t.data_ptr<float>() : nullptr; }
+    static char* cptr(torch::Tensor& t) { return t.numel() ? reinterpret_cast<char*>(t.data_ptr()) : nullptr; }
+    static void check(int rc, const char* what) { TORCH_CHECK(rc == GSLIC_OK, what, " failed (", rc, "): ", gslic_last_error()); }
+    // the role of resizeFunctional (rasterize_points.cu:40-48) for buffers that persist across steps: grow only, with headroom, so a
+    // steady-state step allocates nothing
+    static char* grow_cb(void* ctx, size_t n)
+    {
+        torch::Tensor& t = *static_cast<torch::Tensor*>(ctx);
+        if ((size_t)t.numel() < n) t = torch::empty({(int64_t)(n + n / 8 + 256)}, t.options());
+        return reinterpret_cast<char*>(t.data_ptr());
+    }
+
+    std::array<torch::Tensor, 6> prm_, m_, v_;
+    std::array<float, 6> lrs_;
+    int deg_;
+    float lambda_dssim_, lambda_erank_, b1_, b2_, eps_;
+    torch::Tensor scratch_[4];   // geom, binning, img, sample — order of the C-ABI's allocator arguments
+    torch::Tensor bg_, image_, final_T_, radii_, dm_[3], dL_dimage_, partials_;
+};
+
+}  // namespace gslic

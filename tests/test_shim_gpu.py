@@ -14,6 +14,7 @@ SHIM = os.path.join(ROOT, "gaussian-lic_amd", "libgslic_torch_shim.so")
 CHECK = os.path.join(ROOT, "gaussian-lic_amd", "dropin_check")
 CHECK_GROUPS = os.path.join(ROOT, "gaussian-lic_amd", "dropin_check_groups")
 CHECK_DIST = os.path.join(ROOT, "gaussian-lic_amd", "dropin_check_dist")
+CHECK_FUSED = os.path.join(ROOT, "gaussian-lic_amd", "fused_check")
 
 
 def _load_shim():
@@ -111,6 +112,52 @@ def test_reference_host_code_drives_the_hip_kernels(tmp_path):
                 assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
                 for n, a in first.items():
                     np.testing.assert_array_equal(rd(n, (-1,)), a, err_msg=f"{n} (dist, sparse={sparse})")
+
+
+def _write_case(d, raw, cam, gt):
+    w = lambda name, t: np.ascontiguousarray(t, np.float32).tofile(os.path.join(d, name + ".f32"))
+    for k, n in (("xyz", "xyz"), ("scaling", "scaling"), ("rotation", "rotation"), ("opacity", "opacity"), ("features_dc", "dc"),
+                 ("features_rest", "rest")):
+        w(n, raw[k].numpy())
+    w("view", cam.world_view_transform); w("proj", cam.full_proj_transform); w("campos", cam.camera_center)
+    w("gt", gt.numpy())
+    w("scalars", np.array([cam.tanfovx, cam.tanfovy, cam.limx_neg, cam.limx_pos, cam.limy_neg, cam.limy_pos], np.float32))
+
+
+@pytest.mark.parametrize("deg", [3, 0])
+def test_fused_cpp_host(tmp_path, deg):
+    """fused_check = the fused training step written in C++ against the C-ABI (shim/include/gslic_fused.h: raw-parameter forward, loss
+    kernels, backward with the Adam update inside; no autograd graph).  It issues the same C-ABI calls as trainer.training_step_fused,
+    so image and parameters after four steps are bit-identical to the Python host's; SH degree 0 exercises the empty features_rest group."""
+    if not os.path.exists(CHECK_FUSED):
+        pytest.skip("fused_check not built")
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import trainer
+    from gaussian_lic_amd.synthetic import gt_image
+    P, W, H, iters = 30000, 320, 240, 4
+    raw, sc, camd, cam = make_scene("random", P, W, H, deg, 43)
+    d = str(tmp_path)
+    gt = gt_image(H, W)
+    _write_case(d, raw, cam, gt)
+    r = subprocess.run([CHECK_FUSED, d, str(P), str(W), str(H), str(deg), str(iters)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    dev = torch.device("cuda:0")
+    model = trainer.GaussianModel(raw, dev)
+    model.training_setup()
+    cam.to_device(dev)
+    bg = torch.zeros(3, device=dev)
+    losses = []
+    for _ in range(iters):
+        terms, _vis = trainer.training_step_fused(model, cam, gt.to(dev), bg)
+        losses.append(float(0.8 * terms[0] + 0.2 * (1.0 - terms[1])))
+    rd = lambda name, shape: np.fromfile(os.path.join(d, f"out_{name}.f32"), np.float32).reshape(shape)
+    names = [("xyz", model.xyz), ("scaling", model.scaling), ("rotation", model.rotation), ("opacity", model.opacity), ("dc", model.features_dc)]
+    if deg > 0:
+        names.append(("rest", model.features_rest))
+    for name, t in names:
+        np.testing.assert_array_equal(rd(name, tuple(t.shape)), t.detach().cpu().numpy(), err_msg=name)
+    printed = [float(l.split()[3]) for l in r.stdout.splitlines() if l.startswith("iter ")]
+    assert len(printed) == iters and np.allclose(printed, losses, rtol=1e-5)
 
 
 def test_shim_adam_rejects_noncontiguous_state():
