@@ -346,6 +346,7 @@ def main():
         "extend": None if args.mode != "slam" else {"calls": slam["calls"], "inserted": slam["inserted"], "final_gaussians": model.P,
                                                     "ms_per_call": round(slam["ms"] / max(slam["calls"], 1), 3)},
         "kernel_ms_per_step": {k: round(v[0] / max(nprof, 1), 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
+        "kernel_ms_per_launch_timed": None if not args.profile_all else {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(timed.items(), key=lambda kv: -kv[1][0])},
     }
     print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():

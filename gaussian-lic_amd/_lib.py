@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgslic_hip.so")
+LIB_PATH = os.environ.get("GSLIC_HIP_LIB") or os.path.join(_HERE, "libgslic_hip.so")   # (override: A/B kernel experiments, tools/ab/)
 
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
 

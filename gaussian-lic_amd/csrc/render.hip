@@ -441,9 +441,12 @@ __global__ __launch_bounds__(64) void render_bwd_strict_kernel(RenderBwdArgs a)
 // =========================================================================================================
 // Backward, default (fast) variant: ONE WAVE PER BUCKET, lane = Gaussian, the tile's pixels stream through the lanes.
 //
-// What travels lane -> lane+1 is {T, A, tag}: A = sum_ch ar[ch] * dL/dpixel[ch] replaces the colour vector ar[3] of the reference's
-// formulation (dL/dalpha only ever needs that dot product: dL/dalpha = A' / (1 - alpha) + T (c . g), A' = A + T alpha (c . g)): three
-// DPP moves per step instead of five.  alpha = min(0.99, exp2(p2 + log2 opacity)) with the SAME operation sequence as render_fwd
+// What travels lane -> lane+1 is {T, A}: A = sum_ch ar[ch] * dL/dpixel[ch] replaces the colour vector ar[3] of the reference's
+// formulation (dL/dalpha only ever needs that dot product: dL/dalpha = A' / (1 - alpha) + T (c . g), A' = A + T alpha (c . g)): two
+// DPP moves per step instead of five.  Which pixel a lane works on does not travel at all: the schedule is static — lane L at step s
+// holds the pixel injected at step s - L — so the pixel's record {dL/dpixel, tag} is stored in LDS in INJECTION order and every lane
+// fetches record s - L with one ds_read_b128 at a per-lane address that advances by 16 bytes per step, one step ahead of its use
+// (64 consecutive records per read: no bank conflicts, no dependence on anything computed in the step).  alpha = min(0.99, exp2(p2 + log2 opacity)) with the SAME operation sequence as render_fwd
 // (identical bits on both sides, so both take the same alpha < 1/255 decisions); the products with G = exp(power) that the reference
 // forms are written on a = opacity * G, dL/dopacity is divided by the opacity once per instance, and the conic factors of dL/dmean2D
 // (per-Gaussian constants) are applied once to sum w d instead of in every step.
@@ -456,8 +459,11 @@ __global__ __launch_bounds__(64) void render_bwd_strict_kernel(RenderBwdArgs a)
 // branches, LDS round trips) as much as by the VALU count: branch-free, the pixel's constants are fetched from LDS at the top of the
 // step, the next injection is fetched one step ahead and enters through the DPP's `old` operand, and the loop constants live in VGPRs.
 //
-// tag = rel << 16 | py << 8 | 16 px (rel = min(n_contrib - bucket start, 64) >= 1 for an injected pixel: the low half is the byte offset
-// of the pixel's float4 in grec[] and two bytes v_cvt_f32_ubyte0/1 turn into coordinates), 0 for an empty slot; kcmp < tag <=> lane < rel.
+// tag = rel << 16 | py << 8 | 16 px (rel = min(n_contrib - bucket start, 64) >= 1 for an injected pixel; the two low bytes are what
+// v_cvt_f32_ubyte0/1 turn into coordinates), 0 for an empty slot; kcmp < tag <=> lane < rel.
+// Before the first pixel reaches lane L (s < L) the lane reads whatever lies s - L records before the array — the start states, placed
+// there on purpose: finite numbers — while its travelling state is still T = A = 0, which makes every product of the step an exact zero
+// whatever the record says; behind the last pixel come 64 zero records.
 struct BwdLane {
     v2f d0, hAC, col_rg;          // centre relative to the tile origin; log2(e)-scaled conic diagonal {-1/2 A, -1/2 C}; colour r, g
     float nB, lop, colb;          // log2(e)-scaled -B; log2(opacity); colour b
@@ -468,22 +474,22 @@ struct BwdLane {
 // (T, A, tag) <- shift of the current state with lane 0 <- the fetched injection.  Written as asm so that the destination IS the register
 // that held the injection (with the builtin the compiler copied it first); bound_ctrl off: lane 0 has no source lane and keeps the
 // destination's value.  s_nop 1: a DPP source written by the preceding VALU instruction needs two wait states.
-#define GS_BW_SHIFT_INJ(IT, IA, ITAG, ST, SA, STAG)                                                                  \
-    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                           \
-                 "v_mov_b32_dpp %1, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                       \
-                 "v_mov_b32_dpp %2, %5 wave_shr:1 row_mask:0xf bank_mask:0xf"                                           \
-                 : "+v"(IT), "+v"(IA), "+v"(ITAG) : "v"(ST), "v"(SA), "v"(STAG))
-#define GS_BW_PREFETCH(NT, NA, NTAG)                                                                                 \
-    do { /* every lane reads the same LDS address (a broadcast); the two addresses live in VGPRs and advance by one entry per step */ \
-        const float2 f2_ = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(init) + ainit);            \
+#define GS_BW_SHIFT_INJ(IT, IA, ST, SA)                                                                              \
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                           \
+                 "v_mov_b32_dpp %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf"                                           \
+                 : "+v"(IT), "+v"(IA) : "v"(ST), "v"(SA))
+#define GS_BW_PREFETCH(NT, NA, NR)                                                                                   \
+    do { /* next injection: every lane reads the same address (a broadcast); next record: lane L reads record (step + 1) - L */ \
+        const float2 f2_ = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(smem) + ainit);            \
+        NR = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(smem) + arec);                           \
         NT = f2_.x; NA = f2_.y;                                                                                      \
-        NTAG = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(itags) + atag);                      \
-        ainit += 8u; atag += 4u;                                                                                     \
+        ainit += 8u; arec += 16u;                                                                                    \
+        __builtin_amdgcn_sched_barrier(0); /* keep the LDS reads at the top of the step: a whole step passes before they are used */ \
     } while (0)
-#define GS_BW_BODY(T_, A_, TAG)                                                                                      \
+#define GS_BW_BODY(T_, A_, GR)                                                                                       \
     do {                                                                                                             \
-        const float4 gr = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(grec) + (TAG & kmask));     \
-        __builtin_amdgcn_sched_barrier(0); /* keep the LDS reads at the top of the step: their round trips run under the exponent arithmetic */ \
+        const float4 gr = GR;                                                                                        \
+        const uint32_t TAG = __float_as_uint(gr.w);                                                                  \
         const v2f pxy16 = {(float)(TAG & 0xffu), (float)((TAG >> 8) & 0xffu)}; /* v_cvt_f32_ubyte0 / ubyte1: {16 px, py} */ \
         const v2f d = GS_PK_FMA(pxy16, kneg, L.d0); /* exact: d0 - {px, py} */                                       \
         float p2 = __builtin_fmaf(L.hAC.x * d.x, d.x, L.lop); /* the operation sequence of render_fwd */             \
@@ -514,9 +520,12 @@ struct BwdLane {
 
 __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
 {
-    __shared__ float4 grec[GS_TILE_PIX];       // dL/dpixel of the tile, by pixel index
-    __shared__ float2 init[GS_TILE_PIX + 64];  // start state {T, A} of the pixels that reach this bucket, in injection order, then 64 empty entries
-    __shared__ uint32_t itags[GS_TILE_PIX + 64];
+    // [start states {T, A} of the pixels that reach this bucket, in injection order, + 64 empty entries][their records {dL/dpixel, tag}, same
+    // order, + 64 empty records]; the states come FIRST: they are what a lane reads as "records" before its first pixel arrives (see above)
+    constexpr int NENT = GS_TILE_PIX + 64;
+    __shared__ float4 smem[NENT / 2 + NENT];
+    float2* const init = reinterpret_cast<float2*>(smem);
+    float4* const grec = smem + NENT / 2;
     const int lane = threadIdx.x;
     const uint32_t bucket = blockIdx.x;
     if (a.status[2] != 0u || bucket >= a.bucket_offsets[a.T - 1]) return;  // capacity overflow in the forward / B was a capacity
@@ -614,45 +623,49 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
         last = o > last ? o : last;
     }
     const uint32_t nsteps = readlane_u(last, 0);
+    // the 63 record-sized slots in front of the records (the tail of the start states: what lane L reads until its first pixel arrives)
+    // must hold finite numbers: zero them first — LDS operations of one wave complete in order, so real start states written below win
+    if (lane < 63) smem[NENT / 2 - 63 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const uint32_t pidx = (uint32_t)(c * 64 + lane);
-        grec[pidx] = make_float4(fg[c][0], fg[c][1], fg[c][2], 0.f);
         if (rel[c]) {
             float A0 = (ck[c].y - pf[c].x) * fg[c][0];  // ar = checkpoint colour - final colour (backward.cu:522-523), dotted with dL/dpixel
             A0 = __builtin_fmaf(ck[c].z - pf[c].y, fg[c][1], A0);
             A0 = __builtin_fmaf(ck[c].w - pf[c].z, fg[c][2], A0);
             init[pos[c]] = make_float2(ck[c].x, A0);
-            itags[pos[c]] = (rel[c] << 16) | ((pidx >> 4) << 8) | ((pidx & 15u) << 4);
+            grec[pos[c]] = make_float4(fg[c][0], fg[c][1], fg[c][2], __uint_as_float((rel[c] << 16) | ((pidx >> 4) << 8) | ((pidx & 15u) << 4)));
         }
     }
     init[ninj + (uint32_t)lane] = make_float2(0.f, 0.f);   // what is injected while the last pixels drain (at most 63 steps)
-    itags[ninj + (uint32_t)lane] = 0u;
+    grec[ninj + (uint32_t)lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     // loop constants in VGPRs: a literal or SGPR operand doubles the issue cost of the instruction that reads it
     float c099 = 0.99f, c255 = 1.0f / 255.0f, ninf = -__builtin_inff();
     v2f kneg = {-0.0625f, -1.0f};
-    uint32_t kcmp = ((uint32_t)lane << 16) | 0xffffu, kmask = 0xffffu;
-    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(ninf), "+v"(kneg), "+v"(kcmp), "+v"(kmask));
+    uint32_t kcmp = ((uint32_t)lane << 16) | 0xffffu;
+    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(ninf), "+v"(kneg), "+v"(kcmp));
     v2f acc_S = {0.f, 0.f}, acc_cxy = {0.f, 0.f}, acc_rg = {0.f, 0.f};
     float acc_cw = 0, acc_op = 0, acc_b = 0;
-    // {T, A, tag}: the state travelling through the lanes (set 1) and the injection fetched one step ahead (set 2); a step shifts set 1
-    // into set 2 (whose lane 0 holds the injection), so the sets swap roles every step: two steps per trip, no register copies.
+    // {T, A}: the state travelling through the lanes (set 1) and the injection fetched one step ahead (set 2); a step shifts set 1
+    // into set 2 (whose lane 0 holds the injection), so the sets swap roles every step: two steps per trip, no register copies.  The
+    // records alternate between Ra and Rb the same way.
     float T1 = 0.f, A1 = 0.f, T2, A2;
-    uint32_t tag1 = 0, tag2;
-    uint32_t sidx = 0, ainit = 0, atag = 0;   // (byte offsets of the next entry; past the last pixel the empty entries follow: the drain needs no code of its own)
-    asm volatile("" : "+v"(ainit), "+v"(atag));
-    GS_BW_PREFETCH(T2, A2, tag2);
+    float4 Ra, Rb;
+    uint32_t sidx = 0, ainit = 0;   // (byte offsets into smem; past the last pixel the empty entries follow: the drain needs no code of its own)
+    uint32_t arec = (uint32_t)(NENT / 2) * 16u - 16u * (uint32_t)lane;   // record (0 - lane): inside the start states for lane > 0
+    asm volatile("" : "+v"(ainit), "+v"(arec));
+    GS_BW_PREFETCH(T2, A2, Ra);
     for (;;) {
-        GS_BW_SHIFT_INJ(T2, A2, tag2, T1, A1, tag1);   // set 2 = state
-        GS_BW_PREFETCH(T1, A1, tag1);
-        GS_BW_BODY(T2, A2, tag2);
+        GS_BW_SHIFT_INJ(T2, A2, T1, A1);   // set 2 = state
+        GS_BW_PREFETCH(T1, A1, Rb);
+        GS_BW_BODY(T2, A2, Ra);
         if (++sidx >= nsteps) break;
-        GS_BW_SHIFT_INJ(T1, A1, tag1, T2, A2, tag2);   // set 1 = state
-        GS_BW_PREFETCH(T2, A2, tag2);
-        GS_BW_BODY(T1, A1, tag1);
+        GS_BW_SHIFT_INJ(T1, A1, T2, A2);   // set 1 = state
+        GS_BW_PREFETCH(T2, A2, Ra);
+        GS_BW_BODY(T1, A1, Rb);
         if (++sidx >= nsteps) break;
     }
 
