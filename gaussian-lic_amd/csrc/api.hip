@@ -69,7 +69,7 @@ GeomState GeomState::carve(const void* base, size_t P, size_t* bytes)
     Carver c(base);
     GeomState g;
     g.plan = sort_plan(P, 32);
-    g.rec = c.take<float4>(3 * P);
+    g.rec = c.take<float4>(GS_REC_F4 * P);
     g.tiles_touched = c.take<uint32_t>(P);
     g.depth_keys[0] = c.take<uint32_t>(P);
     g.depth_keys[1] = c.take<uint32_t>(P);
@@ -778,9 +778,9 @@ __global__ __launch_bounds__(256) void export_geom_kernel(int P, const float4* _
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     const bool vis = tiles[i] > 0;
-    const float4 r0 = vis ? rec[3 * (size_t)i] : make_float4(0, 0, 0, 0);
-    const float4 r1 = vis ? rec[3 * (size_t)i + 1] : make_float4(0, 0, 0, 0);
-    const float4 r2 = vis ? rec[3 * (size_t)i + 2] : make_float4(0, 0, 0, 0);
+    const float4 r0 = vis ? rec[GS_REC_F4 * (size_t)i] : make_float4(0, 0, 0, 0);
+    const float4 r1 = vis ? rec[GS_REC_F4 * (size_t)i + 1] : make_float4(0, 0, 0, 0);
+    const float4 r2 = vis ? rec[GS_REC_F4 * (size_t)i + 2] : make_float4(0, 0, 0, 0);
     if (o_tiles) o_tiles[i] = tiles[i];
     if (o_m2d) { o_m2d[2 * i] = r0.x; o_m2d[2 * i + 1] = r0.y; }
     if (o_depth) o_depth[i] = r2.y;
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(256) void export_keys_kernel(uint32_t R, const uint
                                                           const float4* __restrict__ rec, uint64_t* __restrict__ o)
 {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k < R) o[k] = ((uint64_t)tiles[k] << 32) | __float_as_uint(rec[3 * (size_t)point_list[k] + 2].y);
+    if (k < R) o[k] = ((uint64_t)tiles[k] << 32) | __float_as_uint(rec[GS_REC_F4 * (size_t)point_list[k] + 2].y);
 }
 __global__ __launch_bounds__(256) void export_ncontrib_kernel(int W, int H, int gx, const float4* __restrict__ pix_final, uint32_t* o)
 {

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(BS) void preprocess_kernel(PreprocessArgs a)
             rgb[ch] = fmax_c(res, 0.0f);
         }
     }
-    float4* rec = a.rec + 3 * (size_t)idx;
+    float4* rec = a.rec + GS_REC_F4 * (size_t)idx;
     rec[0] = make_float4(mx, my, cA, cB);
     rec[1] = make_float4(cC, op, rgb[0], rgb[1]);
     rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), __int_as_float(radius));
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
     float mx = 0, my = 0, cA = 0, cB = 0, cC = 0, thr = 0;
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     if (active) {
-        const float4 r0 = a.rec[3 * (size_t)idx], r1 = a.rec[3 * (size_t)idx + 1], r2 = a.rec[3 * (size_t)idx + 2];
+        const float4 r0 = a.rec[GS_REC_F4 * (size_t)idx], r1 = a.rec[GS_REC_F4 * (size_t)idx + 1], r2 = a.rec[GS_REC_F4 * (size_t)idx + 2];
         mx = r0.x; my = r0.y; cA = r0.z; cB = r0.w; cC = r1.x;
         thr = cull_threshold(r1.y);
         a.gauss_start[idx] = off;

@@ -462,7 +462,7 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
     // ---- SH backward (backward.cu:27-136); skipped entirely when shs == NULL (backward.cu:352) ----
     float ddc[3] = {0.f, 0.f, 0.f};
     if (a.shs) {
-        const uint32_t clamp_bits = __float_as_uint(a.rec[3 * (size_t)idx + 2].z);
+        const uint32_t clamp_bits = __float_as_uint(a.rec[GS_REC_F4 * (size_t)idx + 2].z);
         const float dox = mx3 - a.campos[0], doy = my3 - a.campos[1], doz = mz3 - a.campos[2];
         const float len = sqrtf(dox * dox + doy * doy + doz * doz);
         const float x = dox / len, y = doy / len, z = doz / len;
@@ -553,7 +553,7 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
         // chain through the activations, as LibTorch autograd does outside the reference's kernels (gaussian.cpp:147-175):
         // d exp = s; d sigmoid = o (1 - o); d normalize = dnormvdv (auxiliary.h:131-143)
         dscale[0] *= sc[0]; dscale[1] *= sc[1]; dscale[2] *= sc[2];
-        const float o = a.rec[3 * (size_t)idx + 1].y;
+        const float o = a.rec[GS_REC_F4 * (size_t)idx + 1].y;
         g_op = s_op * o * (1.0f - o);
         const float sum2 = qraw.x * qraw.x + qraw.y * qraw.y + qraw.z * qraw.z + qraw.w * qraw.w;
         const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);

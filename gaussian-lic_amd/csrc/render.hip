@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
         uint32_t fmask = 0;
         if (lane < m) {
             const uint32_t g = a.point_list[range.x + (uint32_t)(base + lane)];
-            const float4* rp = a.rec + 3 * (size_t)g;
+            const float4* rp = a.rec + GS_REC_F4 * (size_t)g;
             const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
             fdx = r0.x - (float)tx0; fdy = r0.y - (float)ty0;
             fhA = -0.5f * LOG2E * r0.z; fnB = -LOG2E * r0.w; fhC = -0.5f * LOG2E * r1.x;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
         if constexpr (STRICT) {  // raw record: absolute mean, unscaled conic
             if (lane < m) {
                 const uint32_t g = a.point_list[range.x + (uint32_t)(base + lane)];
-                const float4* rp = a.rec + 3 * (size_t)g;
+                const float4* rp = a.rec + GS_REC_F4 * (size_t)g;
                 const float4 r0 = rp[0], r1 = rp[1];
                 fdx = r0.x; fdy = r0.y; fhA = r0.z; fnB = r0.w; fhC = r1.x;
             }
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64) void render_bwd_strict_kernel(RenderBwdArgs a)
     v2f col_rg = {0.f, 0.f}, mabs = {0.f, 0.f};
     if (valid) {
         const uint32_t g = a.point_list[range.x + kit];
-        const float4* rp = a.rec + 3 * (size_t)g;
+        const float4* rp = a.rec + GS_REC_F4 * (size_t)g;
         const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
         mabs.x = r0.x; mabs.y = r0.y;  // absolute coordinates like the reference
         cA = r0.z; cB = r0.w; cC = r1.x; op = r1.y; col_rg.x = r1.z; col_rg.y = r1.w; colb = r2.x;
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     float rop = 0.f;            // 1 / opacity
     if (valid) {
         const uint32_t g = a.point_list[range.x + kit];
-        const float4* rp = a.rec + 3 * (size_t)g;
+        const float4* rp = a.rec + GS_REC_F4 * (size_t)g;
         const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
         L.d0.x = r0.x - (float)tx0; L.d0.y = r0.y - (float)ty0;
         L.hAC.x = -0.5f * LOG2E * r0.z; L.nB = -LOG2E * r0.w; L.hAC.y = -0.5f * LOG2E * r1.x;
