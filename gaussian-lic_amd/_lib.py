@@ -39,7 +39,8 @@ EXPORTS = [
     "gslic_last_error", "gslic_geom_bytes", "gslic_img_bytes", "gslic_binning_bytes", "gslic_sample_bytes",
     "gslic_profile_enable", "gslic_profile_reset", "gslic_profile_collect", "gslic_profile_num_kernels",
     "gslic_profile_kernel_name", "gslic_profile_get", "gslic_debug_export", "gslic_extend_select", "gslic_extend_emit", "gslic_loss_partials_count", "gslic_l1_ssim_loss_forward",
-    "gslic_l1_ssim_loss_backward", "gslic_set_math_mode", "gslic_rasterize_forward_capacity",
+    "gslic_l1_ssim_loss_backward", "gslic_set_math_mode", "gslic_rasterize_forward_capacity", "gslic_rasterize_backward_rgb",
+    "gslic_sh_grad_from_rgb",
 ]
 
 _lib = None
@@ -81,6 +82,9 @@ def lib():
         [ctypes.POINTER(RasterParams), i32, i32] + [vp] * 12 + [vp] * 4 + [vp] + [vp] * 6 + [f32, ctypes.POINTER(AdamFused), vp])
     L.gslic_rasterize_backward_camera.argtypes = (
         [ctypes.POINTER(RasterParams), i32, i32] + [vp] * 12 + [vp] * 4 + [vp] + [vp] * 10 + [f32, vp, vp, vp, vp])
+    L.gslic_rasterize_backward_rgb.argtypes = (
+        [ctypes.POINTER(RasterParams), i32, i32] + [vp] * 12 + [vp] * 4 + [vp] + [vp] * 5 + [f32, vp])
+    L.gslic_sh_grad_from_rgb.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp]
     L.gslic_adam_update.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, u32, u32, vp]
     L.gslic_adam_update_groups.argtypes = [ctypes.POINTER(AdamGroup), i32, vp, f32, f32, f32, u32, vp]
     L.gslic_fusedssim_forward.argtypes = [i32, i32, i32, i32, f32, f32] + [vp] * 6 + [vp]
@@ -95,7 +99,7 @@ def lib():
     L.gslic_l1_ssim_loss_forward.argtypes = [i32, i32, i32, i32, f32, f32] + [vp] * 7 + [vp]
     L.gslic_l1_ssim_loss_backward.argtypes = [i32, i32, i32, i32, f32] + [vp] * 6 + [vp]
     L.gslic_set_math_mode.argtypes = [i32]
-    if L.gslic_abi_version() != 3:
+    if L.gslic_abi_version() != 4:
         raise GslicError("libgslic_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -496,7 +496,8 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
                              const float* cam_pos, const int32_t* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
                              char* sample_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                              float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_ddc, float* dL_dsh, float* dL_dscale,
-                             float* dL_drot, float lambda_erank, const gslic_adam_fused* adam, float* const dL_dcam[3], void* stream)
+                             float* dL_drot, float lambda_erank, const gslic_adam_fused* adam, float* const dL_dcam[3], void* stream,
+                             float* dL_drgb = nullptr)
 {
     (void)background; (void)dc;
     GS_TRY(check_params(prm));
@@ -509,8 +510,10 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
     if (!means3D || !scales || !rotations || !viewmatrix || !projmatrix || !cam_pos || !radii || !geom_buffer || !binning_buffer ||
         !img_buffer || !sample_buffer || !dL_dpix || (prm->M > 0 && !shs))
         return set_error(GSLIC_ERR_INVALID_ARG, "required tensor pointer is NULL");
-    if (!adam && (!dL_dopacity || !dL_dmean3D || !dL_ddc || !dL_dscale || !dL_drot || (prm->M > 0 && !dL_dsh)))
+    if (!adam && !dL_drgb && (!dL_dopacity || !dL_dmean3D || !dL_ddc || !dL_dscale || !dL_drot || (prm->M > 0 && !dL_dsh)))
         return set_error(GSLIC_ERR_INVALID_ARG, "required gradient output pointer is NULL");
+    if (dL_drgb && (adam || dL_ddc || dL_dsh || !dL_dopacity || !dL_dmean3D || !dL_dscale || !dL_drot))
+        return set_error(GSLIC_ERR_INVALID_ARG, "dL_drgb mode: dL_ddc / dL_dsh / adam must be NULL, the four other parameter gradients are required");
     if (adam) {
         if (!prm->raw_params) return set_error(GSLIC_ERR_INVALID_ARG, "fused Adam needs raw_params = 1 (it updates the raw parameters)");
         for (int g = 0; g < 6; g++) {
@@ -546,7 +549,7 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
     pb.campos = cam_pos; pb.radii = radii; pb.rec = geom.rec; pb.tiles_touched = geom.tiles_touched; pb.gauss_start = geom.gauss_start; pb.partials = bin.partials;
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_ddc = dL_ddc; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale;
-    pb.dL_drot = dL_drot;
+    pb.dL_drot = dL_drot; pb.dL_drgb = dL_drgb;
     memset(&pb.adam, 0, sizeof(pb.adam));
     if (adam) {
         for (int g = 0; g < 6; g++) { pb.adam.p[g] = adam->param[g]; pb.adam.m[g] = adam->exp_avg[g]; pb.adam.v[g] = adam->exp_avg_sq[g]; pb.adam.lr[g] = adam->lr[g]; }
@@ -583,6 +586,32 @@ int gslic_rasterize_backward(const gslic_raster_params* prm, int32_t R, int32_t 
                                    projmatrix, cam_pos, radii, geom_buffer, binning_buffer, img_buffer, sample_buffer, dL_dpix, dL_dmean2D,
                                    dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_ddc, dL_dsh, dL_dscale, dL_drot,
                                    lambda_erank, nullptr, nullptr, stream);
+}
+
+int gslic_rasterize_backward_rgb(const gslic_raster_params* prm, int32_t R, int32_t B, const float* background, const float* means3D,
+                                 const float* dc, const float* shs, const float* colors_precomp, const float* scales,
+                                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                 const float* cam_pos, const int32_t* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
+                                 char* sample_buffer, const float* dL_dpix, float* dL_dopacity, float* dL_dmean3D, float* dL_drgb,
+                                 float* dL_dscale, float* dL_drot, float lambda_erank, void* stream)
+{
+    if (!dL_drgb) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_rasterize_backward_rgb: dL_drgb is NULL");
+    return rasterize_backward_impl(prm, R, B, background, means3D, dc, shs, colors_precomp, scales, rotations, cov3D_precomp, viewmatrix,
+                                   projmatrix, cam_pos, radii, geom_buffer, binning_buffer, img_buffer, sample_buffer, dL_dpix, nullptr,
+                                   nullptr, dL_dopacity, nullptr, dL_dmean3D, nullptr, nullptr, nullptr, dL_dscale, dL_drot, lambda_erank,
+                                   nullptr, nullptr, stream, dL_drgb);
+}
+
+int gslic_sh_grad_from_rgb(int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D, const float* campos_all,
+                           const float* rgb_all, int32_t input_is_ddc, float* dL_ddc, float* dL_dsh, void* stream)
+{
+    if (P < 0 || D < 0 || D > 3 || M < 0 || n_views < 1) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_sh_grad_from_rgb: bad P / D / M / n_views");
+    if (P == 0) return GSLIC_OK;
+    if (!means3D || !campos_all || !rgb_all || !dL_ddc || (M > 0 && !dL_dsh)) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_sh_grad_from_rgb: NULL pointer");
+    ShGradFromRgbArgs a;
+    a.P = P; a.D = D; a.M = M; a.n_views = n_views; a.input_is_ddc = input_is_ddc ? 1 : 0;
+    a.means3D = means3D; a.campos_all = campos_all; a.rgb_all = rgb_all; a.dL_ddc = dL_ddc; a.dL_dsh = dL_dsh;
+    return launch_sh_grad_from_rgb(a, (hipStream_t)stream);
 }
 
 int gslic_rasterize_backward_adam(const gslic_raster_params* prm, int32_t R, int32_t B, const float* background, const float* means3D,

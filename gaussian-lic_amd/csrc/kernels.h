@@ -88,11 +88,24 @@ struct PreprocessBwdArgs {
     const uint32_t* gauss_start;
     const float4* partials;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_ddc, *dL_dsh, *dL_dscale, *dL_drot;
+    float* dL_drgb;          // optional [P,3]: dL/d(SH colour) AFTER the clamp mask (backward.cu:41-44) — what the SH backward is linear in.
+                             // When set it is written INSTEAD of dL_ddc (which must be NULL): the N > 1 exchange ships these 12 bytes per
+                             // Gaussian and every rank rebuilds dL_ddc / dL_dsh of all views from them (launch_sh_grad_from_rgb)
     AdamFusedArgs adam;
     const uint32_t* status;  // device status words: a non-zero [2] (capacity overflow in the forward) aborts the kernel (no gradients, no Adam)
     float* cam_partials;  // optional [ceil(P/64)][32]: per-wave sums of the 27 camera-gradient terms (NULL: not computed)
     float* cam_out;       // [35] = dL_dviewmatrix[16] | dL_dprojmatrix[16] | dL_dcampos[3]
 };
 int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
+
+// dL_ddc [P,3] and dL_dsh [P,M,3] summed over n_views views from the views' masked colour gradients (rgb_all [n_views][P][3], or the
+// views' dL_ddc when input_is_ddc) and camera centres (campos_all [n_views][3]): the SH backward (backward.cu:27-136) is the outer
+// product of a direction-only coefficient vector with that colour gradient.  View order 0..n_views-1, plain multiply-then-add.
+struct ShGradFromRgbArgs {
+    int P, D, M, n_views, input_is_ddc;
+    const float *means3D, *campos_all, *rgb_all;
+    float *dL_ddc, *dL_dsh;
+};
+int launch_sh_grad_from_rgb(const ShGradFromRgbArgs& a, hipStream_t s);
 
 }  // namespace gslic

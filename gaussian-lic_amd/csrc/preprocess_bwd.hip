@@ -20,9 +20,22 @@ __constant__ float b_SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31
 __constant__ float b_SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                                  -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
 
-// Direction-only SH coefficients (the factors multiplying sh[k] in forward.cu:37-66), k = 0..14.
+// View direction of the SH evaluation (forward.cu:29-35): normalize(p - campos).  Shared by the backward and by sh_grad_from_rgb_kernel,
+// which must reproduce the backward's numbers bit for bit: no contraction in here (the backend would otherwise fuse differently at
+// the two call sites).
+__device__ __forceinline__ void sh_dir(float px, float py, float pz, const float* __restrict__ campos, float& dox, float& doy, float& doz, float& x,
+                                       float& y, float& z)
+{
+#pragma clang fp contract(off)
+    dox = px - campos[0]; doy = py - campos[1]; doz = pz - campos[2];
+    const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+    x = dox / len; y = doy / len; z = doz / len;
+}
+
+// Direction-only SH coefficients (the factors multiplying sh[k] in forward.cu:37-66), k = 0..14.  (No contraction: see sh_dir.)
 __device__ __forceinline__ void sh_coefs(int D, float x, float y, float z, float (&c)[15])
 {
+#pragma clang fp contract(off)
 #pragma unroll
     for (int k = 0; k < 15; k++) c[k] = 0.f;
     if (D > 0) {
@@ -195,12 +208,13 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
     // ---- small groups: the block's rows of xyz / dc / opacity / scale / rotation are contiguous in memory, so the Adam update runs
     // on float4 columns of those five regions (at most one float4 per thread and group, all fifteen loads issued before the math)
     if constexpr (LDS_SH) {
-        float* const gout[5] = {a.dL_dmean3D, a.dL_ddc, a.dL_dopacity, a.dL_dscale, a.dL_drot};
+        float* const gout[5] = {a.dL_dmean3D, a.dL_drgb ? a.dL_drgb : a.dL_ddc, a.dL_dopacity, a.dL_dscale, a.dL_drot};
         small_groups_sink<BS>(a.adam, gout, lds_g, lds_vis, row0, rows);
         __syncthreads();  // ... and then the dL_dsh rows
     }
     // ---- phase B: this Gaussian's dL_dsh row (zeros when invisible, when shs == NULL, and above the active degree)
     if constexpr (LDS_SH) {
+        if (!a.dL_dsh && !a.adam.on) return;   // (dL_drgb mode: the rows are rebuilt after the exchange)
         if (idx < a.P) {
             float* drow = lds_sh + threadIdx.x * 45;
             if (so.on) {
@@ -294,6 +308,7 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
         if (a.dL_dopacity) a.dL_dopacity[idx] = 0;
         if (a.dL_dmean3D) { a.dL_dmean3D[3 * idx] = 0; a.dL_dmean3D[3 * idx + 1] = 0; a.dL_dmean3D[3 * idx + 2] = 0; }
         if (a.dL_ddc) { a.dL_ddc[3 * idx] = 0; a.dL_ddc[3 * idx + 1] = 0; a.dL_ddc[3 * idx + 2] = 0; }
+        if (a.dL_drgb) { a.dL_drgb[3 * idx] = 0; a.dL_drgb[3 * idx + 1] = 0; a.dL_drgb[3 * idx + 2] = 0; }
         if (a.dL_dscale) { a.dL_dscale[3 * idx] = 0; a.dL_dscale[3 * idx + 1] = 0; a.dL_dscale[3 * idx + 2] = 0; }
         if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0, 0, 0, 0);
         return;
@@ -463,9 +478,8 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
     float ddc[3] = {0.f, 0.f, 0.f};
     if (a.shs) {
         const uint32_t clamp_bits = __float_as_uint(a.rec[GS_REC_F4 * (size_t)idx + 2].z);
-        const float dox = mx3 - a.campos[0], doy = my3 - a.campos[1], doz = mz3 - a.campos[2];
-        const float len = sqrtf(dox * dox + doy * doy + doz * doz);
-        const float x = dox / len, y = doy / len, z = doz / len;
+        float dox, doy, doz, x, y, z;
+        sh_dir(mx3, my3, mz3, a.campos, dox, doy, doz, x, y, z);
         const float* __restrict__ sh = sh_row;
         const float dRGB[3] = {(clamp_bits & 1u) ? 0.f : s_r, (clamp_bits & 2u) ? 0.f : s_g, (clamp_bits & 4u) ? 0.f : s_b};
         so.x = x; so.y = y; so.z = z; so.dR = dRGB[0]; so.dG = dRGB[1]; so.dB = dRGB[2]; so.on = true;
@@ -473,7 +487,7 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
             const float g = dRGB[ch];
-            ddc[ch] = SHC0 * g;
+            ddc[ch] = a.dL_drgb ? g : SHC0 * g;   // (dL_drgb: the dc slot of the outputs carries the masked colour gradient itself)
             float ddx = 0.f, ddy = 0.f, ddz = 0.f;
 #define S(k) sh[3 * (k) + ch]
             if (a.D > 0) {
@@ -584,6 +598,7 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
     if (a.dL_dopacity) a.dL_dopacity[idx] = g_op;
     if (a.dL_dmean3D) { a.dL_dmean3D[3 * idx] = dmean[0]; a.dL_dmean3D[3 * idx + 1] = dmean[1]; a.dL_dmean3D[3 * idx + 2] = dmean[2]; }
     if (a.dL_ddc) { a.dL_ddc[3 * idx] = ddc[0]; a.dL_ddc[3 * idx + 1] = ddc[1]; a.dL_ddc[3 * idx + 2] = ddc[2]; }
+    if (a.dL_drgb) { a.dL_drgb[3 * idx] = ddc[0]; a.dL_drgb[3 * idx + 1] = ddc[1]; a.dL_drgb[3 * idx + 2] = ddc[2]; }
     if (a.dL_dscale) { a.dL_dscale[3 * idx] = dscale[0]; a.dL_dscale[3 * idx + 1] = dscale[1]; a.dL_dscale[3 * idx + 2] = dscale[2]; }
     if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = dq;
     if (a.adam.on) {
@@ -629,7 +644,7 @@ int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
 {
     const bool cam = a.cam_partials != nullptr;
     if (cam) GS_HIP(hipMemsetAsync(a.cam_out, 0, 35 * sizeof(float), s));  // row 3 of the view matrix, row 2 of the projection: untouched terms
-    if (a.M == 15 && a.shs && (a.dL_dsh || a.adam.on)) {
+    if (a.M == 15 && a.shs && (a.dL_dsh || a.adam.on || a.dL_drgb)) {
         // one wave per workgroup: 64 Gaussians' SH rows (11.25 KiB) + small-group gradients in LDS, the phase barriers are wave-level,
         // and ten workgroups per CU sit in different phases (measured 0.72 ms against 0.75 at 128 and 0.88 at 256 threads)
         if (cam) GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64, true>), dim3(div_up(a.P, 64)), dim3(64), 0, s, a);
@@ -639,9 +654,77 @@ int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
         else GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<false, 256, false>), dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
     }
     if (cam) {
-        const size_t rows = (a.M == 15 && a.shs && (a.dL_dsh || a.adam.on)) ? (size_t)div_up(a.P, 64) : (size_t)div_up(a.P, 256) * 4;
+        const size_t rows = (a.M == 15 && a.shs && (a.dL_dsh || a.adam.on || a.dL_drgb)) ? (size_t)div_up(a.P, 64) : (size_t)div_up(a.P, 256) * 4;
         GS_LAUNCH(K_PREPROCESS_BWD, cam_reduce_kernel, dim3(27), dim3(256), 0, s, rows, (const float*)a.cam_partials, a.cam_out);
     }
+    return GSLIC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The SH backward is linear in the clamp-masked colour gradient: dL_ddc = SH_C0 * dRGB, dL_dsh[k] = c_k(dir) * dRGB (backward.cu:27-136) with
+// c_k depending only on the view direction normalize(p - campos).  So the N > 1 exchange does not have to all-reduce the 48 floats of
+// dL_ddc / dL_dsh per Gaussian: every rank all-gathers the views' 3-float dRGB and rebuilds the summed rows here — per view the very
+// products the backward forms (sh_dir / sh_coefs shared, multiply then add, no contraction), summed in view order.
+// One wave per 64 Gaussians; the rows leave through LDS as contiguous runs (M == 15) like the backward's own dL_dsh rows.
+__global__ __launch_bounds__(64) void sh_grad_from_rgb_kernel(ShGradFromRgbArgs a)
+{
+#pragma clang fp contract(off)
+    __shared__ float lds_rows[64 * 48];
+    const int t = threadIdx.x;
+    const int row0 = blockIdx.x * 64;
+    const int idx = row0 + t;
+    const int rows = (a.P - row0) < 64 ? (a.P - row0) : 64;
+    float acc[45], adc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 45; k++) acc[k] = 0.f;
+    if (idx < a.P) {
+        const float px = a.means3D[3 * (size_t)idx], py = a.means3D[3 * (size_t)idx + 1], pz = a.means3D[3 * (size_t)idx + 2];
+        for (int v = 0; v < a.n_views; v++) {
+            const float* g = a.rgb_all + ((size_t)v * a.P + idx) * 3;
+            float d[3] = {g[0], g[1], g[2]};
+            if (d[0] == 0.f && d[1] == 0.f && d[2] == 0.f) continue;   // invisible in this view (or all channels clamped): adds exact zeros
+            float dc_v[3];
+            if (a.input_is_ddc) {   // the view's dL_ddc = SH_C0 * dRGB was shipped (hosts that only have the reference's gradient tensors)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) { dc_v[ch] = d[ch]; d[ch] = d[ch] * (1.0f / SHC0); }
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) dc_v[ch] = SHC0 * d[ch];
+            }
+            float dox, doy, doz, x, y, z, c[15];
+            sh_dir(px, py, pz, a.campos_all + 3 * v, dox, doy, doz, x, y, z);
+            sh_coefs(a.D, x, y, z, c);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) adc[ch] = adc[ch] + dc_v[ch];
+#pragma unroll
+            for (int k = 0; k < 15; k++) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const float prod = c[k] * d[ch];
+                    acc[3 * k + ch] = acc[3 * k + ch] + prod;
+                }
+            }
+        }
+    }
+    // dc rows [64 x 3] then rest rows [64 x 45] through LDS: contiguous float runs instead of 48 strided 4-byte stores per thread
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) lds_rows[3 * t + ch] = adc[ch];
+#pragma unroll
+    for (int k = 0; k < 45; k++) lds_rows[192 + 45 * t + k] = acc[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = t; i < rows * 3; i += 64) a.dL_ddc[(size_t)row0 * 3 + i] = lds_rows[i];
+    if (a.M == 15) {
+        for (int i = t; i < rows * 45; i += 64) a.dL_dsh[(size_t)row0 * 45 + i] = lds_rows[192 + i];
+    } else if (a.M > 0 && idx < a.P) {   // generic row width: coefficients above 15 (and above the active degree) are zero
+        for (int k = 0; k < 3 * a.M; k++) a.dL_dsh[(size_t)3 * a.M * idx + k] = k < 45 ? lds_rows[192 + 45 * t + k] : 0.f;
+    }
+}
+
+int launch_sh_grad_from_rgb(const ShGradFromRgbArgs& a, hipStream_t s)
+{
+    if (a.P <= 0) return GSLIC_OK;
+    GS_LAUNCH(K_PREPROCESS_BWD, sh_grad_from_rgb_kernel, dim3(div_up(a.P, 64)), dim3(64), 0, s, a);
     return GSLIC_OK;
 }
 

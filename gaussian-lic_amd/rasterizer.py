@@ -133,7 +133,7 @@ def rasterize_gaussians_capacity(bufs, background, means3D, opacity, scales, rot
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                                  projmatrix, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, dL_dout_color, dc, sh,
                                  degree, campos, geomBuffer, R, binningBuffer, imageBuffer, B, sampleBuffer, lambda_erank, debug,
-                                 raw_params=False, out=None, adam=None, camera_grads=False):
+                                 raw_params=False, out=None, adam=None, camera_grads=False, rgb_out=None):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:151-246): returns (dL_dmeans2D, dL_dcolors_precomp,
     dL_dopacities, dL_dmeans3D, dL_dcov3Ds_precomp, dL_ddc, dL_dsh, dL_dscales, dL_drotations).
     raw_params=True: scales / rotations are raw and dL_dopacities / dL_dscales / dL_drotations are w.r.t. the raw parameters.
@@ -158,6 +158,23 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             ctypes.c_void_p(geomBuffer.data_ptr()), ctypes.c_void_p(binningBuffer.data_ptr()), ctypes.c_void_p(imageBuffer.data_ptr()),
             ctypes.c_void_p(sampleBuffer.data_ptr()), p(dL), None, None, None, None, None, None, float(lambda_erank), ctypes.byref(adam),
             _lib.current_stream_ptr()))
+        return None
+    if rgb_out is not None:
+        # N > 1 exchange (gslic_rasterize_backward_rgb): the clamp-masked colour gradient [P,3] is written instead of dL_ddc / dL_dsh; the
+        # four other parameter gradients go into the caller's storage (`out`), nothing else is materialised
+        assert out is not None
+        if P != 0:
+            means3D, dc, scales, rotations, dL = map(_f32c, (means3D, dc, scales, rotations, dL_dout_color))
+            sh_c = _f32c(sh) if M > 0 else None
+            viewmatrix, projmatrix, campos, background = map(_f32c, (viewmatrix, projmatrix, campos, background))
+            prm = _params(P, degree, M, H, W, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier, False, debug, False, raw_params)
+            p = _lib.ptr
+            _lib.check(L.gslic_rasterize_backward_rgb(
+                ctypes.byref(prm), int(R), int(B), p(background), p(means3D), p(dc), p(sh_c), p(colors), p(scales), p(rotations),
+                p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos), p(radii.contiguous()),
+                ctypes.c_void_p(geomBuffer.data_ptr()), ctypes.c_void_p(binningBuffer.data_ptr()), ctypes.c_void_p(imageBuffer.data_ptr()),
+                ctypes.c_void_p(sampleBuffer.data_ptr()), p(dL), p(out["opacity"]), p(out["xyz"]), p(rgb_out), p(out["scaling"]), p(out["rotation"]),
+                float(lambda_erank), _lib.current_stream_ptr()))
         return None
     if out is not None:
         # caller-provided gradient storage (e.g. views of one flat slab for a zero-copy all-reduce); the tensors the host
@@ -249,6 +266,18 @@ def render(camera, model, bg_color, no_color=False, scaling_modifier=1.0):
     image, radii, final_T = rasterizer(xyz, screenspace_points, model.get_opacity(), model.get_features_dc(),
                                        model.get_features_rest(), None, model.get_scaling(), model.get_rotation(), None)
     return image, final_T, screenspace_points, radii > 0, radii
+
+
+def sh_grad_from_rgb(means3D, campos_all, rgb_all, degree, dL_ddc, dL_dsh, input_is_ddc=False):
+    """gslic_sh_grad_from_rgb: dL_ddc [P,1,3] and dL_dsh [P,M,3] summed over the views from the views' masked colour gradients
+    rgb_all [n_views,P,3] and camera centres campos_all [n_views,3] (all device fp32, contiguous); written in place."""
+    P, n = means3D.size(0), rgb_all.size(0)
+    M = dL_dsh.size(1) if dL_dsh is not None and dL_dsh.numel() else 0
+    assert rgb_all.is_contiguous() and campos_all.is_contiguous() and dL_ddc.is_contiguous() and (M == 0 or dL_dsh.is_contiguous())
+    assert tuple(rgb_all.shape) == (n, P, 3) and tuple(campos_all.shape) == (n, 3)
+    p = _lib.ptr
+    _lib.check(_lib.lib().gslic_sh_grad_from_rgb(P, int(degree), M, n, p(_f32c(means3D)), p(campos_all), p(rgb_all), int(bool(input_is_ddc)), p(dL_ddc),
+                                                 p(dL_dsh) if M else None, _lib.current_stream_ptr()))
 
 
 def debug_export(settings, P, M, R, B, geom, binning, img, sample, what=("tiles_touched", "point_list", "ranges")):

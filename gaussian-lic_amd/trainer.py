@@ -128,6 +128,16 @@ class GaussianModel:
         return k
 
 
+def exchange_mode():
+    """How the N > 1 step exchanges gradients: "rank1" (default: 11 floats all-reduced + the 3-float colour gradient all-gathered,
+    exchange_rank1), "dense" (the whole [P x 59] slab all-reduced in three pipelined segments), "sparse" (only the rows some view sees).
+    GSLIC_EXCHANGE selects; GSLIC_SPARSE_EXCHANGE=1 is the older spelling of "sparse"."""
+    m = os.environ.get("GSLIC_EXCHANGE", "").lower()
+    if m in ("rank1", "dense", "sparse"):
+        return m
+    return "sparse" if os.environ.get("GSLIC_SPARSE_EXCHANGE") == "1" else "rank1"
+
+
 def _dist_on():
     """True when the per-step gradient exchange has to run.  GSLIC_FORCE_DIST=1 also takes the exchange path in a process group of
     ONE rank (the RCCL smoke test on a single-GPU box: same code path as N > 1, the all-reduce degenerates to a copy)."""
@@ -146,6 +156,8 @@ class GradSlab:
         shapes = [tuple(p.shape) for p in model.parameters()]
         sizes = [int(torch.tensor(s).prod()) for s in shapes]
         self.flat = torch.empty(sum(sizes), device=model.device)
+        self.rgb = torch.empty(self.P, 3, device=model.device)   # this view's clamp-masked colour gradient (exchange_rank1)
+        self.rgb_all, self.campos_all = None, None
         self.views, off = {}, 0
         for name, shp, n in zip(model.NAMES, shapes, sizes):
             self.views[name] = self.flat[off:off + n].view(shp)
@@ -153,6 +165,14 @@ class GradSlab:
 
     def grads(self, model):
         return [self.views[n] for n in model.NAMES]
+
+    def run(self, model, g0, g1):
+        """(flat slice covering the whole groups g0..g1-1, their indices): consecutive groups are contiguous in the slab."""
+        sizes = [self.views[n].numel() for n in model.NAMES]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
+        return self.flat[offs[g0]:offs[g1]], list(range(g0, g1))
 
     def segments(self, model):
         """The slab as three contiguous runs of whole groups, largest first: features_rest (76 % of the bytes), then
@@ -210,6 +230,35 @@ def allreduce_slab_sparse(slab, visible, model):
     for r, part in zip(rows, parts):
         r.index_copy_(0, idx, part)
     return mask, V
+
+
+def exchange_rank1(slab, rgb_local, visible, model, campos):
+    """The N > 1 exchange with the SH gradients shipped as what they are — rank-1.  computeColorFromSH's backward (backward.cu:27-136) is
+    linear in the clamp-masked colour gradient dRGB: dL_ddc = SH_C0 dRGB, dL_dsh[k] = c_k(dir) dRGB with c_k a function of the view
+    direction only.  So of the 59 gradient floats per Gaussian only 11 (xyz, opacity, scaling, rotation) are all-reduced; each rank
+    all-gathers the views' 3-float dRGB and camera centres and rebuilds the summed dL_ddc / dL_dsh itself (gslic_sh_grad_from_rgb:
+    the backward's own products, summed in view order — at N = 2 bit-identical to the dense all-reduce).  Bytes on a rank's links per
+    step: 2 (N-1)/N 44 P + (N-1) 12 P instead of 2 (N-1)/N 236 P — 4.2x less at N = 2, 2.6x less at N = 8 (xGMI is point-to-point: the
+    dense slab is per-link bound).
+    Returns (OR-ed visibility, works) like allreduce_slab_async: wait on a work, then run Adam on its groups; the rebuild of the SH
+    rows runs behind the all-gather (first work) while the small all-reduces are still on the links."""
+    from . import rasterizer as rz
+    dist = torch.distributed
+    n = dist.get_world_size()
+    vis = visible.to(torch.uint8)
+    dist.all_reduce(vis, op=dist.ReduceOp.MAX)
+    if slab.rgb_all is None or slab.rgb_all.size(0) != n:
+        slab.rgb_all = torch.empty(n, slab.P, 3, device=slab.flat.device)
+        slab.campos_all = torch.empty(n, 3, device=slab.flat.device)
+    w_cam = dist.all_gather_into_tensor(slab.campos_all, campos.reshape(1, 3).contiguous(), async_op=True)
+    w_rgb = dist.all_gather_into_tensor(slab.rgb_all, rgb_local.view(1, slab.P, 3), async_op=True)
+    works = [(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True), idx) for seg, idx in (slab.run(model, 0, 1), slab.run(model, 3, 6))]
+
+    class _Rebuild:   # waits for the gathered colour gradients, then rebuilds dL_ddc / dL_dsh of all views into the slab
+        def wait(self_inner):
+            w_cam.wait(); w_rgb.wait()
+            rz.sh_grad_from_rgb(model.xyz.detach(), slab.campos_all, slab.rgb_all, model.sh_degree, slab.views["features_dc"], slab.views["features_rest"])
+    return vis.bool(), [(_Rebuild(), [1, 2])] + works
 
 
 def allreduce_gradients(grads, visible):
@@ -277,13 +326,27 @@ def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=Tr
         slab = getattr(model, "_grad_slab", None)
         if slab is None or slab.P != model.P:
             slab = model._grad_slab = GradSlab(model)
+        mode = exchange_mode() if (do_step and _dist_on()) else None
+        if mode == "rank1":
+            # the SH gradients travel as the 3-float colour gradient they are the outer product of (exchange_rank1)
+            rz.rasterize_gaussians_backward(
+                bg, xyz, radii, e, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
+                float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dL_dimage, dc, rest, model.sh_degree,
+                cam.d_camera_center, geom, R, binning, img, B, sample, model.lambda_erank, False, raw_params=True, out=slab.views, rgb_out=slab.rgb)
+            visible, works = exchange_rank1(slab, slab.rgb, radii > 0, model, cam.d_camera_center)
+            model.optimizer.set_visibility_and_N(visible, model.P)
+            grads = slab.grads(model)
+            for work, idx in works:
+                work.wait()
+                model.optimizer.step(grads, only=idx)
+            return terms, visible
         rz.rasterize_gaussians_backward(
             bg, xyz, radii, e, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
             float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dL_dimage, dc, rest, model.sh_degree,
             cam.d_camera_center, geom, R, binning, img, B, sample, model.lambda_erank, False, raw_params=True, out=slab.views)
         visible = radii > 0
         if do_step:
-            if _dist_on() and os.environ.get("GSLIC_SPARSE_EXCHANGE") == "1":
+            if mode == "sparse":
                 visible, _rows = allreduce_slab_sparse(slab, visible, model)   # visible rows only: fewer bytes on the links, one gather / scatter pass
                 model.optimizer.set_visibility_and_N(visible, model.P)
                 model.optimizer.step(slab.grads(model))

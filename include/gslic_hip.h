@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSLIC_ABI_VERSION 3
+#define GSLIC_ABI_VERSION 4
 
 typedef enum gslic_status {
     GSLIC_OK = 0,
@@ -217,6 +217,34 @@ int gslic_rasterize_backward_adam(
     char* geom_buffer, char* binning_buffer, char* img_buffer, char* sample_buffer, const float* dL_dpix,
     float* dL_dopacity, float* dL_dmean3D, float* dL_ddc, float* dL_dsh, float* dL_dscale, float* dL_drot,
     float lambda_erank, const gslic_adam_fused* adam, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * gslic_rasterize_backward_rgb + gslic_sh_grad_from_rgb — the backward split for the N-GPU exchange (no reference counterpart: the
+ * reference is single-GPU).  The SH backward (computeColorFromSH, backward.cu:27-136) is linear in the clamp-masked colour gradient
+ * dRGB: dL_ddc = SH_C0 dRGB and dL_dsh[k] = c_k(dir) dRGB, with c_k a function of the view direction normalize(p - campos) only.
+ * So a rank does not have to all-reduce the 48 floats of dL_ddc / dL_dsh per Gaussian (81 % of the gradient bytes): it ships dRGB
+ * (12 bytes), all-gathers the other views' dRGB and camera centres, and rebuilds the SUMMED rows locally.  xGMI is point-to-point —
+ * bytes on the links are what bounds the N > 1 step.
+ *
+ * gslic_rasterize_backward_rgb  = gslic_rasterize_backward that writes dL_drgb [P,3] (zeros for invisible Gaussians) instead of
+ *                                 dL_ddc / dL_dsh; the gradients the host discards are not materialised.
+ * gslic_sh_grad_from_rgb        dL_ddc [P,3], dL_dsh [P,M,3] = sum over v < n_views of view v's rows, from
+ *                                 rgb_all [n_views][P][3] and campos_all [n_views][3] (device), in view order with the backward's own
+ *                                 arithmetic (bit-identical to summing the per-view gslic_rasterize_backward outputs in that order).
+ *                                 input_is_ddc = 1: rgb_all holds the views' dL_ddc instead (hosts that only see the reference's
+ *                                 gradient tensors); dRGB is then recovered as dL_ddc * (1 / SH_C0), exact to 1 ulp.
+ */
+int gslic_rasterize_backward_rgb(
+    const gslic_raster_params* prm, int32_t R, int32_t B,
+    const float* background, const float* means3D, const float* dc, const float* shs, const float* colors_precomp,
+    const float* scales, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos, const int32_t* radii,
+    char* geom_buffer, char* binning_buffer, char* img_buffer, char* sample_buffer, const float* dL_dpix,
+    float* dL_dopacity, float* dL_dmean3D, float* dL_drgb, float* dL_dscale, float* dL_drot,
+    float lambda_erank, void* stream);
+int gslic_sh_grad_from_rgb(
+    int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D, const float* campos_all /*[n_views,3]*/,
+    const float* rgb_all /*[n_views,P,3]*/, int32_t input_is_ddc, float* dL_ddc, float* dL_dsh, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * gslic_rasterize_backward_camera — gslic_rasterize_backward plus the gradient w.r.t. the CAMERA inputs (the "cam" of the

@@ -154,15 +154,35 @@ def test_two_ranks_sparse_exchange_equals_dense():
         env = dict(os.environ)
         env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
         env.pop("GSLIC_FORCE_DIST", None)
-        if sparse:
-            env["GSLIC_SPARSE_EXCHANGE"] = "1"
-        else:
-            env.pop("GSLIC_SPARSE_EXCHANGE", None)
+        env.pop("GSLIC_SPARSE_EXCHANGE", None)
+        env["GSLIC_EXCHANGE"] = "sparse" if sparse else "dense"
         return subprocess.Popen([sys.executable, "-c", TWO_RANK_SNIPPET.format(root=ROOT)], env=env, stdout=subprocess.PIPE,
                                 stderr=subprocess.PIPE, text=True)
     digests = []
     for sparse, port in ((False, "29571"), (True, "29573")):
         procs = [run(0, sparse, port), run(1, sparse, port)]
+        outs = [p.communicate(timeout=600) for p in procs]
+        for p, (so, se) in zip(procs, outs):
+            assert p.returncode == 0, se[-2000:]
+        d = [[l for l in so.splitlines() if l.startswith("DIGEST")][-1].split()[2] for so, _ in outs]
+        assert d[0] == d[1]
+        digests.append(d[0])
+    assert digests[0] == digests[1]
+
+
+@pytest.mark.gpu
+def test_two_ranks_rank1_exchange_equals_dense():
+    """The default N > 1 exchange (rank-1: 11 floats all-reduced, the 3-float colour gradients all-gathered, SH rows rebuilt locally)
+    against GSLIC_EXCHANGE=dense (the whole slab all-reduced) on the complete N = 2 step, two processes sharing the GPU: the same bits."""
+    def run(rank, mode, port):
+        env = dict(os.environ)
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0", GSLIC_EXCHANGE=mode)
+        env.pop("GSLIC_FORCE_DIST", None); env.pop("GSLIC_SPARSE_EXCHANGE", None)
+        return subprocess.Popen([sys.executable, "-c", TWO_RANK_SNIPPET.format(root=ROOT)], env=env, stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True)
+    digests = []
+    for mode, port in (("dense", "29575"), ("rank1", "29577")):
+        procs = [run(0, mode, port), run(1, mode, port)]
         outs = [p.communicate(timeout=600) for p in procs]
         for p, (so, se) in zip(procs, outs):
             assert p.returncode == 0, se[-2000:]

@@ -67,6 +67,40 @@ def _worker(rank, world, port, q):
     assert torch.equal(svis2, dvis) and rows == int(dvis.sum())
     for a, b in zip(slab.grads(_M()), dense_red):
         assert torch.equal(a, b)      # bit for bit the dense result (two addends)
+    # the rank-1 exchange (default at N > 1): xyz / opacity / scaling / rotation all-reduced, the views' masked colour gradients and
+    # camera centres all-gathered, dL_ddc / dL_dsh of all views rebuilt locally.  The HIP rebuild kernel is replaced by its plain-torch
+    # restatement here (tests/sh_rank1_ref.py; the kernel itself is checked on the GPU): this covers the collectives, the slab
+    # layout and the order in which the groups become ready
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import sh_rank1_ref as ref
+    from gaussian_lic_amd import rasterizer as rz
+    means = torch.randn(P, 3, generator=torch.Generator().manual_seed(7)) * 3.0     # replicated map: same on every rank
+    campos = torch.tensor([0.25 * rank - 0.1, 0.05 * rank, -0.3])
+    rgb = torch.randn(P, 3, generator=g) * vis.view(-1, 1)                          # zeros where this view does not see the Gaussian
+    dc_v, sh_v = ref.rows_one_view(means, campos, rgb, 3, 15)
+    for v, x in zip(slab.grads(_M()), [grads[0] * vis.view(-1, 1), dc_v, sh_v, grads[3] * vis.view(-1, 1), grads[4] * vis.view(-1, 1), grads[5] * vis.view(-1, 1)]):
+        v.copy_(x)
+    keep = [v.clone() for v in slab.grads(_M())]
+    trainer.allreduce_slab(slab, vis)
+    dense_r1 = [v.clone() for v in slab.grads(_M())]
+    for v, x in zip(slab.grads(_M()), keep):
+        v.copy_(x)
+    slab.views["features_dc"].fill_(float("nan")); slab.views["features_rest"].fill_(float("nan"))   # not shipped: rebuilt after the exchange
+    def _rebuild(means3D, campos_all, rgb_all, degree, dL_ddc, dL_dsh, input_is_ddc=False):
+        a, b = ref.rows_from_rgb(means3D, campos_all, rgb_all, degree, dL_dsh.shape[1])
+        dL_ddc.copy_(a); dL_dsh.copy_(b)
+    rz.sh_grad_from_rgb = _rebuild
+    class _Model(_M):
+        xyz = means
+        sh_degree = 3
+    r1vis, works = trainer.exchange_rank1(slab, rgb.contiguous(), vis, _Model(), campos)
+    order = []
+    for work, idx in works:
+        work.wait()
+        order += idx
+    assert order == [1, 2, 0, 3, 4, 5] and torch.equal(r1vis, dvis)
+    for i, (a, b) in enumerate(zip(slab.grads(_M()), dense_r1)):
+        assert torch.equal(a, b), i      # two addends, the restatement on both sides: bit for bit the dense all-reduce
     q.put((rank, [r.clone().numpy() for r in red], rvis.numpy(), [x.numpy() for x in grads], vis.numpy()))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
