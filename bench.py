@@ -265,6 +265,8 @@ def main():
     avg_ms = dom_ms / max(dom_n, 1)
     fused_adam = args.mode in ("train", "slam") and args.host == "fused" and world == 1
     abytes = algorithmic_bytes("preprocess_bwd+adam" if (dominant == "preprocess_bwd" and fused_adam) else dominant, stats)
+    if dominant == "adam" and dom_n > args.steps:
+        abytes /= round(dom_n / args.steps)   # N > 1: the optimiser runs once per exchanged segment; the formula is per STEP, the time per launch
     achieved = abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # HBM traffic and VALU instruction counts cannot be measured from inside this process (PMC counters need rocprofv3 around it): they are
     # REPLAYED from the committed profile of the same workload and labelled with the file they come from; null when the workload differs.
@@ -334,7 +336,9 @@ def main():
                                + (f"; learning rates x{args.lr_scale:g} (stationary synthetic scene)" if args.mode != "render" else "")
                                + ("; step replayed as one hipGraph (capacity-mode forward)" if args.graph else "")
                                + ("; extend() append of a LiDAR frame every 10 steps, timed" if args.mode == "slam" else "")
-                               + ("" if world == 1 else f"; {world} views/step, one gradient all-reduce per step"),
+                               + ("" if world == 1 else f"; {world} views/step, one gradient exchange per step ({trainer.exchange_mode()}: "
+                                  + {"rank1": "xyz / opacity / scaling / rotation all-reduced, the 3-float colour gradients all-gathered and the SH rows rebuilt locally",
+                                     "dense": "the [P x 59] slab all-reduced", "sparse": "the visible rows of the slab all-reduced"}[trainer.exchange_mode()] + ")"),
                    "mode": args.mode, "host": args.host if args.mode != "render" else "dropin", "parallelism": f"dp{world}" if world > 1 else "single",
                    "visible": stats["V"], "instances_R": stats["R"], "buckets_B": stats["B"]},
         "roofline": roofline,

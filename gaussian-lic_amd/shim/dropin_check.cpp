@@ -10,6 +10,7 @@
 #ifdef GSLIC_DIST
 #include "gslic_dist.h"             // the N > 1 exchange step (this repo): RANK / WORLD_SIZE / MASTER_PORT from the environment
 #include <cstdlib>
+#include <unistd.h>
 #endif
 
 #include <fstream>
@@ -50,6 +51,7 @@ int main(int argc, char** argv)
     const int rank = std::getenv("RANK") ? std::atoi(std::getenv("RANK")) : 0, world = std::getenv("WORLD_SIZE") ? std::atoi(std::getenv("WORLD_SIZE")) : 1;
     const int port = std::getenv("MASTER_PORT") ? std::atoi(std::getenv("MASTER_PORT")) : 29591;
     const bool sparse = std::getenv("GSLIC_SPARSE_EXCHANGE") && std::atoi(std::getenv("GSLIC_SPARSE_EXCHANGE")) != 0;
+    const bool rank1 = std::getenv("GSLIC_EXCHANGE") && std::string(std::getenv("GSLIC_EXCHANGE")) == "rank1";
     // one process per GPU: the launcher gives every rank its device through HIP_VISIBLE_DEVICES, so "cuda:0" is this rank's GPU
     auto pg = gslic::make_rccl_group("127.0.0.1", port, rank, world);
     const std::string sfx = world > 1 ? "_" + std::to_string(rank) : "";   // rank k renders view k: view_k.f32, proj_k.f32, campos_k.f32, gt_k.f32
@@ -93,7 +95,8 @@ int main(int argc, char** argv)
         auto visible = radii > 0;
 #ifdef GSLIC_DIST
         // the one exchange of the N-GPU step, between loss.backward() and step() (gaussian.cpp:697-707): SUM of the gradients, OR of the masks
-        visible = gslic::exchange_gradients(*pg, {xyz, dc, rest, opacity, scaling, rotation}, visible, sparse);
+        if (rank1) visible = gslic::exchange_gradients_rank1(*pg, {xyz, dc, rest, opacity, scaling, rotation}, visible, campos, deg);   // 11 floats all-reduced + 3 all-gathered
+        else visible = gslic::exchange_gradients(*pg, {xyz, dc, rest, opacity, scaling, rotation}, visible, sparse);
 #endif
         opt.set_visibility_and_N(visible, xyz.size(0));
         opt.step();
@@ -101,11 +104,18 @@ int main(int argc, char** argv)
         std::cout << "iter " << it << " loss " << loss.item<float>() << " visible " << visible.sum().item<int>() << std::endl;
     }
 #ifdef GSLIC_DIST
-    if (rank != 0) return 0;   // replicas are identical: rank 0 reports
+    if (rank != 0) { torch::cuda::synchronize(); std::cout.flush(); _exit(0); }   // replicas are identical: rank 0 reports
 #endif
     save(d + "/out_image.f32", image);
     save(d + "/out_xyz.f32", xyz); save(d + "/out_scaling.f32", scaling); save(d + "/out_rotation.f32", rotation);
     save(d + "/out_opacity.f32", opacity); save(d + "/out_dc.f32", dc);
     if (M > 0) save(d + "/out_rest.f32", rest);
+#ifdef GSLIC_DIST
+    // leave without running static destructors: tearing down c10d's ProcessGroupNCCL / RCCL at process exit aborts intermittently
+    // ("double free or corruption") after all work is done and saved — not something this check is about
+    torch::cuda::synchronize();
+    std::cout << "saved" << std::endl;
+    _exit(0);
+#endif
     return 0;
 }
