@@ -611,6 +611,29 @@ int gslic_sh_grad_from_rgb(int32_t P, int32_t D, int32_t M, int32_t n_views, con
     ShGradFromRgbArgs a;
     a.P = P; a.D = D; a.M = M; a.n_views = n_views; a.input_is_ddc = input_is_ddc ? 1 : 0;
     a.means3D = means3D; a.campos_all = campos_all; a.rgb_all = rgb_all; a.dL_ddc = dL_ddc; a.dL_dsh = dL_dsh;
+    a.visible = nullptr;
+    memset(&a.adam, 0, sizeof(a.adam));
+    return launch_sh_grad_from_rgb(a, (hipStream_t)stream);
+}
+
+int gslic_sh_grad_from_rgb_adam(int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D, const float* campos_all,
+                                const float* rgb_all, int32_t input_is_ddc, const uint8_t* visible, const gslic_adam_fused* adam, float* dL_ddc,
+                                float* dL_dsh, void* stream)
+{
+    if (P < 0 || D < 0 || D > 3 || M < 0 || n_views < 1) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_sh_grad_from_rgb_adam: bad P / D / M / n_views");
+    if (P == 0) return GSLIC_OK;
+    if (!means3D || !campos_all || !rgb_all || !visible || !adam) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_sh_grad_from_rgb_adam: NULL pointer");
+    for (int g = 1; g <= 2; g++) {
+        if (g == 2 && M == 0) continue;
+        if (!adam->param[g] || !adam->exp_avg[g] || !adam->exp_avg_sq[g]) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_sh_grad_from_rgb_adam: group %d has a NULL pointer", g);
+    }
+    ShGradFromRgbArgs a;
+    a.P = P; a.D = D; a.M = M; a.n_views = n_views; a.input_is_ddc = input_is_ddc ? 1 : 0;
+    a.means3D = means3D; a.campos_all = campos_all; a.rgb_all = rgb_all; a.dL_ddc = dL_ddc; a.dL_dsh = M > 0 ? dL_dsh : nullptr;
+    a.visible = visible;
+    memset(&a.adam, 0, sizeof(a.adam));
+    for (int g = 1; g <= 2; g++) { a.adam.p[g] = adam->param[g]; a.adam.m[g] = adam->exp_avg[g]; a.adam.v[g] = adam->exp_avg_sq[g]; a.adam.lr[g] = adam->lr[g]; }
+    a.adam.b1 = adam->b1; a.adam.b2 = adam->b2; a.adam.eps = adam->eps; a.adam.on = 1;
     return launch_sh_grad_from_rgb(a, (hipStream_t)stream);
 }
 

@@ -104,7 +104,9 @@ int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
 struct ShGradFromRgbArgs {
     int P, D, M, n_views, input_is_ddc;
     const float *means3D, *campos_all, *rgb_all;
-    float *dL_ddc, *dL_dsh;
+    float *dL_ddc, *dL_dsh;     // outputs; both may be NULL when the Adam update below consumes the rows
+    const uint8_t* visible;     // [P] the exchanged (OR-ed) visibility mask: rows the Adam update applies to
+    AdamFusedArgs adam;         // on: groups 1 (features_dc) and 2 (features_rest) are updated in place from the rebuilt rows
 };
 int launch_sh_grad_from_rgb(const ShGradFromRgbArgs& a, hipStream_t s);
 

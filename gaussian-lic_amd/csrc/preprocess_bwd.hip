@@ -666,6 +666,7 @@ int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
 // dL_ddc / dL_dsh per Gaussian: every rank all-gathers the views' 3-float dRGB and rebuilds the summed rows here — per view the very
 // products the backward forms (sh_dir / sh_coefs shared, multiply then add, no contraction), summed in view order.
 // One wave per 64 Gaussians; the rows leave through LDS as contiguous runs (M == 15) like the backward's own dL_dsh rows.
+template <bool ADAM>
 __global__ __launch_bounds__(64) void sh_grad_from_rgb_kernel(ShGradFromRgbArgs a)
 {
 #pragma clang fp contract(off)
@@ -713,18 +714,84 @@ __global__ __launch_bounds__(64) void sh_grad_from_rgb_kernel(ShGradFromRgbArgs 
     for (int k = 0; k < 45; k++) lds_rows[192 + 45 * t + k] = acc[k];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int i = t; i < rows * 3; i += 64) a.dL_ddc[(size_t)row0 * 3 + i] = lds_rows[i];
-    if (a.M == 15) {
-        for (int i = t; i < rows * 45; i += 64) a.dL_dsh[(size_t)row0 * 45 + i] = lds_rows[192 + i];
-    } else if (a.M > 0 && idx < a.P) {   // generic row width: coefficients above 15 (and above the active degree) are zero
-        for (int k = 0; k < 3 * a.M; k++) a.dL_dsh[(size_t)3 * a.M * idx + k] = k < 45 ? lds_rows[192 + 45 * t + k] : 0.f;
+    if (a.dL_ddc)
+        for (int i = t; i < rows * 3; i += 64) a.dL_ddc[(size_t)row0 * 3 + i] = lds_rows[i];
+    if (a.dL_dsh) {
+        if (a.M == 15) {
+            for (int i = t; i < rows * 45; i += 64) a.dL_dsh[(size_t)row0 * 45 + i] = lds_rows[192 + i];
+        } else if (a.M > 0 && idx < a.P) {   // generic row width: coefficients above 15 (and above the active degree) are zero
+            for (int k = 0; k < 3 * a.M; k++) a.dL_dsh[(size_t)3 * a.M * idx + k] = k < 45 ? lds_rows[192 + 45 * t + k] : 0.f;
+        }
+    }
+    if constexpr (ADAM) {
+        // the masked Adam of optim_utils.h:102-137 on features_dc and features_rest straight from the rebuilt rows (adam_scalar: the one
+        // definition every call site shares), on float4 columns of the block's contiguous regions like the fused backward's phase C
+        __shared__ uint8_t lds_vis[64];
+        lds_vis[t] = (idx < a.P && a.visible[idx]) ? 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const AdamFusedArgs& A = a.adam;
+        auto update = [&](int grp, int width, const float* rows_lds, size_t base) {
+            // region of this block: rows * width floats at param + base, 16-byte aligned (row0 is a multiple of 64)
+            if (rows == 64) {
+                const int nv = 64 * width / 4;
+                const float4* s4 = reinterpret_cast<const float4*>(rows_lds);
+                constexpr int U = 4;
+                for (int i0 = t; i0 < nv; i0 += 64 * U) {
+                    float4 g[U], p[U], m[U], v[U];
+                    bool vis[U][4], any[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int i = i0 + 64 * u;
+                        any[u] = false;
+                        if (i < nv) {
+                            g[u] = s4[i];
+                            const int e = 4 * i;
+                            vis[u][0] = lds_vis[e / width]; vis[u][1] = lds_vis[(e + 1) / width];
+                            vis[u][2] = lds_vis[(e + 2) / width]; vis[u][3] = lds_vis[(e + 3) / width];
+                            any[u] = vis[u][0] | vis[u][1] | vis[u][2] | vis[u][3];
+                        }
+                        if (any[u]) {
+                            p[u] = reinterpret_cast<float4*>(A.p[grp] + base)[i];
+                            m[u] = reinterpret_cast<float4*>(A.m[grp] + base)[i];
+                            v[u] = reinterpret_cast<float4*>(A.v[grp] + base)[i];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        if (!any[u]) continue;
+                        const int i = i0 + 64 * u;
+                        if (vis[u][0]) adam_scalar(p[u].x, g[u].x, m[u].x, v[u].x, A.lr[grp], A.b1, A.b2, A.eps);
+                        if (vis[u][1]) adam_scalar(p[u].y, g[u].y, m[u].y, v[u].y, A.lr[grp], A.b1, A.b2, A.eps);
+                        if (vis[u][2]) adam_scalar(p[u].z, g[u].z, m[u].z, v[u].z, A.lr[grp], A.b1, A.b2, A.eps);
+                        if (vis[u][3]) adam_scalar(p[u].w, g[u].w, m[u].w, v[u].w, A.lr[grp], A.b1, A.b2, A.eps);
+                        reinterpret_cast<float4*>(A.p[grp] + base)[i] = p[u];
+                        reinterpret_cast<float4*>(A.m[grp] + base)[i] = m[u];
+                        reinterpret_cast<float4*>(A.v[grp] + base)[i] = v[u];
+                    }
+                }
+            } else {
+                for (int i = t; i < rows * width; i += 64)
+                    if (lds_vis[i / width]) adam_scalar(A.p[grp][base + i], rows_lds[i], A.m[grp][base + i], A.v[grp][base + i], A.lr[grp], A.b1, A.b2, A.eps);
+            }
+        };
+        update(1, 3, lds_rows, (size_t)row0 * 3);
+        if (a.M == 15) {
+            update(2, 45, lds_rows + 192, (size_t)row0 * 45);
+        } else if (a.M > 0 && idx < a.P && lds_vis[t]) {
+            for (int k = 0; k < 3 * a.M; k++) {
+                const size_t o = (size_t)3 * a.M * idx + k;
+                adam_scalar(A.p[2][o], k < 45 ? lds_rows[192 + 45 * t + k] : 0.f, A.m[2][o], A.v[2][o], A.lr[2], A.b1, A.b2, A.eps);
+            }
+        }
     }
 }
 
 int launch_sh_grad_from_rgb(const ShGradFromRgbArgs& a, hipStream_t s)
 {
     if (a.P <= 0) return GSLIC_OK;
-    GS_LAUNCH(K_PREPROCESS_BWD, sh_grad_from_rgb_kernel, dim3(div_up(a.P, 64)), dim3(64), 0, s, a);
+    if (a.adam.on) GS_LAUNCH(K_ADAM, sh_grad_from_rgb_kernel<true>, dim3(div_up(a.P, 64)), dim3(64), 0, s, a);
+    else GS_LAUNCH(K_PREPROCESS_BWD, sh_grad_from_rgb_kernel<false>, dim3(div_up(a.P, 64)), dim3(64), 0, s, a);
     return GSLIC_OK;
 }
 

@@ -254,11 +254,16 @@ def exchange_rank1(slab, rgb_local, visible, model, campos):
     w_rgb = dist.all_gather_into_tensor(slab.rgb_all, rgb_local.view(1, slab.P, 3), async_op=True)
     works = [(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True), idx) for seg, idx in (slab.run(model, 0, 1), slab.run(model, 3, 6))]
 
-    class _Rebuild:   # waits for the gathered colour gradients, then rebuilds dL_ddc / dL_dsh of all views into the slab
+    fused = getattr(model, "optimizer", None) is not None and os.environ.get("GSLIC_RANK1_SPLIT_ADAM") != "1"
+
+    class _Rebuild:   # waits for the gathered colour gradients, then rebuilds dL_ddc / dL_dsh of all views
         def wait(self_inner):
             w_cam.wait(); w_rgb.wait()
-            rz.sh_grad_from_rgb(model.xyz.detach(), slab.campos_all, slab.rgb_all, model.sh_degree, slab.views["features_dc"], slab.views["features_rest"])
-    return vis.bool(), [(_Rebuild(), [1, 2])] + works
+            if fused:   # ... and applies the masked Adam to features_dc / features_rest in the same kernel: the rows are never materialised
+                model.optimizer.step_sh_from_rgb(model.xyz.detach(), slab.campos_all, slab.rgb_all, model.sh_degree)
+            else:       # ... into the slab, for a following optimizer.step(only=[1, 2])
+                rz.sh_grad_from_rgb(model.xyz.detach(), slab.campos_all, slab.rgb_all, model.sh_degree, slab.views["features_dc"], slab.views["features_rest"])
+    return vis.bool(), [(_Rebuild(), [] if fused else [1, 2])] + works
 
 
 def allreduce_gradients(grads, visible):

@@ -245,6 +245,13 @@ int gslic_rasterize_backward_rgb(
 int gslic_sh_grad_from_rgb(
     int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D, const float* campos_all /*[n_views,3]*/,
     const float* rgb_all /*[n_views,P,3]*/, int32_t input_is_ddc, float* dL_ddc, float* dL_dsh, void* stream);
+/* The same rebuild with the masked Adam update of features_dc / features_rest (groups 1 and 2 of `adam`; the other groups are ignored)
+ * applied straight from the rebuilt rows: the 192 B/Gaussian of dL_ddc / dL_dsh are neither written nor re-read.  `visible` = the
+ * exchanged (OR-ed) mask, one byte per Gaussian.  dL_ddc / dL_dsh may be NULL (not materialised) or non-NULL (also written).
+ * Bit-identical to gslic_sh_grad_from_rgb followed by gslic_adam_update_groups on the two groups. */
+int gslic_sh_grad_from_rgb_adam(
+    int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D, const float* campos_all, const float* rgb_all,
+    int32_t input_is_ddc, const uint8_t* visible, const gslic_adam_fused* adam, float* dL_ddc, float* dL_dsh, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * gslic_rasterize_backward_camera — gslic_rasterize_backward plus the gradient w.r.t. the CAMERA inputs (the "cam" of the

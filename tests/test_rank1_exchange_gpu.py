@@ -73,3 +73,41 @@ def test_backward_rgb_and_rebuild_equal_the_dense_backward(deg):
     if M:
         s = float(want_sh.abs().max())
         assert float((dsh2 - want_sh).abs().max()) <= 1e-6 * max(s, 1e-30)
+
+
+@pytest.mark.parametrize("deg,P", [(3, 20000), (3, 20037), (0, 5000)])
+def test_rebuild_with_adam_inside_equals_rebuild_then_adam(deg, P):
+    """gslic_sh_grad_from_rgb_adam (rows rebuilt and consumed by the masked Adam in one kernel) against gslic_sh_grad_from_rgb followed by
+    SparseGaussianAdam.step(only=[1, 2]): parameters and both moments bit for bit, over three steps; P = 20037 leaves a partial last block."""
+    from gaussian_lic_amd import rasterizer as rz
+    from gaussian_lic_amd import trainer
+    W, H, n = 320, 240, 2
+    t, views = _views(P, W, H, deg, n)
+    dev = t["xyz"].device
+    raw = {k: v.cpu() for k, v in t.items()}
+    raw["sh_degree"] = deg
+    rgb_all = torch.stack([v["rgb"] for v in views]).contiguous()
+    campos_all = torch.stack([v["cam"].d_camera_center for v in views]).contiguous()
+    vis = (views[0]["radii"] > 0) | (views[1]["radii"] > 0)
+    models = []
+    for fused in (False, True):
+        m = trainer.GaussianModel({k: (v.clone() if torch.is_tensor(v) else v) for k, v in raw.items()}, dev)
+        m.training_setup()
+        for step in range(3):
+            m.optimizer.set_visibility_and_N(vis, P)
+            scale = 1.0 + 0.5 * step        # different gradients every step so that the moments matter
+            if fused:
+                m.optimizer.step_sh_from_rgb(m.xyz.detach(), campos_all, (rgb_all * scale).contiguous(), deg)
+            else:
+                ddc, dsh = torch.empty_like(m.features_dc), torch.empty_like(m.features_rest)
+                rz.sh_grad_from_rgb(m.xyz.detach(), campos_all, (rgb_all * scale).contiguous(), deg, ddc, dsh)
+                m.optimizer.step([None, ddc, dsh, None, None, None], only=[1, 2])
+        models.append(m)
+    a, b = models
+    for i in (1, 2):
+        assert torch.equal(a.optimizer.params[i], b.optimizer.params[i]), i
+        if a.optimizer.params[i].numel():
+            assert torch.equal(a.optimizer.state[i]["exp_avg"], b.optimizer.state[i]["exp_avg"]), i
+            assert torch.equal(a.optimizer.state[i]["exp_avg_sq"], b.optimizer.state[i]["exp_avg_sq"]), i
+    if deg > 0:   # (with an empty sh tensor the SH backward is skipped altogether, like the reference's `if (shs)`, backward.cu:352: zero gradients)
+        assert not torch.equal(a.features_dc, raw["features_dc"].to(dev))     # the update did something
