@@ -18,6 +18,9 @@ X="--no-cpu-baseline --no-extras --steps 100"
   $B --scene lidar --gaussians 500000 $X 2>/dev/null | tail -1               # config 2 at its own size
   $B --gaussians 5000000 --width 3840 --height 2160 $X --steps 30 2>/dev/null | tail -1   # config 5 shape on one GPU
   GSLIC_STRICT_MATH=1 $B $X 2>/dev/null | tail -1                            # strict arithmetic of the blend kernels
+  # the per-rank compute leg of the N > 1 step, in a ONE-rank RCCL group (collectives degenerate to copies): rank-1 exchange (default) and dense slab
+  GSLIC_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29555 RANK=0 WORLD_SIZE=1 $B $X 2>/dev/null | grep "^{" | tail -1
+  GSLIC_EXCHANGE=dense GSLIC_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29557 RANK=0 WORLD_SIZE=1 $B $X 2>/dev/null | grep "^{" | tail -1
 } > $OUT/${TAG}_bench_lines.jsonl
 # per-kernel durations
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG -- python $R/bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-extras > /tmp/prof_$TAG.log 2>&1
