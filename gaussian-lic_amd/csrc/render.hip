@@ -277,169 +277,10 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define GS_SPLAT(x) ((v2f){(x), (x)})
 
 // =========================================================================================================
-// Backward, strict variant (gslic_set_math_mode(1)): ONE WAVE PER BUCKET, the reference's arithmetic operation for operation.
-// The evolving state of a pixel {ar0, ar1, T, ar2} and its tag (rel << 16 | py << 8 | 16 px) move lane -> lane+1 with one DPP
-// each; the injected values enter at lane 0 from LDS under a one-lane exec mask; the per-pixel constants (dL/dpixel) are parked
-// in LDS by pixel index and fetched with one ds_read_b128 when a lane blends.
-#define GS_BWD_SHIFT(sl)                                                                                             \
-    do {                                                                                                             \
-        st.x = shift_zero_f(st.x); st.y = shift_zero_f(st.y); st.z = shift_zero_f(st.z); st.w = shift_zero_f(st.w);  \
-        tag = shift_zero_u(tag);                                                                                     \
-        if (lane == 0) { /* one ds_read_b128 under a one-lane exec mask, straight into the state registers */       \
-            st = *reinterpret_cast<const v4f*>(&init[sl]);                                                           \
-            tag = itags[sl];                                                                                         \
-        }                                                                                                            \
-    } while (0)
-#define GS_BWD_SHIFT_ZERO()                                                                                          \
-    do {                                                                                                             \
-        st.x = shift_zero_f(st.x); st.y = shift_zero_f(st.y); st.z = shift_zero_f(st.z); st.w = shift_zero_f(st.w);  \
-        tag = shift_zero_u(tag);                                                                                     \
-    } while (0)
-// backward.cu:538-581, contraction off, exp() and the IEEE divide of the device library, absolute pixel coordinates: the
-// per-instance sums are the reference's Register_* values up to the order in which a lane meets its pixels.
-#define GS_BWD_BODY_STRICT()                                                                                         \
-    do {                                                                                                             \
-        if (kcmp < tag) { /* lane < n_contrib - bucket start: this Gaussian precedes the pixel's last one (backward.cu:538) */ \
-            _Pragma("clang fp contract(off)")                                                                        \
-            const float pixx = (float)(tx0 + (int)((tag >> 4) & 15u)), pixy = (float)(ty0 + (int)((tag >> 8) & 0xffu)); \
-            const float dx = mabs.x - pixx, dy = mabs.y - pixy;                                                      \
-            const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;                                \
-            const float G = expf(power);                                                                             \
-            const float alpha = fminf(0.99f, op * G);                                                                \
-            if (!(power > 0.0f) && !(alpha < 1.0f / 255.0f)) {                                                       \
-                const float4 gr = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(grec) + (tag & 0xffffu)); \
-                const float T = st.z;                                                                                \
-                const float dchannel_dcolor = alpha * T;                                                             \
-                const float alpha_inverse = 1.0f / (1.0f - alpha);                                                   \
-                float dL_dalpha = 0.0f;                                                                              \
-                st.x += T * alpha * col_rg.x; acc_rg.x += dchannel_dcolor * gr.x;                                    \
-                dL_dalpha += ((col_rg.x * T) - alpha_inverse * (-st.x)) * gr.x;                                      \
-                st.y += T * alpha * col_rg.y; acc_rg.y += dchannel_dcolor * gr.y;                                    \
-                dL_dalpha += ((col_rg.y * T) - alpha_inverse * (-st.y)) * gr.y;                                      \
-                st.w += T * alpha * colb; acc_b += dchannel_dcolor * gr.z;                                           \
-                dL_dalpha += ((colb * T) - alpha_inverse * (-st.w)) * gr.z;                                          \
-                st.z = T * (1.0f - alpha);                                                                           \
-                const float dL_dG = op * dL_dalpha;                                                                  \
-                const float gdx = G * dx, gdy = G * dy;                                                              \
-                const float dG_ddelx = -gdx * cA - gdy * cB;                                                         \
-                const float dG_ddely = -gdy * cC - gdx * cB;                                                         \
-                acc_m.x += dL_dG * dG_ddelx * ddelx_dx;                                                              \
-                acc_m.y += dL_dG * dG_ddely * ddely_dy;                                                              \
-                acc_cxy.x += -0.5f * gdx * dx * dL_dG;                                                               \
-                acc_cxy.y += -0.5f * gdx * dy * dL_dG;                                                               \
-                acc_cw += -0.5f * gdy * dy * dL_dG;                                                                  \
-                acc_op += G * dL_dalpha;                                                                             \
-            }                                                                                                        \
-        }                                                                                                            \
-    } while (0)
-
-__global__ __launch_bounds__(64) void render_bwd_strict_kernel(RenderBwdArgs a)
-{
-    // LDS: the pixel records of the whole tile (dL/dpixel, by pixel index) and the current chunk's start states
-    __shared__ float4 grec[GS_TILE_PIX];
-    __shared__ float4 init[64];
-    __shared__ uint32_t itags[64];
-    const int lane = threadIdx.x;
-    const uint32_t bucket = blockIdx.x;
-    if (a.status[2] != 0u || bucket >= a.bucket_offsets[a.T - 1]) return;  // capacity overflow in the forward / B was a capacity
-    const uint32_t tile = a.bucket_to_tile[bucket];
-    const uint2 range = a.ranges[tile];
-    const uint32_t n = range.y - range.x;
-    const uint32_t bbm = (tile == 0) ? 0u : a.bucket_offsets[tile - 1];
-    const uint32_t bit = bucket - bbm;
-    const uint32_t bstart = bit * GS_BUCKET;
-    const uint32_t kit = bstart + (uint32_t)lane;  // splat index in tile
-    const bool valid = kit < n;
-    const uint32_t slot = valid ? a.inst_slot[range.x + kit] : 0u;
-
-    // bucket entirely behind every pixel's last contributor (backward.cu:428): gradients are exactly zero
-    if (bstart >= a.max_contrib[tile]) {
-        if (valid) {
-            float4* o = a.partials + 3 * (size_t)slot;
-            o[0] = o[1] = o[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        return;
-    }
-
-    const int tx0 = (int)(tile % (uint32_t)a.gx) * GS_TILE, ty0 = (int)(tile / (uint32_t)a.gx) * GS_TILE;
-    float cA = 0, cB = 0, cC = 0, op = 0, colb = 0;
-    v2f col_rg = {0.f, 0.f}, mabs = {0.f, 0.f};
-    if (valid) {
-        const uint32_t g = a.point_list[range.x + kit];
-        const float4* rp = a.rec + GS_REC_F4 * (size_t)g;
-        const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-        mabs.x = r0.x; mabs.y = r0.y;  // absolute coordinates like the reference
-        cA = r0.z; cB = r0.w; cC = r1.x; op = r1.y; col_rg.x = r1.z; col_rg.y = r1.w; colb = r2.x;
-    }
-    const float ddelx_dx = (float)(0.5 * a.W), ddely_dy = (float)(0.5 * a.H);  // backward.cu:464-465
-    // pixel tag = rel << 16 | py << 8 | 16 px, rel = min(n_contrib - bucket start, 64): the low half is the byte offset of the pixel's
-    // float4 in grec[] (row stride 256 B); kcmp < tag  <=>  lane < rel
-    const uint32_t kcmp = ((uint32_t)lane << 16) | 0xffffu;
-    v2f acc_m = {0.f, 0.f}, acc_cxy = {0.f, 0.f}, acc_rg = {0.f, 0.f};
-    float acc_cw = 0, acc_op = 0, acc_b = 0;
-    const size_t plane = (size_t)a.H * a.W;
-
-    v4f st = {0.f, 0.f, 0.f, 0.f};  // {ar0, ar1, T, ar2}
-    uint32_t tag = 0;
-
-    // 64-pixel feed chunk (register double buffer: chunk c+1 is in flight while chunk c streams through)
-    float4 ck, pf;
-    float fg0, fg1, fg2;
-    bool inside;
-    auto load_chunk = [&](int c) {
-        const int pidx = c * 64 + lane;
-        ck = a.ckpt[(size_t)bucket * GS_TILE_PIX + pidx];
-        pf = a.pix_final[(size_t)tile * GS_TILE_PIX + pidx];
-        const int px = tx0 + (pidx & 15), py = ty0 + (pidx >> 4);
-        inside = px < a.W && py < a.H;
-        fg0 = fg1 = fg2 = 0.f;
-        if (inside) {
-            const size_t pid = (size_t)py * a.W + px;
-            fg0 = a.dL_dpix[pid]; fg1 = a.dL_dpix[plane + pid]; fg2 = a.dL_dpix[2 * plane + pid];
-        }
-    };
-    load_chunk(0);
-#pragma unroll 1
-    for (int c = 0; c < 4; c++) {
-        const uint32_t ncp = inside ? __float_as_uint(pf.w) : 0u;
-        const uint32_t pidx = (uint32_t)(c * 64 + lane);
-        const uint32_t rel = ncp > bstart ? (ncp - bstart < 64u ? ncp - bstart : 64u) : 0u;
-        const uint32_t ftag = (rel << 16) | ((pidx >> 4) << 8) | ((pidx & 15u) << 4);
-        grec[c * 64 + lane] = make_float4(fg0, fg1, fg2, 0.f);
-        {
-#pragma clang fp contract(off)
-            init[lane] = make_float4(-pf.x + ck.y, -pf.y + ck.z, ck.x, -pf.z + ck.w);  // ar = -final + sampled (backward.cu:522-523); T
-        }
-        itags[lane] = ftag;
-        uint64_t active = __ballot(ncp > bstart);  // pixels that reach this bucket; the others contribute nothing here
-        if (c < 3) load_chunk(c + 1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        while (active) {
-            const int sl = __builtin_ctzll(active);
-            active &= active - 1;
-            GS_BWD_SHIFT(sl);
-            GS_BWD_BODY_STRICT();
-        }
-        __builtin_amdgcn_wave_barrier();  // init[] is rewritten by the next chunk only after its last read above
-    }
-    // drain: the last injected pixel still has to pass the bucket's remaining (valid) lanes
-    const int nvalid = (n - bstart) < (uint32_t)GS_BUCKET ? (int)(n - bstart) : GS_BUCKET;
-#pragma unroll 1
-    for (int dr = 1; dr < nvalid; dr++) {
-        GS_BWD_SHIFT_ZERO();
-        GS_BWD_BODY_STRICT();
-    }
-    if (valid) {  // every factor was applied term by term, as the reference does
-        float4* o = a.partials + 3 * (size_t)slot;
-        o[0] = make_float4(acc_m.x, acc_m.y, acc_cxy.x, acc_cxy.y);
-        o[1] = make_float4(acc_cw, acc_op, acc_rg.x, acc_rg.y);
-        o[2] = make_float4(acc_b, 0.f, 0.f, 0.f);
-    }
-}
-
-// =========================================================================================================
-// Backward, default (fast) variant: ONE WAVE PER BUCKET, lane = Gaussian, the tile's pixels stream through the lanes.
+// Backward: ONE WAVE PER BUCKET, lane = Gaussian, the tile's pixels stream through the lanes.  STRICT (gslic_set_math_mode(1)) changes only
+// how a pair's alpha is formed — the reference's operations in source order (absolute pixel coordinates, power as backward.cu:541,
+// expf, opacity * G, IEEE divide for 1 / (1 - alpha), contraction off), so every blend / skip decision is the strict forward's and the
+// reference's — the pipeline around it is the same; the text below describes the default (fast) arithmetic.
 //
 // What travels lane -> lane+1 is {T, A}: A = sum_ch ar[ch] * dL/dpixel[ch] replaces the colour vector ar[3] of the reference's
 // formulation (dL/dalpha only ever needs that dot product: dL/dalpha = A' / (1 - alpha) + T (c . g), A' = A + T alpha (c . g)): two
@@ -464,6 +305,15 @@ __global__ __launch_bounds__(64) void render_bwd_strict_kernel(RenderBwdArgs a)
 // Before the first pixel reaches lane L (s < L) the lane reads whatever lies s - L records before the array — the start states, placed
 // there on purpose: finite numbers — while its travelling state is still T = A = 0, which makes every product of the step an exact zero
 // whatever the record says; behind the last pixel come 64 zero records.
+// STRICT: delta, power and opacity * G of one (pixel, Gaussian) pair as backward.cu:539-542 / forward.cu:424-432 form them.
+__device__ __forceinline__ void strict_pair(v2f mean, v2f pix, v2f cAC, float cB, float op, v2f& d, float& power, float& araw)
+{
+#pragma clang fp contract(off)
+    d.x = mean.x - pix.x; d.y = mean.y - pix.y;
+    power = -0.5f * (cAC.x * d.x * d.x + cAC.y * d.y * d.y) - cB * d.x * d.y;
+    araw = op * expf(power);
+}
+
 struct BwdLane {
     v2f d0, hAC, col_rg;          // centre relative to the tile origin; log2(e)-scaled conic diagonal {-1/2 A, -1/2 C}; colour r, g
     float nB, lop, colb;          // log2(e)-scaled -B; log2(opacity); colour b
@@ -491,17 +341,27 @@ struct BwdLane {
         const float4 gr = GR;                                                                                        \
         const uint32_t TAG = __float_as_uint(gr.w);                                                                  \
         const v2f pxy16 = {(float)(TAG & 0xffu), (float)((TAG >> 8) & 0xffu)}; /* v_cvt_f32_ubyte0 / ubyte1: {16 px, py} */ \
-        const v2f d = GS_PK_FMA(pxy16, kneg, L.d0); /* exact: d0 - {px, py} */                                       \
-        float p2 = __builtin_fmaf(L.hAC.x * d.x, d.x, L.lop); /* the operation sequence of render_fwd */             \
-        p2 = __builtin_fmaf(L.hAC.y * d.y, d.y, p2);                                                                 \
-        p2 = __builtin_fmaf(L.nB * d.x, d.y, p2); /* = log2(e) * power + log2(opacity) */                            \
-        const float araw = __builtin_amdgcn_exp2f(p2); /* opacity * G */                                             \
-        /* lane < n_contrib - bucket start (backward.cu:538), power <= 0, alpha >= 1/255 (:543-546; min(0.99, a) < 1/255 iff a < 1/255) */ \
-        const bool hit = (kcmp < TAG) & !(p2 > L.lop) & !(araw < c255);                                              \
+        v2f d;                                                                                                       \
+        float araw;                                                                                                  \
+        bool hit;                                                                                                    \
+        if constexpr (STRICT) {                                                                                      \
+            const v2f pix = GS_PK_FMA(pxy16, kneg, torg); /* exact: tile origin + {px, py} (kneg = {1/16, 1} here) */ \
+            float power;                                                                                             \
+            strict_pair(L.d0, pix, L.hAC, L.nB, L.lop, d, power, araw);                                              \
+            hit = (kcmp < TAG) & !(power > 0.0f) & !(araw < c255);                                                   \
+        } else {                                                                                                     \
+            d = GS_PK_FMA(pxy16, kneg, L.d0); /* exact: d0 - {px, py} */                                             \
+            float p2 = __builtin_fmaf(L.hAC.x * d.x, d.x, L.lop); /* the operation sequence of render_fwd */         \
+            p2 = __builtin_fmaf(L.hAC.y * d.y, d.y, p2);                                                             \
+            p2 = __builtin_fmaf(L.nB * d.x, d.y, p2); /* = log2(e) * power + log2(opacity) */                        \
+            araw = __builtin_amdgcn_exp2f(p2); /* opacity * G */                                                     \
+            /* lane < n_contrib - bucket start (backward.cu:538), power <= 0, alpha >= 1/255 (:543-546; min(0.99, a) < 1/255 iff a < 1/255) */ \
+            hit = (kcmp < TAG) & !(p2 > L.lop) & !(araw < c255);                                                     \
+        }                                                                                                            \
         const float ah = hit ? araw : 0.0f; /* one select masks both alpha and the gradient weight */                \
         const float alpha = __builtin_amdgcn_fmed3f(ah, ninf, c099); /* min(0.99, .) without the canonicalising v_max fminf costs */ \
         const float om = 1.0f - alpha;                                                                               \
-        const float rinv = __builtin_amdgcn_rcpf(om);                                                                \
+        const float rinv = STRICT ? 1.0f / om : __builtin_amdgcn_rcpf(om);                                           \
         const float Ta = T_ * alpha;                                                                                 \
         float cg = L.col_rg.x * gr.x;                                                                                \
         cg = __builtin_fmaf(L.col_rg.y, gr.y, cg);                                                                   \
@@ -518,6 +378,7 @@ struct BwdLane {
         acc_op += w; /* divided by the opacity at the end */                                                         \
     } while (0)
 
+template <bool STRICT>
 __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
 {
     // [start states {T, A} of the pixels that reach this bucket, in injection order, + 64 empty entries][their records {dL/dpixel, tag}, same
@@ -571,15 +432,22 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     BwdLane L;
     L.d0 = L.hAC = L.col_rg = (v2f){0.f, 0.f};
     L.nB = L.colb = 0.f;
-    L.lop = -__builtin_inff();  // a lane without a Gaussian: alpha = exp2(-inf) = 0, never blends
+    L.lop = STRICT ? 0.f : -__builtin_inff();  // a lane without a Gaussian: alpha = exp2(-inf) = 0 (STRICT: opacity 0), never blends
     float rop = 0.f;            // 1 / opacity
     if (valid) {
         const uint32_t g = a.point_list[range.x + kit];
         const float4* rp = a.rec + GS_REC_F4 * (size_t)g;
         const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-        L.d0.x = r0.x - (float)tx0; L.d0.y = r0.y - (float)ty0;
-        L.hAC.x = -0.5f * LOG2E * r0.z; L.nB = -LOG2E * r0.w; L.hAC.y = -0.5f * LOG2E * r1.x;
-        rop = r1.y > 0.f ? 1.0f / r1.y : 0.f; L.lop = __builtin_amdgcn_logf(r1.y);
+        if constexpr (STRICT) {   // absolute mean, the conic and the opacity as stored
+            L.d0.x = r0.x; L.d0.y = r0.y;
+            L.hAC.x = r0.z; L.nB = r0.w; L.hAC.y = r1.x;
+            L.lop = r1.y;
+        } else {
+            L.d0.x = r0.x - (float)tx0; L.d0.y = r0.y - (float)ty0;
+            L.hAC.x = -0.5f * LOG2E * r0.z; L.nB = -LOG2E * r0.w; L.hAC.y = -0.5f * LOG2E * r1.x;
+            L.lop = __builtin_amdgcn_logf(r1.y);
+        }
+        rop = r1.y > 0.f ? 1.0f / r1.y : 0.f;
         L.col_rg.x = r1.z; L.col_rg.y = r1.w; L.colb = r2.x;
     }
 
@@ -644,9 +512,10 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
 
     // loop constants in VGPRs: a literal or SGPR operand doubles the issue cost of the instruction that reads it
     float c099 = 0.99f, c255 = 1.0f / 255.0f, ninf = -__builtin_inff();
-    v2f kneg = {-0.0625f, -1.0f};
+    v2f kneg = STRICT ? (v2f){0.0625f, 1.0f} : (v2f){-0.0625f, -1.0f};
+    v2f torg = {(float)tx0, (float)ty0};   // (STRICT: absolute pixel coordinates = tile origin + in-tile offset)
     uint32_t kcmp = ((uint32_t)lane << 16) | 0xffffu;
-    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(ninf), "+v"(kneg), "+v"(kcmp));
+    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(ninf), "+v"(kneg), "+v"(kcmp), "+v"(torg));
     v2f acc_S = {0.f, 0.f}, acc_cxy = {0.f, 0.f}, acc_rg = {0.f, 0.f};
     float acc_cw = 0, acc_op = 0, acc_b = 0;
     // {T, A}: the state travelling through the lanes (set 1) and the injection fetched one step ahead (set 2); a step shifts set 1
@@ -672,9 +541,15 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     if (valid) {
         // acc_S = sum of w d (w = G dL/dG): dL/dmean2D = -(0.5 W, 0.5 H) o (A S.x + B S.y, C S.y + B S.x) (backward.cu:566-573), written on the
         // log2(e)-scaled conic the lane holds: A = -2 hA / log2 e, B = -nB / log2 e
-        const float kx = 0.5f * (float)a.W / LOG2E, ky = 0.5f * (float)a.H / LOG2E;
-        const float gx = __builtin_fmaf(2.0f * L.hAC.x, acc_S.x, L.nB * acc_S.y) * kx;
-        const float gy = __builtin_fmaf(2.0f * L.hAC.y, acc_S.y, L.nB * acc_S.x) * ky;
+        float gx, gy;
+        if constexpr (STRICT) {   // the lane holds A, B, C themselves
+            gx = -(L.hAC.x * acc_S.x + L.nB * acc_S.y) * (0.5f * (float)a.W);
+            gy = -(L.hAC.y * acc_S.y + L.nB * acc_S.x) * (0.5f * (float)a.H);
+        } else {
+            const float kx = 0.5f * (float)a.W / LOG2E, ky = 0.5f * (float)a.H / LOG2E;
+            gx = __builtin_fmaf(2.0f * L.hAC.x, acc_S.x, L.nB * acc_S.y) * kx;
+            gy = __builtin_fmaf(2.0f * L.hAC.y, acc_S.y, L.nB * acc_S.x) * ky;
+        }
         float4* o = a.partials + 3 * (size_t)slot;
         o[0] = make_float4(gx, gy, -0.5f * acc_cxy.x, -0.5f * acc_cxy.y);
         o[1] = make_float4(-0.5f * acc_cw, acc_op * rop, acc_rg.x, acc_rg.y);  // acc_op = sum of opacity * G * dL/dalpha (backward.cu:580 sums G * dL/dalpha)
@@ -686,7 +561,8 @@ int launch_render_fwd(const RenderFwdArgs& a, hipStream_t s)
 {
     static const int split = [] { const char* e = getenv("GSLIC_FWD_SPLIT"); const int v = e ? atoi(e) : 2; return (v == 1 || v == 4) ? v : 2; }();
     const unsigned T = (unsigned)(a.gx * a.gy);
-    if (g_strict_math) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 1>), dim3(T), dim3(64), 0, s, a);
+    if (g_strict_math && split == 1) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 1>), dim3(T), dim3(64), 0, s, a);
+    else if (g_strict_math) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 2>), dim3(T, 2), dim3(64), 0, s, a);   // per-pixel arithmetic does not depend on the split
     else if (split == 1) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<false, 1>), dim3(T), dim3(64), 0, s, a);
     else if (split == 4) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<false, 4>), dim3(T, 4), dim3(64), 0, s, a);
     else GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<false, 2>), dim3(T, 2), dim3(64), 0, s, a);
@@ -695,12 +571,9 @@ int launch_render_fwd(const RenderFwdArgs& a, hipStream_t s)
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s)
 {
     if (a.B <= 0) return GSLIC_OK;
-    if (g_strict_math) {
-        GS_LAUNCH(K_RENDER_BWD, render_bwd_strict_kernel, dim3(a.B), dim3(64), 0, s, a);
-        return GSLIC_OK;
-    }
     static const int lds_pad = [] { const char* e = getenv("GSLIC_BWD_LDS_PAD"); return e ? atoi(e) : 0; }();  // occupancy experiments only
-    GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel, dim3(a.B), dim3(64), (size_t)lds_pad, s, a);
+    if (g_strict_math) GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel<true>, dim3(a.B), dim3(64), (size_t)lds_pad, s, a);
+    else GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel<false>, dim3(a.B), dim3(64), (size_t)lds_pad, s, a);
     return GSLIC_OK;
 }
 

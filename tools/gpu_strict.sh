@@ -1,0 +1,12 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_fullsize_reference_gpu.py tests/test_vs_reference_kernels_gpu.py tests/test_parity_gpu.py -m gpu -x -q 2>&1 | tail -n 4
+for sp in 1 2; do
+GSLIC_FWD_SPLIT=$sp GSLIC_STRICT_MATH=1 timeout 300 python bench.py --steps 100 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); k = d['kernel_ms_per_step']; print('strict split $sp', d['value'], 'views/s', d['ms_per_step'], 'ms', {n: k[n] for n in ('render_bwd', 'preprocess_bwd', 'render_fwd', 'preprocess')})
+"
+done
