@@ -222,6 +222,32 @@ __device__ __forceinline__ uint32_t block256_exclusive_prefix(uint32_t thread_su
 }
 __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+// Streaming accesses: data that is read once or written once per launch (Adam moments, per-instance partial gradients) goes past the
+// L2's retention — measured on this part (tools/ubench/hbm_rate): copy 4.9 -> 5.7 TB/s, Adam-shaped read-modify-write 5.98 -> 6.29.
+// GSLIC_NT = 0 at compile time turns them back into plain accesses (A/B runs).
+#ifndef GSLIC_NT
+#define GSLIC_NT 1
+#endif
+typedef float gs_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float4* p)
+{
+#if GSLIC_NT
+    const gs_v4f v = __builtin_nontemporal_load(reinterpret_cast<const gs_v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream(float4* p, const float4 v)
+{
+#if GSLIC_NT
+    const gs_v4f t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<gs_v4f*>(p));
+#else
+    *p = v;
+#endif
+}
+
 // The Adam update of adam.cu:26-37, one definition for every kernel that applies it (adam.hip and the fused backward):
 // contraction is pinned off so that the two call sites round identically (their results are compared bit for bit).
 __device__ __forceinline__ void adam_scalar(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps)

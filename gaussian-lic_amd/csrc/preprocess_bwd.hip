@@ -92,8 +92,8 @@ __device__ __forceinline__ void small_groups_sink(const AdamFusedArgs& A, float*
             if (on[k]) {
                 const size_t base = (size_t)row0 * wid[k];
                 p[k] = reinterpret_cast<const float4*>(A.p[gid[k]] + base)[t];
-                m[k] = reinterpret_cast<const float4*>(A.m[gid[k]] + base)[t];
-                v[k] = reinterpret_cast<const float4*>(A.v[gid[k]] + base)[t];
+                m[k] = ld_stream(reinterpret_cast<const float4*>(A.m[gid[k]] + base) + t);
+                v[k] = ld_stream(reinterpret_cast<const float4*>(A.v[gid[k]] + base) + t);
             }
         }
 #pragma unroll
@@ -105,9 +105,9 @@ __device__ __forceinline__ void small_groups_sink(const AdamFusedArgs& A, float*
             if (vis[k][2]) adam_scalar(p[k].z, g[k].z, m[k].z, v[k].z, lr, A.b1, A.b2, A.eps);
             if (vis[k][3]) adam_scalar(p[k].w, g[k].w, m[k].w, v[k].w, lr, A.b1, A.b2, A.eps);
             const size_t base = (size_t)row0 * wid[k];
-            reinterpret_cast<float4*>(A.p[gid[k]] + base)[t] = p[k];
-            reinterpret_cast<float4*>(A.m[gid[k]] + base)[t] = m[k];
-            reinterpret_cast<float4*>(A.v[gid[k]] + base)[t] = v[k];
+            st_stream(reinterpret_cast<float4*>(A.p[gid[k]] + base) + t, p[k]);
+            st_stream(reinterpret_cast<float4*>(A.m[gid[k]] + base) + t, m[k]);
+            st_stream(reinterpret_cast<float4*>(A.v[gid[k]] + base) + t, v[k]);
         }
     } else {
 #pragma unroll
@@ -252,9 +252,9 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
                         }
                     }
                     if (any[u]) {
-                        p[u] = reinterpret_cast<float4*>(A.p[2] + base)[i];
-                        m[u] = reinterpret_cast<float4*>(A.m[2] + base)[i];
-                        v[u] = reinterpret_cast<float4*>(A.v[2] + base)[i];
+                        p[u] = reinterpret_cast<float4*>(A.p[2] + base)[i];   // (read a moment ago as the SH row: an L2 hit)
+                        m[u] = ld_stream(reinterpret_cast<const float4*>(A.m[2] + base) + i);
+                        v[u] = ld_stream(reinterpret_cast<const float4*>(A.v[2] + base) + i);
                     }
                 }
 #pragma unroll
@@ -265,9 +265,9 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
                     if (vis[u][1]) adam_scalar(p[u].y, g[u].y, m[u].y, v[u].y, A.lr[2], A.b1, A.b2, A.eps);
                     if (vis[u][2]) adam_scalar(p[u].z, g[u].z, m[u].z, v[u].z, A.lr[2], A.b1, A.b2, A.eps);
                     if (vis[u][3]) adam_scalar(p[u].w, g[u].w, m[u].w, v[u].w, A.lr[2], A.b1, A.b2, A.eps);
-                    reinterpret_cast<float4*>(A.p[2] + base)[i] = p[u];
-                    reinterpret_cast<float4*>(A.m[2] + base)[i] = m[u];
-                    reinterpret_cast<float4*>(A.v[2] + base)[i] = v[u];
+                    st_stream(reinterpret_cast<float4*>(A.p[2] + base) + i, p[u]);
+                    st_stream(reinterpret_cast<float4*>(A.m[2] + base) + i, m[u]);
+                    st_stream(reinterpret_cast<float4*>(A.v[2] + base) + i, v[u]);
                 }
             }
         } else {
@@ -752,9 +752,9 @@ __global__ __launch_bounds__(64) void sh_grad_from_rgb_kernel(ShGradFromRgbArgs 
                             any[u] = vis[u][0] | vis[u][1] | vis[u][2] | vis[u][3];
                         }
                         if (any[u]) {
-                            p[u] = reinterpret_cast<float4*>(A.p[grp] + base)[i];
-                            m[u] = reinterpret_cast<float4*>(A.m[grp] + base)[i];
-                            v[u] = reinterpret_cast<float4*>(A.v[grp] + base)[i];
+                            p[u] = ld_stream(reinterpret_cast<const float4*>(A.p[grp] + base) + i);
+                            m[u] = ld_stream(reinterpret_cast<const float4*>(A.m[grp] + base) + i);
+                            v[u] = ld_stream(reinterpret_cast<const float4*>(A.v[grp] + base) + i);
                         }
                     }
 #pragma unroll
@@ -765,9 +765,9 @@ __global__ __launch_bounds__(64) void sh_grad_from_rgb_kernel(ShGradFromRgbArgs 
                         if (vis[u][1]) adam_scalar(p[u].y, g[u].y, m[u].y, v[u].y, A.lr[grp], A.b1, A.b2, A.eps);
                         if (vis[u][2]) adam_scalar(p[u].z, g[u].z, m[u].z, v[u].z, A.lr[grp], A.b1, A.b2, A.eps);
                         if (vis[u][3]) adam_scalar(p[u].w, g[u].w, m[u].w, v[u].w, A.lr[grp], A.b1, A.b2, A.eps);
-                        reinterpret_cast<float4*>(A.p[grp] + base)[i] = p[u];
-                        reinterpret_cast<float4*>(A.m[grp] + base)[i] = m[u];
-                        reinterpret_cast<float4*>(A.v[grp] + base)[i] = v[u];
+                        st_stream(reinterpret_cast<float4*>(A.p[grp] + base) + i, p[u]);
+                        st_stream(reinterpret_cast<float4*>(A.m[grp] + base) + i, m[u]);
+                        st_stream(reinterpret_cast<float4*>(A.v[grp] + base) + i, v[u]);
                     }
                 }
             } else {

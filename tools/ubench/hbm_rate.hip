@@ -20,6 +20,23 @@ __global__ __launch_bounds__(256) void k_rmw3(float4* __restrict__ p, float4* __
         p[i] = P; m[i] = M; v[i] = V;
     }
 }
+// the same two kernels with non-temporal stores (and loads): does bypassing the L2's retention help a pure stream on this part?
+typedef float v4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy_nt(const v4* __restrict__ a, v4* __restrict__ b, size_t n)
+{
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) __builtin_nontemporal_store(__builtin_nontemporal_load(a + i), b + i);
+}
+__global__ __launch_bounds__(256) void k_rmw3_nt(v4* __restrict__ p, v4* __restrict__ m, v4* __restrict__ v, const v4* __restrict__ g, size_t n)
+{
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        v4 P = __builtin_nontemporal_load(p + i), M = __builtin_nontemporal_load(m + i), V = __builtin_nontemporal_load(v + i);
+        const v4 G = __builtin_nontemporal_load(g + i);
+        M = 0.9f * M + 0.1f * G;
+        V = 0.999f * V + 0.001f * G * G;
+        P.x -= 1e-3f * M.x / (sqrtf(V.x) + 1e-15f); P.y -= 1e-3f * M.y / (sqrtf(V.y) + 1e-15f); P.z -= 1e-3f * M.z / (sqrtf(V.z) + 1e-15f); P.w -= 1e-3f * M.w / (sqrtf(V.w) + 1e-15f);
+        __builtin_nontemporal_store(P, p + i); __builtin_nontemporal_store(M, m + i); __builtin_nontemporal_store(V, v + i);
+    }
+}
 __global__ __launch_bounds__(256) void k_read(const float4* __restrict__ a, float* out, size_t n)
 {
     float s = 0;
@@ -41,6 +58,10 @@ int main()
         CK(hipEventElapsedTime(&ms, e0, e1)); printf("grid %6d  copy  %.3f ms  %.2f TB/s\n", grid, ms, 2.0 * n * 16 / ms * 1e-9);
         for (int rep = 0; rep < 2; rep++) { CK(hipEventRecord(e0)); hipLaunchKernelGGL(k_rmw3, dim3(grid), dim3(256), 0, 0, a, b, c, d, n); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); }
         CK(hipEventElapsedTime(&ms, e0, e1)); printf("grid %6d  rmw3  %.3f ms  %.2f TB/s\n", grid, ms, 7.0 * n * 16 / ms * 1e-9);
+        for (int rep = 0; rep < 2; rep++) { CK(hipEventRecord(e0)); hipLaunchKernelGGL(k_copy_nt, dim3(grid), dim3(256), 0, 0, (const v4*)a, (v4*)b, n); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); }
+        CK(hipEventElapsedTime(&ms, e0, e1)); printf("grid %6d  copy, non-temporal  %.3f ms  %.2f TB/s\n", grid, ms, 2.0 * n * 16 / ms * 1e-9);
+        for (int rep = 0; rep < 2; rep++) { CK(hipEventRecord(e0)); hipLaunchKernelGGL(k_rmw3_nt, dim3(grid), dim3(256), 0, 0, (v4*)a, (v4*)b, (v4*)c, (const v4*)d, n); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); }
+        CK(hipEventElapsedTime(&ms, e0, e1)); printf("grid %6d  rmw3, non-temporal  %.3f ms  %.2f TB/s\n", grid, ms, 7.0 * n * 16 / ms * 1e-9);
         for (int rep = 0; rep < 2; rep++) { CK(hipEventRecord(e0)); hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, a, o, n); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); }
         CK(hipEventElapsedTime(&ms, e0, e1)); printf("grid %6d  read  %.3f ms  %.2f TB/s\n", grid, ms, 1.0 * n * 16 / ms * 1e-9);
     }
