@@ -54,7 +54,7 @@ __global__ __launch_bounds__(BS) void preprocess_kernel(PreprocessArgs a)
 #pragma unroll
             for (int k = 0; k < SH_REGS; k++) {
                 const int i = threadIdx.x + k * BS;
-                if (i < BS * 45 / 4) sh_pre[k] = s4[i];
+                if (i < BS * 45 / 4) sh_pre[k] = __builtin_nontemporal_load(s4 + i);   // 360 MB read once per forward: past the L2's retention
             }
         } else {
             for (int i = threadIdx.x; i < rows * 45; i += BS) lds_sh[i] = src[i];
