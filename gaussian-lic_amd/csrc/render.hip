@@ -257,20 +257,6 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
     }
 }
 
-// Whole-wave shift by one lane: lane l >= 1 receives v[l-1], lane 0 receives 0 (bound_ctrl), so source and destination may be the same
-// register (v_mov_b32 v, v wave_shr:1): one VALU op per value, no copies.
-__device__ __forceinline__ float shift_zero_f(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
-}
-__device__ __forceinline__ uint32_t shift_zero_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
-// the same shift with lane 0 receiving `old` (bound_ctrl off: a lane without a source lane keeps the destination's previous value)
-__device__ __forceinline__ float shift_old_f(float old, float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x138, 0xf, 0xf, false));
-}
-__device__ __forceinline__ int32_t shift_old_i(int32_t old, int32_t v) { return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false); }
-
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 #define GS_PK_FMA(a, b, c) __builtin_elementwise_fma((a), (b), (c))
