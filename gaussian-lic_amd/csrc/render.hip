@@ -1,24 +1,20 @@
 // render.hip — the two alpha-blend kernels, designed for 64-lane waves.
 //
-// render_fwd_kernel  replaces renderCUDA<3> (forward.cu:321-481)
-//   ONE WAVE PER 16x16 TILE, four pixels per lane (lane l owns pixels l, l+64, l+128, l+192 of the tile in
-//   thread_rank order, i.e. column l&15, rows (l>>4)+{0,4,8,12}).  The wave fetches 64 list entries at a time
-//   (one 48-byte record per lane, three dwordx4 loads), pre-scales them, parks them in LDS and fetches entry j with three
-//   ds_read_b128 at a wave-uniform address (LDS broadcast, next entry prefetched): the kernel is VALU-issue bound and LDS reads cost
-//   no issue slot, ten v_readlane per entry did.  A 4-bit mask per entry says which 16x4 pixel strips it can reach at all; a
-//   checkpoint {T, C} per pixel is stored at every 64th entry (bucket = one wave of entries) as one coalesced 1-KiB dwordx4
-//   store per quarter.  One wave per workgroup: no barrier anywhere.
+// render_fwd_kernel<STRICT, SPLIT>  replaces renderCUDA<3> (forward.cu:321-481)
+//   SPLIT WAVES PER 16x16 TILE (default 2), each blending 4 / SPLIT of the tile's four 16x4-row pixel strips per lane (lane l owns
+//   column l&15, rows (l>>4) + 4q).  A wave fetches 64 list entries at a time (one 48-byte record per lane, three dwordx4 loads),
+//   pre-scales them, parks them in LDS and fetches entry j with three ds_read_b128 at a wave-uniform address (LDS broadcast, next
+//   entry prefetched): the kernel is VALU-issue bound and LDS reads cost no issue slot.  A 4-bit mask per entry says which strips
+//   it can reach at all; a checkpoint {T, C} per pixel is stored at every 64th entry (bucket = one wave of entries) as one coalesced
+//   1-KiB dwordx4 store per strip.  One wave per workgroup: no barrier anywhere.
 //
-// render_bwd_kernel  replaces PerGaussianRenderCUDA<3> (backward.cu:379-597)
+// render_bwd_kernel<STRICT>  replaces PerGaussianRenderCUDA<3> (backward.cu:379-597)
 //   ONE WAVE PER BUCKET of 64 list entries: lane = Gaussian, the tile's pixels stream through the lanes as a 64-deep systolic
-//   pipeline; the evolving per-pixel state {ar0, ar1, T, ar2} and the pixel's tag move lane -> lane+1 with one in-place
-//   v_mov_b32 DPP wave_shr:1 per value (no ds_bpermute, no copies); lane 0 is then re-loaded with the next pixel by one
-//   ds_read_b128 + ds_read_b32 under a one-lane exec mask.  The per-pixel constants (dL/dpixel) are parked in LDS once per tile
-//   and fetched with one ds_read_b96 when a lane actually blends.  Only pixels whose n_contrib reaches this bucket are injected
-//   (a 64-bit ballot per 64-pixel chunk, walked with s_ff1): pixels that terminated earlier cost no pipeline step at all.  Each
-//   lane accumulates its Gaussian's nine 2D gradients in registers and writes them ONCE to its emission slot (plain 48-byte
-//   store): no atomics — the sum over a Gaussian's tiles is a contiguous segmented reduction in preprocess_bwd_kernel,
-//   deterministic run to run.
+//   pipeline.  Two values per pixel, {T, A = ar . dL/dpixel}, move lane -> lane+1 with one v_mov_b32 DPP wave_shr:1 each; the
+//   schedule is static, so every lane fetches the record {dL/dpixel, tag} of the pixel it holds from LDS at a per-lane address one
+//   step ahead.  Only pixels whose n_contrib reaches this bucket are injected, deepest first.  Each lane accumulates its Gaussian's
+//   nine 2D gradients in registers and writes them ONCE to its emission slot (plain 48-byte store): no atomics — the sum over a
+//   Gaussian's tiles is a contiguous segmented reduction in preprocess_bwd_kernel, deterministic run to run.  (Details above the kernel.)
 #include "gslic_common.h"
 #include "kernels.h"
 #include <stdlib.h>
