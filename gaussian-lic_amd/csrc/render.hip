@@ -541,8 +541,11 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
 
 int launch_render_fwd(const RenderFwdArgs& a, hipStream_t s)
 {
-    static const int split = [] { const char* e = getenv("GSLIC_FWD_SPLIT"); const int v = e ? atoi(e) : 2; return (v == 1 || v == 4) ? v : 2; }();
+    // waves per tile: two halve the serial chain of a tile's wave, at the price of both fetching the tile's records — worth it while the
+    // tiles alone do not fill the machine (1080p: 8160 tiles, 0.33 -> 0.30 ms), not at 4K (32 400 tiles: 0.92 vs 1.00 ms).  GSLIC_FWD_SPLIT pins it.
+    static const int forced = [] { const char* e = getenv("GSLIC_FWD_SPLIT"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
     const unsigned T = (unsigned)(a.gx * a.gy);
+    const int split = forced ? forced : (T <= 16384u ? 2 : 1);
     if (g_strict_math && split == 1) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 1>), dim3(T), dim3(64), 0, s, a);
     else if (g_strict_math) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 2>), dim3(T, 2), dim3(64), 0, s, a);   // per-pixel arithmetic does not depend on the split
     else if (split == 1) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<false, 1>), dim3(T), dim3(64), 0, s, a);
