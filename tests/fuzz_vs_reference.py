@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Ad-hoc fuzz (not collected by pytest): random small scenes, HIP path vs the reference's own kernels, strict and fast arithmetic.
+    python tests/fuzz_vs_reference.py [n_cases] [seed0]
+Prints one line per case and a summary; exits non-zero when a strict run is not bit-identical (image / final_T / n_contrib / lists)
+or a gradient element is beyond 1e-4.  Test infrastructure (uses oracle/_ref); needs the MI355X."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
+import numpy as np
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    from refcompare import GRADS, compare
+    rng = np.random.default_rng(seed0)
+    bad = 0
+    worst_fast = 0.0
+    for i in range(n):
+        kind = "random" if rng.random() < 0.7 else "lidar"
+        P = 256 * int(rng.choice([1, 2, 7, 40, 100, 300]))
+        W = int(rng.choice([33, 64, 100, 160, 320, 333, 640]))
+        H = int(rng.choice([17, 48, 90, 97, 180, 360]))
+        deg = int(rng.integers(0, 4))
+        seed = int(rng.integers(0, 10 ** 6))
+        res = compare(kind, P, W, H, deg, seed)
+        st, fa = res["strict"], res["fast"]
+        ok = (st["radii_mismatch"] == 0 and st["tiles_touched_mismatch"] == 0 and st["point_list_equal"] and st["color"]["bit_equal"]
+              and st["final_T"]["bit_equal"] and st["n_contrib_mismatch"] == 0 and all(st[k]["over"] == 0 for k in GRADS))
+        fast_over = sum(fa[k]["over"] for k in GRADS) + fa["color"]["over"]
+        fmax = max([fa[k]["max_rel"] for k in GRADS] + [fa["color"]["max_rel"]])
+        worst_fast = max(worst_fast, fmax)
+        print(f"{i:3d} {kind:6s} P={P:6d} {W}x{H} deg{deg} seed={seed}: R={res['ref']['R']} strict {'OK' if ok else 'MISMATCH'} "
+              f"(max grad err {max(st[k]['max_rel'] for k in GRADS):.1e}); fast: {fast_over} elements over 1e-4, max {fmax:.1e}", flush=True)
+        bad += 0 if ok else 1
+    print(f"{n} cases, {bad} strict mismatches, worst fast-mode error {worst_fast:.2e}")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
