@@ -4,6 +4,8 @@
 // reads  <dir>/{xyz,scaling,rotation,opacity,dc,rest,view,proj,campos,gt}.f32 and scalars.f32 (tanfovx, tanfovy, 4 lims),
 // writes <dir>/out_{image,xyz,scaling,rotation,opacity,dc,rest}.f32 after <iters> steps; with timed_iters > 0 it then times that many
 // further steps (wall clock between two device synchronisations) and prints "views_per_s <v> ms_per_step <t>".
+// When <dir>/frame_pts.f32 exists (+ frame_col.f32 [n,3], frame_rsp.f32 [n], frame_pose.f32 = R_cw[9] | t_cw[3] | fx fy cx cy, frame_n.f32 = n),
+// one extend() with that LiDAR frame follows the <iters> steps, then <iters> more steps, and "extend inserted <k>" is printed.
 // Needs no reference source: LibTorch + libgslic_hip.so only.
 #include "gslic_fused.h"
 
@@ -54,6 +56,23 @@ int main(int argc, char** argv)
     for (int it = 0; it < iters; it++) {
         torch::Tensor terms = fs.step(cam, gt);
         std::cout << "iter " << it << " loss " << fs.loss_value(terms) << " visible " << fs.visible().sum().item<int>() << std::endl;
+    }
+    {
+        std::ifstream probe(d + "/frame_n.f32", std::ios::binary);
+        if (probe.good()) {
+            const int64_t n = (int64_t)load(d + "/frame_n.f32", {1}).item<float>();
+            torch::Tensor pts = load(d + "/frame_pts.f32", {n, 3}), col = load(d + "/frame_col.f32", {n, 3}), rsp = load(d + "/frame_rsp.f32", {n});
+            torch::Tensor pose = load(d + "/frame_pose.f32", {16}).to(torch::kCPU);
+            const float* q = pose.data_ptr<float>();
+            torch::Tensor Rcw = pose.narrow(0, 0, 9).reshape({3, 3}).clone(), tcw = pose.narrow(0, 9, 3).clone();
+            const int64_t k = fs.extend(cam, pts, col, rsp, Rcw, tcw, q[12], q[13], q[14], q[15]);
+            std::cout << "extend inserted " << k << " size " << fs.size() << " capacity " << fs.capacity() << std::endl;
+            for (int it = 0; it < iters; it++) {
+                torch::Tensor terms = fs.step(cam, gt);
+                std::cout << "iter " << (iters + it) << " loss " << fs.loss_value(terms) << " visible " << fs.visible().sum().item<int>() << std::endl;
+            }
+            xyz = fs.param(0); dc = fs.param(1); rest = fs.param(2); opacity = fs.param(3); scaling = fs.param(4); rotation = fs.param(5);
+        }
     }
     save(d + "/out_image.f32", fs.image());
     save(d + "/out_xyz.f32", xyz); save(d + "/out_scaling.f32", scaling); save(d + "/out_rotation.f32", rotation);

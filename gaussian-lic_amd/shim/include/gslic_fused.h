@@ -17,6 +17,7 @@
 #pragma once
 #include <torch/torch.h>
 
+#include <algorithm>
 #include <array>
 #include <vector>
 
@@ -63,6 +64,61 @@ public:
         prm_ = std::move(params); m_ = std::move(exp_avg); v_ = std::move(exp_avg_sq);
     }
     void set_lr(int group, float lr) { lrs_[group] = lr; }
+
+    // extend() of gaussian.cpp:499-638 for one new LiDAR frame: transmittance-only render of `cam` (no_color, :501-507), device-side
+    // selection of the points that land on not-yet-opaque pixels (nearest per pixel, gslic_extend_select), append of the new Gaussians'
+    // rows (gslic_extend_emit) and of zero Adam moments.  Storage grows by capacity doubling, so an append is in place most of the time
+    // instead of the reference's six torch::cat of every parameter and moment (densificationPostfix, :426-497).  After a call that
+    // returned k > 0 the six parameter tensors are NEW views: fetch them with param(i).
+    //   points, colors [n,3], depths_rsp [n]: device fp32; R_cw [3,3] row-major, t_cw [3] (any device); returns the number inserted.
+    int64_t extend(const FusedCamera& cam, const torch::Tensor& points, const torch::Tensor& colors, const torch::Tensor& depths_rsp,
+                   const torch::Tensor& R_cw, const torch::Tensor& t_cw, float fx, float fy, float cx, float cy, float scaling_scale = 1.0f)
+    {
+        torch::NoGradGuard ng;
+        const int64_t P = prm_[0].size(0), n = points.size(0);
+        const int W = cam.image_width, H = cam.image_height;
+        auto fo = prm_[0].options().requires_grad(false);
+        // render(no_color) through the operator entry point with LibTorch activations, exactly as renderer.cpp:57-63 feeds it
+        gslic_raster_params rp{};
+        rp.P = (int32_t)P; rp.D = deg_; rp.M = prm_[2].numel() ? (int32_t)prm_[2].size(1) : 0; rp.width = W; rp.height = H;
+        rp.tan_fovx = cam.tanfovx; rp.tan_fovy = cam.tanfovy;
+        rp.limx_neg = cam.limx_neg; rp.limx_pos = cam.limx_pos; rp.limy_neg = cam.limy_neg; rp.limy_pos = cam.limy_pos;
+        rp.scale_modifier = 1.0f; rp.no_color = 1;
+        torch::Tensor op = torch::sigmoid(prm_[3]).contiguous(), sc = torch::exp(prm_[4]).contiguous();
+        torch::Tensor rot = torch::nn::functional::normalize(prm_[5]).contiguous();
+        torch::Tensor final_T = torch::empty({H, W}, fo), color = torch::empty({3, H, W}, fo), radii = torch::empty({P}, fo.dtype(torch::kInt32));
+        int32_t R = 0, B = 0;
+        check(gslic_rasterize_forward(&rp, grow_cb, &scratch_[0], grow_cb, &scratch_[1], grow_cb, &scratch_[2], grow_cb, &scratch_[3], f(bg_), f(prm_[0]),
+                                      f(prm_[1]), f(prm_[2]), nullptr, f(op), f(sc), f(rot), nullptr, f(cam.world_view_transform),
+                                      f(cam.full_proj_transform), f(cam.camera_center), color.data_ptr<float>(), final_T.data_ptr<float>(),
+                                      radii.data_ptr<int32_t>(), &R, &B, nullptr),
+              "gslic_rasterize_forward (no_color)");
+        torch::Tensor pts = points.to(fo).contiguous(), col = colors.to(fo).contiguous(), rsp = depths_rsp.to(fo).contiguous();
+        torch::Tensor Rc = R_cw.to(fo).contiguous(), tc = t_cw.to(fo).contiguous();
+        torch::Tensor sel_scratch = torch::empty({0}, fo.dtype(torch::kByte));
+        uint32_t *flags = nullptr, *pos = nullptr;
+        int32_t count = 0;
+        check(gslic_extend_select((int32_t)n, f(pts), f(rsp), f(Rc), f(tc), fx, fy, cx, cy, W, H, f(final_T), grow_cb, &sel_scratch, &flags, &pos, &count,
+                                  nullptr),
+              "gslic_extend_select");
+        if (count == 0) return 0;
+        reserve(P + count);
+        const int64_t M = buf_[2].numel() ? buf_[2].size(1) : 0;
+        auto row = [&](int g) { return buf_[g].numel() ? buf_[g].data_ptr<float>() + P * (buf_[g].numel() / buf_[g].size(0)) : nullptr; };
+        check(gslic_extend_emit((int32_t)n, flags, pos, f(pts), f(col), f(rsp), scaling_scale, (fx + fy) / 2.0f, (int32_t)M, row(0), row(1), row(2), row(3),
+                                row(4), row(5), nullptr),
+              "gslic_extend_emit");
+        for (int g = 0; g < 6; g++) {   // new rows start with zero moments (gaussian.cpp:458-459)
+            mbuf_[g].narrow(0, P, count).zero_();
+            vbuf_[g].narrow(0, P, count).zero_();
+        }
+        bind(P + count);
+        torch::cuda::synchronize();   // (the selection scratch is released on return)
+        return count;
+    }
+    const torch::Tensor& param(int group) const { return prm_[group]; }
+    int64_t size() const { return prm_[0].size(0); }
+    int64_t capacity() const { return buf_[0].defined() ? buf_[0].size(0) : prm_[0].size(0); }
 
     // One optimisation step on one view.  Returns the device tensor [mean |image - gt|, mean ssim]; nothing synchronises.
     torch::Tensor step(const FusedCamera& cam, const torch::Tensor& gt_image)
@@ -127,6 +183,27 @@ public:
     const torch::Tensor& exp_avg_sq(int group) const { return v_[group]; }
 
 private:
+    // capacity storage: created by the first extend(); until then the tensors handed to the constructor are used in place
+    void reserve(int64_t newP)
+    {
+        const int64_t P = prm_[0].size(0);
+        if (buf_[0].defined() && newP <= buf_[0].size(0)) return;
+        const int64_t cap = std::max<int64_t>(2 * capacity(), newP);
+        for (int g = 0; g < 6; g++) {
+            std::vector<int64_t> shp = prm_[g].sizes().vec();
+            shp[0] = cap;
+            torch::Tensor nb = torch::empty(shp, prm_[g].options().requires_grad(false)), nm = torch::zeros(shp, m_[g].options()), nv = torch::zeros(shp, v_[g].options());
+            nb.narrow(0, 0, P).copy_(prm_[g].detach());
+            nm.narrow(0, 0, P).copy_(m_[g]);
+            nv.narrow(0, 0, P).copy_(v_[g]);
+            buf_[g] = nb; mbuf_[g] = nm; vbuf_[g] = nv;
+        }
+        bind(P);
+    }
+    void bind(int64_t P)
+    {
+        for (int g = 0; g < 6; g++) { prm_[g] = buf_[g].narrow(0, 0, P); m_[g] = mbuf_[g].narrow(0, 0, P); v_[g] = vbuf_[g].narrow(0, 0, P); }
+    }
     static const float* f(const torch::Tensor& t) { return t.numel() ? t.data_ptr<float>() : nullptr; }
     static char* cptr(torch::Tensor& t) { return t.numel() ? reinterpret_cast<char*>(t.data_ptr()) : nullptr; }
     static void check(int rc, const char* what) { TORCH_CHECK(rc == GSLIC_OK, what, " failed (", rc, "): ", gslic_last_error()); }
@@ -140,6 +217,7 @@ private:
     }
 
     std::array<torch::Tensor, 6> prm_, m_, v_;
+    std::array<torch::Tensor, 6> buf_, mbuf_, vbuf_;
     std::array<float, 6> lrs_;
     int deg_;
     float lambda_dssim_, lambda_erank_, b1_, b2_, eps_;

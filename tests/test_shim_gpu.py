@@ -169,6 +169,58 @@ def test_fused_cpp_host(tmp_path, deg):
     assert len(printed) == iters and np.allclose(printed, losses, rtol=1e-5)
 
 
+def test_fused_cpp_host_extend(tmp_path):
+    """extend() from C++ (gslic::FusedStep::extend: transmittance render, device-side point selection, in-place append with capacity
+    doubling, zero moments) inside the fused training loop — three steps, one LiDAR frame appended, three more steps — against the
+    Python host doing the same (trainer.GaussianModel.extend + training_step_fused): same number of Gaussians inserted, bit-identical
+    parameters afterwards."""
+    if not os.path.exists(CHECK_FUSED):
+        pytest.skip("fused_check not built")
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import trainer
+    from gaussian_lic_amd.synthetic import gt_image, lidar_scene
+    P, W, H, iters, deg = 20000, 320, 240, 3, 3
+    raw, sc, camd, cam = make_scene("random", P, W, H, deg, 47)
+    u_pix = raw["xyz"][:, 0] * (0.675 * W) / raw["xyz"][:, 2].abs().clamp_min(0.2) + 0.4857 * W     # leave the right 30 % of the image uncovered
+    keep = u_pix < 0.7 * W
+    raw = {k: (v[keep].contiguous() if torch.is_tensor(v) else v) for k, v in raw.items()}
+    P = int(raw["xyz"].shape[0])
+    d = str(tmp_path)
+    gt = gt_image(H, W)
+    _write_case(d, raw, cam, gt)
+    frame = lidar_scene(4000, W, H, sh_degree=3, seed=101)
+    f_pts = frame["xyz"].contiguous()
+    f_col = (frame["features_dc"].reshape(-1, 3) * 0.28209479177387814 + 0.5).contiguous()
+    f_rsp = frame["xyz"][:, 2].contiguous()
+    Rcw = np.ascontiguousarray(cam.world_view_transform[:3, :3].T, np.float32)
+    tcw = np.ascontiguousarray(cam.world_view_transform[3, :3], np.float32)
+    intr = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    w = lambda name, t: np.ascontiguousarray(t, np.float32).tofile(os.path.join(d, name + ".f32"))
+    w("frame_pts", f_pts.numpy()); w("frame_col", f_col.numpy()); w("frame_rsp", f_rsp.numpy())
+    w("frame_pose", np.concatenate([Rcw.reshape(-1), tcw.reshape(-1), intr]))
+    w("frame_n", np.array([f_pts.shape[0]], np.float32))
+    r = subprocess.run([CHECK_FUSED, d, str(P), str(W), str(H), str(deg), str(iters)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ins = [l for l in r.stdout.splitlines() if l.startswith("extend inserted")]
+    assert ins, r.stdout[-1000:]
+    k_cpp, size_cpp = int(ins[0].split()[2]), int(ins[0].split()[4])
+    dev = torch.device("cuda:0")
+    model = trainer.GaussianModel(raw, dev)
+    model.training_setup()
+    cam.to_device(dev)
+    bg = torch.zeros(3, device=dev)
+    for _ in range(iters):
+        trainer.training_step_fused(model, cam, gt.to(dev), bg)
+    k_py = model.extend(cam, f_pts.to(dev), f_col.to(dev), f_rsp.to(dev), torch.from_numpy(Rcw), torch.from_numpy(tcw), tuple(float(v) for v in intr))
+    for _ in range(iters):
+        trainer.training_step_fused(model, cam, gt.to(dev), bg)
+    assert k_cpp == k_py and k_py > 100 and size_cpp == model.P
+    rd = lambda name, shape: np.fromfile(os.path.join(d, f"out_{name}.f32"), np.float32).reshape(shape)
+    for name, t in (("xyz", model.xyz), ("scaling", model.scaling), ("rotation", model.rotation), ("opacity", model.opacity),
+                    ("dc", model.features_dc), ("rest", model.features_rest)):
+        np.testing.assert_array_equal(rd(name, tuple(t.shape)), t.detach().cpu().numpy(), err_msg=name)
+
+
 def test_shim_adam_rejects_noncontiguous_state():
     """adamUpdate works in place on param / exp_avg / exp_avg_sq: a strided view must be refused, not silently updated in a temporary
     copy (the reference takes data_ptr of whatever it is given, rasterize_points.cu:262-272)."""
