@@ -74,21 +74,32 @@ __device__ __forceinline__ void ssim_fwd_stage(FwdLds& L, const float* __restric
     }
     __syncthreads();
 }
-__device__ __forceinline__ FwdStats ssim_fwd_column(const FwdLds& L, int ly, int lx)
+// Vertical pass for FOUR consecutive output rows ly0 .. ly0+3 of column lx in one sweep over the 14 rows they share: row r feeds tap r - k of
+// output k, so every output still sees its taps 0..10 in ascending order from 0.0f (the reference's operation sequence), with 14 LDS
+// row reads instead of 44 — the LDS pipe, one per CU, was what these kernels waited for.
+__device__ __forceinline__ void ssim_fwd_column4(const FwdLds& L, int ly0, int lx, FwdStats (&out)[4])
 {
-    v2f v02 = {0.f, 0.f}, v13 = {0.f, 0.f};
-    float v4 = 0.f;
+    v2f v02[4], v13[4];
+    float v4[4];
 #pragma unroll
-    for (int j = 0; j < 11; j++) {
-        const v4f q = L.h4[ly + j][lx];
-        const v2f g2 = {c_G[j], c_G[j]};
-        v02 = SS_FMA2(g2, ((v2f){q.x, q.y}), v02);
-        v13 = SS_FMA2(g2, ((v2f){q.z, q.w}), v13);
-        v4 = __builtin_fmaf(c_G[j], L.h1[ly + j][lx], v4);
+    for (int k = 0; k < 4; k++) { v02[k] = (v2f){0.f, 0.f}; v13[k] = (v2f){0.f, 0.f}; v4[k] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < 14; r++) {
+        const v4f q = L.h4[ly0 + r][lx];
+        const float q1 = L.h1[ly0 + r][lx];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = r - k;
+            if (j >= 0 && j <= 10) {
+                const v2f g2 = {c_G[j], c_G[j]};
+                v02[k] = SS_FMA2(g2, ((v2f){q.x, q.y}), v02[k]);
+                v13[k] = SS_FMA2(g2, ((v2f){q.z, q.w}), v13[k]);
+                v4[k] = __builtin_fmaf(c_G[j], q1, v4[k]);
+            }
+        }
     }
-    FwdStats s;
-    s.mu1 = v02.x; s.mu2 = v02.y; s.e11 = v13.x; s.e22 = v13.y; s.e12 = v4;
-    return s;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { out[k].mu1 = v02[k].x; out[k].mu2 = v02[k].y; out[k].e11 = v13[k].x; out[k].e22 = v13[k].y; out[k].e12 = v4[k]; }
 }
 
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, float C1, float C2, const float* __restrict__ img1,
@@ -102,10 +113,12 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, float C1, f
     const int tid = threadIdx.x;
     ssim_fwd_stage(L, img1 + plane, img2 + plane, H, W, x0, y0);
     const int lx = tid & 31;
+    FwdStats st4[4];
+    ssim_fwd_column4(L, 4 * (tid >> 5), lx, st4);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int ly = (tid >> 5) + 8 * q;
-        const FwdStats st = ssim_fwd_column(L, ly, lx);
+        const int ly = 4 * (tid >> 5) + q;
+        const FwdStats st = st4[q];
         const int px = x0 + lx, py = y0 + ly;
         if (px < W && py < H) {
             const float mu1 = st.mu1, mu2 = st.mu2;
@@ -175,15 +188,25 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float
     }
     __syncthreads();
     const int lx = tid & 31;
+    // four consecutive rows per thread, one sweep over the 14 rows of hs they share (ssim_fwd_column4): taps in ascending order per output
+    const int ly0 = 4 * (tid >> 5);
+    float w0[4] = {0.f, 0.f, 0.f, 0.f}, w1[4] = {0.f, 0.f, 0.f, 0.f}, w2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 14; r++) {
+        const float a0 = hs[0][ly0 + r][lx], a1 = hs[1][ly0 + r][lx], a2 = hs[2][ly0 + r][lx];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = r - k;
+            if (j >= 0 && j <= 10) {
+                const float g = c_G[j];
+                w0[k] += g * a0; w1[k] += g * a1; w2[k] += g * a2;
+            }
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int ly = (tid >> 5) + 8 * q;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 11; j++) {
-            const float g = c_G[j];
-            v0 += g * hs[0][ly + j][lx]; v1 += g * hs[1][ly + j][lx]; v2 += g * hs[2][ly + j][lx];
-        }
+        const int ly = ly0 + q;
+        const float v0 = w0[q], v1 = w1[q], v2 = w2[q];
         const int px = x0 + lx, py = y0 + ly;
         if (px < W && py < H) {
             const size_t o = plane + (size_t)py * W + px;
@@ -225,10 +248,12 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(int H, int W, float C1, f
     ssim_fwd_stage(L, img1 + plane, img2 + plane, H, W, x0, y0);
     const int lx = tid & 31;
     float sum_l1 = 0.f, sum_ssim = 0.f;
+    FwdStats st4[4];
+    ssim_fwd_column4(L, 4 * (tid >> 5), lx, st4);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int ly = (tid >> 5) + 8 * q;
-        const FwdStats st = ssim_fwd_column(L, ly, lx);
+        const int ly = 4 * (tid >> 5) + q;
+        const FwdStats st = st4[q];
         const int px = x0 + lx, py = y0 + ly;
         if (px < W && py < H) {
             const float mu1 = st.mu1, mu2 = st.mu2;
@@ -314,15 +339,25 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(int H, int W, float w_l1,
     }
     __syncthreads();
     const int lx = tid & 31;
+    // four consecutive rows per thread, one sweep over the 14 rows of hs they share (ssim_fwd_column4): taps in ascending order per output
+    const int ly0 = 4 * (tid >> 5);
+    float w0[4] = {0.f, 0.f, 0.f, 0.f}, w1[4] = {0.f, 0.f, 0.f, 0.f}, w2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 14; r++) {
+        const float a0 = hs[0][ly0 + r][lx], a1 = hs[1][ly0 + r][lx], a2 = hs[2][ly0 + r][lx];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = r - k;
+            if (j >= 0 && j <= 10) {
+                const float g = c_G[j];
+                w0[k] += g * a0; w1[k] += g * a1; w2[k] += g * a2;
+            }
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int ly = (tid >> 5) + 8 * q;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 11; j++) {
-            const float g = c_G[j];
-            v0 += g * hs[0][ly + j][lx]; v1 += g * hs[1][ly + j][lx]; v2 += g * hs[2][ly + j][lx];
-        }
+        const int ly = ly0 + q;
+        const float v0 = w0[q], v1 = w1[q], v2 = w2[q];
         const int px = x0 + lx, py = y0 + ly;
         if (px < W && py < H) {
             const size_t o = plane + (size_t)py * W + px;

@@ -10,7 +10,7 @@ for r in $(seq $N); do
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); k = d['kernel_ms_per_launch_timed']; print('$v', d['value'], 'views/s', d['ms_per_step'], 'ms', {n: k[n] for n in ('render_bwd', 'preprocess_bwd', 'render_fwd', 'preprocess', 'keybuild')})
+        d = json.loads(l); k = d['kernel_ms_per_launch_timed']; print('$v', d['value'], 'views/s', d['ms_per_step'], 'ms', {n: k[n] for n in ('render_bwd', 'preprocess_bwd', 'render_fwd', 'preprocess', 'ssim_fwd', 'ssim_bwd')})
 "
   done
 done
