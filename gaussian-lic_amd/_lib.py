@@ -107,7 +107,7 @@ def lib():
 
 
 def set_math_mode(strict):
-    """gslic_set_math_mode: True = the blend kernels in the reference's arithmetic (bit-identical image), False = fast (default).
+    """gslic_set_math_mode: True (default) = the blend kernels in the reference's arithmetic (bit-identical image), False = fast (opt-in; GSLIC_FAST_MATH=1).
     Returns the previous mode."""
     return bool(lib().gslic_set_math_mode(int(bool(strict))))
 

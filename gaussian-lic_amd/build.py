@@ -40,6 +40,14 @@ def _newer(a, b):
 
 
 def build(force=False, verbose=False):
+    # A/B variants (tools/ab): GSLIC_BUILD_EXTRA="-DFOO=1 ..." compiles every file with extra flags into its own object directory and
+    # GSLIC_BUILD_LIB=<path> names the library, so the in-tree libgslic_hip.so is left alone
+    global OBJ, LIB
+    extra_all = os.environ.get("GSLIC_BUILD_EXTRA", "").split()
+    if os.environ.get("GSLIC_BUILD_LIB"):
+        LIB = os.path.abspath(os.environ["GSLIC_BUILD_LIB"])
+        OBJ = os.path.join(CSRC, "build_" + os.path.splitext(os.path.basename(LIB))[0])
+        force = True
     os.makedirs(OBJ, exist_ok=True)
     hdr_paths = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     jobs = []
@@ -47,7 +55,7 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         if force or _newer(s, o) or any(_newer(h, o) for h in hdr_paths):
-            jobs.append((s, o, [HIPCC] + COMMON + extra + ["-c", s, "-o", o]))
+            jobs.append((s, o, [HIPCC] + COMMON + extra + extra_all + ["-c", s, "-o", o]))
 
     def run(job):
         s, o, cmd = job

@@ -26,7 +26,14 @@ int set_error(int code, const char* fmt, ...)
 
 // ---------------------------------------------------------------------------------------------------------
 bool g_prof_on = false;
-int g_strict_math = (getenv("GSLIC_STRICT_MATH") && atoi(getenv("GSLIC_STRICT_MATH")) != 0) ? 1 : 0;
+// Arithmetic of the two blend kernels: 1 (default) = the reference's operations in source order (bit-identical image / final_T /
+// n_contrib to the reference kernels), 0 = the fast variant (opt-in: GSLIC_FAST_MATH=1, or the older GSLIC_STRICT_MATH=0).
+int g_strict_math = [] {
+    const char* s = getenv("GSLIC_STRICT_MATH");
+    if (s) return atoi(s) != 0 ? 1 : 0;
+    const char* f = getenv("GSLIC_FAST_MATH");
+    return (f && atoi(f) != 0) ? 0 : 1;
+}();
 static uint32_t g_prof_mask = 0xffffffffu;
 static bool g_prof_cur_on = false;
 static const char* const k_names[K_COUNT] = {

@@ -63,7 +63,7 @@ enum KernelId {
 void prof_begin(int id, hipStream_t s);
 void prof_end(int id, hipStream_t s);
 extern bool g_prof_on;
-extern int g_strict_math;  // gslic_set_math_mode(): 1 = blend kernels in the reference's arithmetic (render.hip), 0 = fast (default)
+extern int g_strict_math;  // gslic_set_math_mode(): 1 (default) = blend kernels in the reference's arithmetic (render.hip), 0 = fast (GSLIC_FAST_MATH=1)
 
 #define GS_LAUNCH(id, kernel, grid, block, shmem, stream, ...)                                             \
     do {                                                                                                   \
@@ -257,6 +257,25 @@ __device__ __forceinline__ void adam_scalar(float& p, float g, float& m, float& 
     v = b2 * v + (1.0f - b2) * g * g;
     p += -lr * m / (sqrtf(v) + eps);
 }
+
+// expf() as hipcc lowers it for gfx950 (the AMDGPU lowering of llvm.exp.f32: x log2(e) split into a rounded head PH and a tail PL by
+// two FMAs, E = rint(PH), v_exp_f32((PH - E) + PL), ldexp by E — see the disassembly of any expf() call under -fno-fast-math), minus
+// its two range checks (x < -103.28 -> 0, x > 88.72 -> inf).  Those never decide anything in a blend: a pair with power > 0 is skipped
+// before exp is looked at, and below -103.28 both this sequence (a denormal or 0 out of v_ldexp_f32) and the library (0) give an
+// alpha far under 1/255.  Everywhere else the two are the same instructions on the same operands: bit-identical results
+// (tools/ubench/expf_replica checks every float in [-104, 0] on the device).  kL2E / kCC live in VGPRs at the call sites (a literal
+// operand doubles the issue cost of a VALU instruction on this part).
+__device__ __forceinline__ float expf_core(float x, float kL2E, float kCC)
+{
+#pragma clang fp contract(off)
+    const float ph = x * kL2E;
+    const float pl = __builtin_fmaf(x, kCC, __builtin_fmaf(x, kL2E, -ph));
+    const float e = __builtin_rintf(ph);
+    const float a = (ph - e) + pl;
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
+}
+#define GS_EXP_L2E 0x1.715476p+0f   /* log2(e) rounded to float: 0x3fb8aa3b */
+#define GS_EXP_CC 0x1.4ae0bep-26f   /* log2(e) - (float)log2(e): 0x32a5705f */
 
 // Canonical logf for the culling threshold (forward.cu:302): fixed double polynomial, identical to orc_logf.
 __device__ __forceinline__ float canon_logf(float x)

@@ -19,6 +19,10 @@
 #include "kernels.h"
 #include <stdlib.h>
 
+#ifndef GSLIC_STRICT_FWD_BRANCH
+#define GSLIC_STRICT_FWD_BRANCH 0   // A/B switch (tools/ab): 1 = the strict forward applies an entry under an exec mask instead of with selects
+#endif
+
 namespace gslic {
 
 // Upper bound of p2(x, y) = hA dx^2 + hC dy^2 + nB dx dy (dx = gx - x, dy = gy - y; a negative-definite form scaled by log2 e)
@@ -105,6 +109,15 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
         asm volatile("" : "+v"(lyq[q]));
     }
     asm volatile("" : "+v"(c099), "+v"(c255), "+v"(c1e4), "+v"(ninf));
+    // STRICT only: absolute pixel coordinates and the constants of expf_core, in VGPRs like the others
+    float pxf = (float)px, pyq[QN], kL2E = GS_EXP_L2E, kCC = GS_EXP_CC, kmh = -0.5f, kzero = 0.0f, vonef = 1.0f;
+#pragma unroll
+    for (int q = 0; q < QN; q++) pyq[q] = (float)(pyb + 4 * (q0 + q));
+    if constexpr (STRICT) {
+#pragma unroll
+        for (int q = 0; q < QN; q++) asm volatile("" : "+v"(pyq[q]));
+        asm volatile("" : "+v"(pxf), "+v"(kL2E), "+v"(kCC), "+v"(kmh), "+v"(kzero), "+v"(vonef));
+    }
 
     for (int base = 0; base < n; base += GS_BUCKET) {
         bool alldone = true;
@@ -165,23 +178,41 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
             const float gdx = e0.x, gdy = e0.y, hA = e0.z, nB = e0.w, hC = e1.x, op = e1.y, colr = e1.z, colg = e1.w, colb = e2.x;
             if constexpr (STRICT) {
 #pragma clang fp contract(off)
-                const float dxs = gdx - (float)px;  // float2 d = { xy.x - pixf.x, xy.y - pixf.y } (forward.cu:424)
+                // forward.cu:424-445 operation for operation: d from absolute coordinates, the three products of the power rounded one by
+                // one, hipcc's expf (expf_core), opacity * exp, (colour * alpha) * T added to C.  Straight-line like the default variant:
+                // a pixel the entry does not blend into runs the same instructions with alpha forced to +0, which leaves C (>= 0), T and
+                // the last contributor unchanged bit for bit.  (-0.5f * s - c as one fma: halving is exact.)
+                const float dxs = gdx - pxf;              // float2 d = { xy.x - pixf.x, xy.y - pixf.y } (forward.cu:424)
+                const float ax = (hA * dxs) * dxs;        // con_o.x * d.x * d.x
+                const float bx = nB * dxs;                // con_o.y * d.x
 #pragma unroll
                 for (int q = 0; q < QN; q++) {
                     if (!(smask & (1u << q))) continue;  // wave-uniform; conservative (no pixel of the strip reaches alpha >= 1/255)
-                    const float dys = gdy - (float)(pyb + 4 * (q0 + q));
-                    const float power = -0.5f * (hA * dxs * dxs + hC * dys * dys) - nB * dxs * dys;
-                    const float alpha = fminf(0.99f, op * expf(power));
-                    const float test_T = T[q] * (1 - alpha);
-                    if (!(power > 0.0f) && !(alpha < 1.0f / 255.0f) && T[q] > 0.f) {
-                        if (test_T < 0.0001f) {
+                    const float dys = gdy - pyq[q];
+                    const float s2 = ax + (hC * dys) * dys;
+                    const float power = __builtin_fmaf(kmh, s2, -(bx * dys));
+                    const float alpha = __builtin_amdgcn_fmed3f(op * expf_core(power, kL2E, kCC), ninf, c099);   // min(0.99f, con_o.w * exp(power))
+                    const float test_T = T[q] * (vonef - alpha);
+                    const bool ok = (T[q] > kzero) & !(power > kzero) & !(alpha < c255);   // live pixel, forward.cu:431,437
+                    const bool stop = ok & (test_T < c1e4);                               // done; this entry is NOT applied (forward.cu:438-443)
+                    const bool app = ok & !stop;
+#if GSLIC_STRICT_FWD_BRANCH
+                    if (ok) {   // exec-masked: skipped when no pixel of the strip blends this entry
+                        if (stop) {
                             T[q] = -T[q];
                         } else {
-                            Cr[q] += colr * alpha * T[q]; Cg[q] += colg * alpha * T[q]; Cb[q] += colb * alpha * T[q];
+                            Cr[q] = Cr[q] + (colr * alpha) * T[q]; Cg[q] = Cg[q] + (colg * alpha) * T[q]; Cb[q] = Cb[q] + (colb * alpha) * T[q];
                             T[q] = test_T;
-                            last[q] = contributor;
+                            last[q] = vcontrib;
                         }
                     }
+#else
+                    const float am = app ? alpha : kzero;
+                    Cr[q] = Cr[q] + (colr * am) * T[q]; Cg[q] = Cg[q] + (colg * am) * T[q]; Cb[q] = Cb[q] + (colb * am) * T[q];
+                    const float Tdone = stop ? -T[q] : T[q];
+                    T[q] = app ? test_T : Tdone;
+                    last[q] = app ? vcontrib : last[q];
+#endif
                 }
             } else {
                 // e1.y holds log2(opacity) here.  The operation sequence below is repeated verbatim by the backward (GS_BW_BODY), so both
@@ -287,13 +318,19 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // Before the first pixel reaches lane L (s < L) the lane reads whatever lies s - L records before the array — the start states, placed
 // there on purpose: finite numbers — while its travelling state is still T = A = 0, which makes every product of the step an exact zero
 // whatever the record says; behind the last pixel come 64 zero records.
-// STRICT: delta, power and opacity * G of one (pixel, Gaussian) pair as backward.cu:539-542 / forward.cu:424-432 form them.
-__device__ __forceinline__ void strict_pair(v2f mean, v2f pix, v2f cAC, float cB, float op, v2f& d, float& power, float& araw)
+// STRICT: delta, power and opacity * G of one (pixel, Gaussian) pair as backward.cu:539-542 / forward.cu:424-432 form them: the
+// reference's operations in source order, separately rounded (no contraction), and hipcc's expf().  -0.5f * s - c is written as ONE
+// fma(-0.5, s, -c): halving is exact (nothing is rounded before the subtraction), so the bits are those of multiply-then-subtract.
+__device__ __forceinline__ void strict_pair(v2f mean, v2f pix, v2f cAC, float cB, float op, float kL2E, float kCC, float kmh, v2f& d, float& power,
+                                            float& araw)
 {
 #pragma clang fp contract(off)
-    d.x = mean.x - pix.x; d.y = mean.y - pix.y;
-    power = -0.5f * (cAC.x * d.x * d.x + cAC.y * d.y * d.y) - cB * d.x * d.y;
-    araw = op * expf(power);
+    d = mean - pix;
+    const v2f t = (cAC * d) * d;          // {A dx dx, C dy dy}
+    const float s = t.x + t.y;
+    const float c = (cB * d.x) * d.y;
+    power = __builtin_fmaf(kmh, s, -c);
+    araw = op * expf_core(power, kL2E, kCC);
 }
 
 struct BwdLane {
@@ -329,8 +366,8 @@ struct BwdLane {
         if constexpr (STRICT) {                                                                                      \
             const v2f pix = GS_PK_FMA(pxy16, kneg, torg); /* exact: tile origin + {px, py} (kneg = {1/16, 1} here) */ \
             float power;                                                                                             \
-            strict_pair(L.d0, pix, L.hAC, L.nB, L.lop, d, power, araw);                                              \
-            hit = (kcmp < TAG) & !(power > 0.0f) & !(araw < c255);                                                   \
+            strict_pair(L.d0, pix, L.hAC, L.nB, L.lop, kL2E, kCC, kmh, d, power, araw);                              \
+            hit = (kcmp < TAG) & !(power > kzero) & !(araw < c255);                                                  \
         } else {                                                                                                     \
             d = GS_PK_FMA(pxy16, kneg, L.d0); /* exact: d0 - {px, py} */                                             \
             float p2 = __builtin_fmaf(L.hAC.x * d.x, d.x, L.lop); /* the operation sequence of render_fwd */         \
@@ -343,7 +380,7 @@ struct BwdLane {
         const float ah = hit ? araw : 0.0f; /* one select masks both alpha and the gradient weight */                \
         const float alpha = __builtin_amdgcn_fmed3f(ah, ninf, c099); /* min(0.99, .) without the canonicalising v_max fminf costs */ \
         const float om = 1.0f - alpha;                                                                               \
-        const float rinv = STRICT ? 1.0f / om : __builtin_amdgcn_rcpf(om);                                           \
+        const float rinv = __builtin_amdgcn_rcpf(om); /* both modes: 1 / (1 - alpha) scales a gradient term, it decides nothing (<= 1 ulp) */ \
         const float Ta = T_ * alpha;                                                                                 \
         float cg = L.col_rg.x * gr.x;                                                                                \
         cg = __builtin_fmaf(L.col_rg.y, gr.y, cg);                                                                   \
@@ -498,6 +535,8 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     v2f torg = {(float)tx0, (float)ty0};   // (STRICT: absolute pixel coordinates = tile origin + in-tile offset)
     uint32_t kcmp = ((uint32_t)lane << 16) | 0xffffu;
     asm volatile("" : "+v"(c099), "+v"(c255), "+v"(ninf), "+v"(kneg), "+v"(kcmp), "+v"(torg));
+    float kL2E = GS_EXP_L2E, kCC = GS_EXP_CC, kmh = -0.5f, kzero = 0.0f;   // STRICT only (dead registers otherwise)
+    if constexpr (STRICT) asm volatile("" : "+v"(kL2E), "+v"(kCC), "+v"(kmh), "+v"(kzero));
     v2f acc_S = {0.f, 0.f}, acc_cxy = {0.f, 0.f}, acc_rg = {0.f, 0.f};
     float acc_cw = 0, acc_op = 0, acc_b = 0;
     // {T, A}: the state travelling through the lanes (set 1) and the injection fetched one step ahead (set 2); a step shifts set 1

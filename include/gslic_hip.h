@@ -372,12 +372,15 @@ int gslic_extend_emit(
 int gslic_abi_version(void);
 const char* gslic_last_error(void);
 
-/* Arithmetic of the two blend kernels (process-wide; returns the previous mode).  0 (default) = fast: conic pre-scaled by log2(e),
- * tile-relative coordinates, v_exp_f32 / v_rcp_f32, fused multiply-adds — results within fp32 rounding of the reference
- * (forward.cu:424-445, backward.cu:538-581), which flips the alpha < 1/255 and T < 1e-4 decisions of a few (pixel, Gaussian)
- * pairs per million.  1 = strict: the reference's operations in source order, no contraction, the device library's exp() and
- * IEEE divide — image / final_T / n_contrib are then bit-identical to the reference kernels compiled for the same GPU
- * (tests/test_fullsize_reference_gpu.py).  Initial value: environment GSLIC_STRICT_MATH=1. */
+/* Arithmetic of the two blend kernels (process-wide; returns the previous mode).
+ * 1 (default) = strict: the reference's operations in source order (forward.cu:424-445, backward.cu:538-581) — absolute pixel
+ * coordinates, every product of the power rounded on its own (no contraction), exp() as hipcc lowers expf() (the same instruction
+ * sequence, inlined without its two range checks), opacity * exp, (colour * alpha) * T.  Image / final_T / n_contrib are bit-identical
+ * to the reference's kernels compiled by hipcc -ffp-contract=off for the same GPU, every blend / skip decision of the backward is the
+ * reference's, gradients agree to fp32 summation order (tests/test_fullsize_reference_gpu.py).  This is what bench.py times.
+ * 0 = fast (opt-in: GSLIC_FAST_MATH=1 in the environment, or this call): conic pre-scaled by log2(e), tile-relative coordinates,
+ * alpha = v_exp_f32(p2 + log2 opacity), fused multiply-adds — within fp32 rounding of the reference, which flips the alpha < 1/255
+ * and T < 1e-4 decisions of a few (pixel, Gaussian) pairs per million (counted in the same test). */
 int gslic_set_math_mode(int32_t strict);
 
 /* Sizes the four scratch buffers would need, for hosts that prefer to pre-size (bytes incl. slack). */

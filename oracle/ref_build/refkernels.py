@@ -6,10 +6,11 @@ import os
 import numpy as np
 
 LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_ref", "libref_hip.so")
+LIB_FMA = os.path.join(os.path.dirname(LIB), "libref_hip_fma.so")   # the same sources under -ffp-contract=fast (build_ref.py): the yardstick build
 
 
-def available():
-    return os.path.exists(LIB)
+def available(fma=False):
+    return os.path.exists(LIB_FMA if fma else LIB)
 
 
 def _p(a):
@@ -17,8 +18,9 @@ def _p(a):
 
 
 class RefKernels:
-    def __init__(self):
-        self.lib = ctypes.CDLL(LIB)
+    def __init__(self, fma=False):
+        """fma=True loads the contracted build (hipcc's default -ffp-contract=fast, the analogue of nvcc's default --fmad=true)."""
+        self.lib = ctypes.CDLL(LIB_FMA if fma else LIB)
         self.lib.ref_create.restype = ctypes.c_void_p
         self.lib.ref_destroy.argtypes = [ctypes.c_void_p]
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Prints (and writes as JSON) the element-wise comparison of the HIP path with the reference's own kernels at BASELINE's full
-sizes, fast and strict arithmetic — the table of DESIGN.md section 2 comes from this script.
+sizes, fast and strict arithmetic, plus the yardstick column `ref_contract`: the reference's kernels against themselves under
+-ffp-contract=fast vs off — the table of DESIGN.md section 2 comes from this script.
 
     python tests/parity_report.py [--out gpurun_out/parity_report.json] [--configs small,c2,c3,c5]
 
@@ -27,15 +28,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join("gpurun_out", "parity_report.json"))
     ap.add_argument("--configs", default="small,c2,c3,c5")
+    ap.add_argument("--no-ref-contract", action="store_true", help="skip the reference-vs-reference (contraction on / off) yardstick column")
     args = ap.parse_args()
-    from refcompare import compare, summarize
+    from oracle.ref_build import refkernels
+    from refcompare import compare, compare_reference_builds, summarize, summarize_reference_builds
     results = {}
     for name in args.configs.split(","):
         t0 = time.time()
         res = compare(*CONFIGS[name])
+        if not args.no_ref_contract and refkernels.available(fma=True):
+            res["ref_contract"] = compare_reference_builds(*CONFIGS[name])
         res["seconds"] = round(time.time() - t0, 1)
         results[name] = res
         print(f"== {name} ({res['seconds']} s)\n" + summarize(res), flush=True)
+        if "ref_contract" in res:
+            print(summarize_reference_builds(res["ref_contract"]), flush=True)
         os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
         json.dump(results, open(args.out, "w"), indent=1)
 

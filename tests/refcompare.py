@@ -75,6 +75,57 @@ def compare(kind, P, W, H, deg, seed, modes=("fast", "strict"), backward=True):
     return out
 
 
+def compare_reference_builds(kind, P, W, H, deg, seed):
+    """The yardstick: the reference's kernels against THEMSELVES under the two contraction settings — oracle/_ref/libref_hip.so
+    (-ffp-contract=off, the pin of the parity tests) vs libref_hip_fma.so (-ffp-contract=fast: hipcc's default and the analogue of nvcc's
+    default --fmad=true that upstream is built with).  Same statistics as compare(): what one compiler flag moves in the reference's own
+    output is the noise floor any "bit-identical to the reference" statement sits on."""
+    from conftest import make_scene
+    from gaussian_lic_amd.synthetic import pixel_grad
+    from oracle.ref_build import refkernels
+    assert P % 256 == 0
+    raw, sc, camd, cam = make_scene(kind, P, W, H, deg, seed)
+    dL = pixel_grad(H, W, seed=1).numpy()
+    a = refkernels.RefKernels().run(sc, camd, dL)
+    b = refkernels.RefKernels(fma=True).run(sc, camd, dL)
+    vis = (a["radii"] > 0) & (b["radii"] > 0)
+    st = {}
+    st["radii_mismatch"] = int((a["radii"] != b["radii"]).sum())
+    bad = np.nonzero(a["tiles_touched"] != b["tiles_touched"])[0]
+    st["tiles_touched_mismatch"] = int(bad.size)
+    st["R"] = [int(a["R"]), int(b["R"])]
+    pa, pb = a["point_list"], b["point_list"]
+    st["point_list_equal_raw"] = bool(pa.shape == pb.shape and np.array_equal(pa, pb))
+    if bad.size:
+        pa, pb = pa[~np.isin(pa, bad)], pb[~np.isin(pb, bad)]
+    st["point_list_equal"] = bool(pa.shape == pb.shape and np.array_equal(pa, pb))   # after removing the Gaussians whose tile count differs
+    st["point_list_order_differences"] = int((pa != pb).sum()) if pa.shape == pb.shape else None
+    for k in ("means2D", "depths", "conic_opacity", "rgb"):
+        st[k + "_bit_equal"] = bool(np.array_equal(a[k][vis], b[k][vis]))
+        st[k + "_elements_differing"] = int((a[k][vis] != b[k][vis]).sum())
+    st["color"] = _err_stats(b["color"], a["color"])
+    st["final_T"] = _err_stats(b["final_T"], a["final_T"])
+    st["n_contrib_mismatch"] = int((a["n_contrib"] != b["n_contrib"]).sum())
+    st["pixels"] = int(a["n_contrib"].size)
+    for k in GRADS:
+        scale = None
+        if k == "dL_drot":
+            scale = max(float(np.abs(a["dL_drot"]).max()), float(np.abs(a["dL_dscale"]).max() * sc["scales"].max()))
+        st[k] = _err_stats(b[k], a[k], scale)
+    return st
+
+
+def summarize_reference_builds(st):
+    parts = [f"radii!={st['radii_mismatch']}", f"tiles_touched!={st['tiles_touched_mismatch']}", f"R={st['R']}",
+             f"lists_equal={st['point_list_equal']} (order differences {st['point_list_order_differences']})",
+             "geometry elements differing: " + ", ".join(f"{k}={st[k + '_elements_differing']}" for k in ("means2D", "depths", "conic_opacity", "rgb")),
+             f"color over1e-4={st['color']['over']}/{st['color']['n']} max={st['color']['max_rel']:.2e} bit_equal={st['color']['bit_equal']}",
+             f"final_T over={st['final_T']['over']} max={st['final_T']['max_rel']:.2e}", f"n_contrib!={st['n_contrib_mismatch']}/{st['pixels']}"]
+    for k in GRADS:
+        parts.append(f"{k} over={st[k]['over']}/{st[k]['n']} max={st[k]['max_rel']:.2e}")
+    return "  [reference -ffp-contract=fast vs reference -ffp-contract=off] " + "  ".join(parts)
+
+
 def summarize(res):
     """One line per mode: what a reader of the test log needs."""
     lines = []

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_close_flips, make_scene, rel_err
+from conftest import make_scene, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -43,11 +43,12 @@ def test_forward_backward_parity(oracle32, kind, P, W, H, deg, seed):
     np.testing.assert_array_equal(npy(d["conic_opacity"])[vis], ref["pre"]["conic_opacity"][vis])
     assert rel_err(npy(d["rgb"])[vis], ref["pre"]["rgb"][vis]) < 1e-6
     # ---- image
-    assert_close_flips(npy(got["color"]), ref["color"], TOL, "color")
-    assert_close_flips(npy(got["final_T"]), ref["final_T"], TOL, "final_T")
+    # (default = strict arithmetic.  The oracle's exp() is the host libm's, the device's is hipcc's expf lowering: both within an ulp
+    # of each other, so a pair sitting exactly on a cut could still decide differently; on these seeded cases none does.)
+    assert rel_err(npy(got["color"]), ref["color"]) < TOL
+    assert rel_err(npy(got["final_T"]), ref["final_T"]) < TOL
     nc = npy(d["n_contrib"]).astype(np.int64)
-    mism = (nc != ref["n_contrib"].astype(np.int64)).mean()
-    assert mism < 2e-3, f"n_contrib differs on {mism:.2%} of pixels (exp() ulp flips at the alpha/T thresholds)"
+    assert int((nc != ref["n_contrib"].astype(np.int64)).sum()) == 0
     # bucket count = sum ceil(n_t / 64)
     r = ref["bins"]["ranges"].astype(np.int64)
     assert got["B"] == int(((r[:, 1] - r[:, 0] + 63) // 64).sum())
@@ -61,8 +62,7 @@ def test_forward_backward_parity(oracle32, kind, P, W, H, deg, seed):
         if k == "dL_drot":  # exactly 0 for isotropic Gaussians: measure against the magnitude of the cancelling terms
             scale = max(scale, float(np.abs(gref["dL_dscale"]).max() * sc["scales"].max()))
         err_ = np.abs(a_ - b_) / max(scale, 1e-30) if b_.size else np.zeros(1)
-        nbad = int((err_ > TOL).sum())  # a threshold flip of the blend (see conftest.assert_close_flips) touches a few Gaussians
-        assert nbad <= max(1, int(2e-5 * b_.size)) and err_.max() < 2e-2, f"{k}: {nbad} elements > {TOL}, max rel err {err_.max():.3e}"
+        assert err_.max() < TOL, f"{k}: {int((err_ > TOL).sum())} elements > {TOL}, max rel err {err_.max():.3e}"
         assert np.all(ggot[k].reshape(P, -1)[~vis] == 0), f"{k}: invisible rows must be exact zeros"
 
 
@@ -278,10 +278,10 @@ def test_degenerate_shapes(oracle32, case):
     np.testing.assert_array_equal(npy(got["radii"]), ref["pre"]["radii"])
     np.testing.assert_array_equal(npy(got["dbg"]["point_list"])[:R].astype(np.uint32), ref["bins"]["point_list"][:R].astype(np.uint32))
     np.testing.assert_array_equal(npy(got["dbg"]["ranges"]).reshape(-1, 2).astype(np.uint32), ref["bins"]["ranges"].astype(np.uint32))
-    assert_close_flips(npy(got["color"]), ref["color"], 1e-4, "color")
+    assert rel_err(npy(got["color"]), ref["color"]) < 1e-4
     dL = pixel_grad(H, W, seed=1)
     g = hip_backward(got, dL)
     rg = oracle32.backward(sc, camd, ref, dL.numpy())
     for k in ("dL_dmean3D", "dL_dopacity", "dL_ddc", "dL_dsh", "dL_dscale"):
         if rg[k].size and np.abs(rg[k]).max() > 0:
-            assert_close_flips(g[k].reshape(rg[k].shape), rg[k], 1e-4, k, flip_bound=2e-2)
+            assert rel_err(g[k].reshape(rg[k].shape), rg[k]) < 1e-4, k
