@@ -98,6 +98,7 @@ ImageState ImageState::carve(const void* base, size_t T, size_t* bytes)
     g.ranges = c.take<uint2>(T);
     g.bucket_offsets = c.take<uint32_t>(T);
     g.max_contrib = c.take<uint32_t>(T);
+    g.tile_order = c.take<uint32_t>(T);
     g.pix_final = c.take<float4>(T * GS_TILE_PIX);
     if (bytes) *bytes = c.used(base) + 256;
     return g;
@@ -113,7 +114,8 @@ BinningState BinningState::carve(const void* base, size_t R, int end_bit, bool n
         g.gauss[i] = c.take<uint32_t>(R);
     }
     g.sort_scratch = c.take<char>(sort_scratch_bytes(g.plan));
-    g.partials = no_color ? nullptr : c.take<float4>(3 * R);
+    g.partials = no_color ? nullptr : c.take<float>(9 * R);
+    g.dead = no_color ? nullptr : c.take<uint8_t>(R);
     if (bytes) *bytes = c.used(base) + 256;
     return g;
 }
@@ -427,7 +429,7 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
         sb.v0_identity = true;
         GS_TRY(radix_sort_u32(sb, bin.plan, bin.sort_scratch, (onesweep_mask() & 2) != 0, K_SORT_HIST, K_SORT_SCATTER, s, R_dev));
         DEBUG_SYNC(prm, s);
-        GS_TRY(launch_finalize_ranges(R, R_dev, bin.sorted_tiles(), img.ranges, s));
+        GS_TRY(launch_finalize_ranges(R, R_dev, bin.sorted_tiles(), img.ranges, bin.dead, s));
         DEBUG_SYNC(prm, s);
     }
 
@@ -435,7 +437,7 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
     memset(&smp, 0, sizeof(smp));
     uint32_t B = 0;
     if (!no_color) {
-        GS_TRY(launch_bucket_scan(T, img.ranges, img.bucket_offsets, img.max_contrib, s));
+        GS_TRY(launch_bucket_scan(T, img.ranges, img.bucket_offsets, img.max_contrib, img.tile_order, s));
         if (cap) {
             B = capacity_for(cap->sample_bytes, [&](uint32_t b) { size_t n; SampleState::carve(nullptr, (size_t)b, &n); return n; });
         } else {
@@ -453,6 +455,8 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
     RenderFwdArgs ra;
     ra.W = prm->width; ra.H = prm->height; ra.gx = gx; ra.gy = gy; ra.no_color = prm->no_color;
     ra.ranges = img.ranges; ra.point_list = bin.point_list(); ra.rec = geom.rec; ra.bucket_offsets = img.bucket_offsets;
+    static const bool tile_lpt = getenv("GSLIC_NO_TILE_ORDER") == nullptr;
+    ra.tile_order = (no_color || !tile_lpt) ? nullptr : img.tile_order;   // (written by the bucket scan, which a no_color forward skips)
     ra.bucket_to_tile = smp.bucket_to_tile; ra.ckpt = smp.ckpt; ra.pix_final = img.pix_final; ra.max_contrib = img.max_contrib;
     ra.out_color = out_color; ra.out_final_T = out_final_T; ra.capB = B; ra.status = geom.flags;
     GS_TRY(launch_render_fwd(ra, s));
@@ -542,7 +546,7 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
     rb.W = prm->width; rb.H = prm->height; rb.gx = gx; rb.B = B;
     rb.ranges = img.ranges; rb.point_list = bin.point_list(); rb.inst_slot = bin.inst_slot(); rb.rec = geom.rec;
     rb.bucket_offsets = img.bucket_offsets; rb.bucket_to_tile = smp.bucket_to_tile; rb.ckpt = smp.ckpt; rb.pix_final = img.pix_final;
-    rb.max_contrib = img.max_contrib; rb.dL_dpix = dL_dpix; rb.partials = bin.partials; rb.status = geom.flags; rb.T = T;
+    rb.max_contrib = img.max_contrib; rb.dL_dpix = dL_dpix; rb.partials = bin.partials; rb.dead = bin.dead; rb.status = geom.flags; rb.T = T;
     GS_TRY(launch_render_bwd(rb, s));
     DEBUG_SYNC(prm, s);
 
@@ -553,7 +557,7 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
     pb.limx_neg = prm->limx_neg; pb.limx_pos = prm->limx_pos; pb.limy_neg = prm->limy_neg; pb.limy_pos = prm->limy_pos;
     pb.scale_modifier = prm->scale_modifier; pb.lambda_erank = lambda_erank;
     pb.means = means3D; pb.scales = scales; pb.rots = rotations; pb.dc = dc; pb.shs = shs; pb.view = viewmatrix; pb.proj = projmatrix;
-    pb.campos = cam_pos; pb.radii = radii; pb.rec = geom.rec; pb.tiles_touched = geom.tiles_touched; pb.gauss_start = geom.gauss_start; pb.partials = bin.partials;
+    pb.campos = cam_pos; pb.radii = radii; pb.rec = geom.rec; pb.tiles_touched = geom.tiles_touched; pb.gauss_start = geom.gauss_start; pb.partials = bin.partials; pb.dead = bin.dead;
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_ddc = dL_ddc; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale;
     pb.dL_drot = dL_drot; pb.dL_drgb = dL_drgb;

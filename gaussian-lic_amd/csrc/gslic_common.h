@@ -159,6 +159,7 @@ struct ImageState {
     uint2* ranges;            // [T]
     uint32_t* bucket_offsets; // [T] inclusive scan of ceil(n_t / GS_BUCKET)
     uint32_t* max_contrib;    // [T]
+    uint32_t* tile_order;     // [T] tile ids by descending bucket count (render_fwd hands out its workgroups in this order)
     float4* pix_final;        // [T*256] tile-major {C.r,C.g,C.b, n_contrib bits}
     static ImageState carve(const void* base, size_t T, size_t* bytes);
 };
@@ -167,7 +168,9 @@ struct BinningState {
     uint32_t* slots[2];       // [R] ping-pong payload: emission slot u (where the backward writes the instance's partials)
     uint32_t* gauss[2];       // [R] ping-pong payload: Gaussian id; gauss[passes & 1] after the sort IS the point list
     void* sort_scratch;
-    float4* partials;         // [3R] per emission slot: 9 partial gradients (+3 pad), only when !no_color
+    float* partials;          // [9R] per emission slot: the instance's 9 partial gradients (36-byte rows), only when !no_color
+    uint8_t* dead;            // [R] per emission slot: 1 = the instance lies in a bucket behind its tile's last contributor (its partial row is
+                              // NOT written and must not be read: all nine gradients are exactly zero); zeroed by finalize_ranges_kernel
     SortPlan plan;
     uint32_t* point_list() const { return gauss[plan.passes & 1]; }
     uint32_t* inst_slot() const { return slots[plan.passes & 1]; }
@@ -229,6 +232,7 @@ __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int l) { return (uint
 #define GSLIC_NT 1
 #endif
 typedef float gs_v4f __attribute__((ext_vector_type(4)));
+typedef float gs_v4f_u __attribute__((ext_vector_type(4), aligned(4)));   // four floats at a dword-aligned address (the 36-byte partial rows)
 __device__ __forceinline__ float4 ld_stream(const float4* p)
 {
 #if GSLIC_NT

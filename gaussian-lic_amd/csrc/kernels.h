@@ -32,8 +32,10 @@ struct KeybuildArgs {
 };
 int launch_keybuild(const KeybuildArgs& a, hipStream_t s);
 // R_dev != NULL: the real instance count is read on the device and R is the capacity the launch is sized for
-int launch_finalize_ranges(uint32_t R, const uint32_t* R_dev, const uint32_t* sorted_tiles, uint2* ranges, hipStream_t s);
-int launch_bucket_scan(int T, const uint2* ranges, uint32_t* bucket_offsets, uint32_t* max_contrib /* zeroed */, hipStream_t s);  // scan.hip
+// dead != NULL: also clears the per-slot dead flags of the backward (BinningState::dead)
+int launch_finalize_ranges(uint32_t R, const uint32_t* R_dev, const uint32_t* sorted_tiles, uint2* ranges, uint8_t* dead, hipStream_t s);
+// per-tile bucket counts + their scan, max_contrib zeroed, and tile_order = the tiles by descending bucket count (scan.hip)
+int launch_bucket_scan(int T, const uint2* ranges, uint32_t* bucket_offsets, uint32_t* max_contrib /* zeroed */, uint32_t* tile_order, hipStream_t s);
 
 struct RenderFwdArgs {
     int W, H, gx, gy, no_color;
@@ -41,6 +43,7 @@ struct RenderFwdArgs {
     const uint32_t* point_list;
     const float4* rec;
     const uint32_t* bucket_offsets;
+    const uint32_t* tile_order;  // [T] tiles by descending list length (NULL: identity) — the order the workgroups are handed out in
     uint32_t* bucket_to_tile;
     float4* ckpt;
     float4* pix_final;
@@ -64,7 +67,8 @@ struct RenderBwdArgs {
     const float4* pix_final;
     const uint32_t* max_contrib;
     const float* dL_dpix;
-    float4* partials;
+    float* partials;           // [9R] 36-byte rows, written for the instances of live buckets only
+    uint8_t* dead;             // [R] set to 1 for the instances of dead buckets (zeroed by the forward)
     const uint32_t* status;    // device status words: a non-zero [2] (capacity overflow in the forward) aborts the kernel
     int T;                     // tiles: bucket_offsets[T - 1] is the real bucket count (B may be a capacity)
 };
@@ -86,7 +90,8 @@ struct PreprocessBwdArgs {
     const float4* rec;
     const uint32_t* tiles_touched;
     const uint32_t* gauss_start;
-    const float4* partials;
+    const float* partials;
+    const uint8_t* dead;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_ddc, *dL_dsh, *dL_dscale, *dL_drot;
     float* dL_drgb;          // optional [P,3]: dL/d(SH colour) AFTER the clamp mask (backward.cu:41-44) — what the SH backward is linear in.
                              // When set it is written INSTEAD of dL_ddc (which must be NULL): the N > 1 exchange ships these 12 bytes per

@@ -344,11 +344,12 @@ __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
 
 // tile ranges of the sorted instance list (identifyTileRanges, rasterizer_impl.cu:131-156)
 __global__ __launch_bounds__(256) void finalize_ranges_kernel(uint32_t R_cap, const uint32_t* __restrict__ R_dev, const uint32_t* __restrict__ tiles,
-                                                              uint2* __restrict__ ranges)
+                                                              uint2* __restrict__ ranges, uint8_t* __restrict__ dead)
 {
     const uint32_t R = R_dev ? (*R_dev < R_cap ? *R_dev : R_cap) : R_cap;
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= R) return;
+    if (dead) dead[k] = 0;   // the backward's dead-instance flags (one byte per emission slot) start clear: a coalesced store riding on this pass
     const uint32_t tile = tiles[k];
     if (k == 0) {
         ranges[tile].x = 0;
@@ -379,10 +380,10 @@ int launch_keybuild(const KeybuildArgs& a, hipStream_t s)
     GS_LAUNCH(K_KEYBUILD, keybuild_kernel, dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
     return GSLIC_OK;
 }
-int launch_finalize_ranges(uint32_t R, const uint32_t* R_dev, const uint32_t* sorted_tiles, uint2* ranges, hipStream_t s)
+int launch_finalize_ranges(uint32_t R, const uint32_t* R_dev, const uint32_t* sorted_tiles, uint2* ranges, uint8_t* dead, hipStream_t s)
 {
     if (R == 0) return GSLIC_OK;
-    GS_LAUNCH(K_FINALIZE_LISTS, finalize_ranges_kernel, dim3((R + 255u) / 256u), dim3(256), 0, s, R, R_dev, sorted_tiles, ranges);
+    GS_LAUNCH(K_FINALIZE_LISTS, finalize_ranges_kernel, dim3((R + 255u) / 256u), dim3(256), 0, s, R, R_dev, sorted_tiles, ranges, dead);
     return GSLIC_OK;
 }
 }  // namespace gslic

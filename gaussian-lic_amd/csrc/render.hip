@@ -19,10 +19,6 @@
 #include "kernels.h"
 #include <stdlib.h>
 
-#ifndef GSLIC_STRICT_FWD_BRANCH
-#define GSLIC_STRICT_FWD_BRANCH 0   // A/B switch (tools/ab): 1 = the strict forward applies an entry under an exec mask instead of with selects
-#endif
-
 namespace gslic {
 
 // Upper bound of p2(x, y) = hA dx^2 + hC dy^2 + nB dx dy (dx = gx - x, dy = gy - y; a negative-definite form scaled by log2 e)
@@ -66,8 +62,15 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
 {
     constexpr int QN = 4 / SPLIT;          // strips (= pixels per lane) of this wave
     __shared__ float4 s_rec[3 * GS_BUCKET];
-    const int tile = blockIdx.x;
-    const int q0 = (int)blockIdx.y * QN;   // first strip of this wave
+    // 1-D grid in groups of 8 * SPLIT workgroups: workgroup b of a group works on tile rank 8 * group + b % 8, strips (b / 8) * QN...:
+    // consecutive workgroups go to consecutive XCDs (eight L2s), so the SPLIT waves of one tile land on the SAME XCD, a few dispatches
+    // apart — the second wave's fetch of the tile's records hits the L2 the first one filled.  tile_order (optional) lists the tiles by
+    // descending list length: the longest tiles start first and the short ones fill the tail of the launch.
+    const uint32_t grp = blockIdx.x / (8u * SPLIT), rem = blockIdx.x % (8u * SPLIT);
+    const uint32_t rank = grp * 8u + (rem & 7u);
+    if (rank >= (uint32_t)(a.gx * a.gy)) return;
+    const int tile = a.tile_order ? (int)a.tile_order[rank] : (int)rank;
+    const int q0 = (int)(rem >> 3) * QN;   // first strip of this wave
     const int lane = threadIdx.x;
     const int tx0 = (tile % a.gx) * GS_TILE, ty0 = (tile / a.gx) * GS_TILE;
     if (a.status[2] != 0u) return;  // capacity mode: the instance lists did not fit; the host re-runs the step with larger buffers
@@ -142,10 +145,10 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
             fhA = -0.5f * LOG2E * r0.z; fnB = -LOG2E * r0.w; fhC = -0.5f * LOG2E * r1.x;
             fop = r1.y; fr = r1.z; fg = r1.w; fb = r2.x;
             flop = __builtin_amdgcn_logf(fop);  // log2(opacity): alpha = exp2(p2 + log2 opacity), one multiply less per (pixel, entry)
-            // which of the tile's four 16x4 strips (= the four pixels of every lane) can this entry reach at all
+            // which of this wave's 16x4 strips (= the QN pixels of every lane) can this entry reach at all (bit q = strip q0 + q)
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float pm = strip_max_p2(fhA, fhC, fnB, fdx, fdy, 0.0f, 15.0f, (float)(4 * q), (float)(4 * q + 3));
+            for (int q = 0; q < QN; q++) {
+                const float pm = strip_max_p2(fhA, fhC, fnB, fdx, fdy, 0.0f, 15.0f, (float)(4 * (q0 + q)), (float)(4 * (q0 + q) + 3));
                 if (!(fop * __builtin_amdgcn_exp2f(pm) < 0.999f * (1.0f / 255.0f))) fmask |= 1u << q;
             }
         }
@@ -173,15 +176,14 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
         asm volatile("" : "+v"(vcontrib), "+v"(vone));
         auto blend_entry = [&](const float4 e0, const float4 e1, const float4 e2, const uint32_t contributor) {
             vcontrib += vone;  // == contributor, kept in a VGPR (an SGPR operand doubles the issue cost of the select that reads it)
-            const uint32_t smask = ((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(e2.y)) >> q0) & ((1u << QN) - 1u);  // this wave's strips
+            const uint32_t smask = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(e2.y));  // this wave's strips
             if (smask == 0u) return;
             const float gdx = e0.x, gdy = e0.y, hA = e0.z, nB = e0.w, hC = e1.x, op = e1.y, colr = e1.z, colg = e1.w, colb = e2.x;
             if constexpr (STRICT) {
 #pragma clang fp contract(off)
                 // forward.cu:424-445 operation for operation: d from absolute coordinates, the three products of the power rounded one by
-                // one, hipcc's expf (expf_core), opacity * exp, (colour * alpha) * T added to C.  Straight-line like the default variant:
-                // a pixel the entry does not blend into runs the same instructions with alpha forced to +0, which leaves C (>= 0), T and
-                // the last contributor unchanged bit for bit.  (-0.5f * s - c as one fma: halving is exact.)
+                // one, hipcc's expf (expf_core), opacity * exp, (colour * alpha) * T added to C; the entry is applied under an exec mask
+                // (measured against select-masked straight-line code: 0.39 vs 0.40 ms).  (-0.5f * s - c as one fma: halving is exact.)
                 const float dxs = gdx - pxf;              // float2 d = { xy.x - pixf.x, xy.y - pixf.y } (forward.cu:424)
                 const float ax = (hA * dxs) * dxs;        // con_o.x * d.x * d.x
                 const float bx = nB * dxs;                // con_o.y * d.x
@@ -193,26 +195,16 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
                     const float power = __builtin_fmaf(kmh, s2, -(bx * dys));
                     const float alpha = __builtin_amdgcn_fmed3f(op * expf_core(power, kL2E, kCC), ninf, c099);   // min(0.99f, con_o.w * exp(power))
                     const float test_T = T[q] * (vonef - alpha);
-                    const bool ok = (T[q] > kzero) & !(power > kzero) & !(alpha < c255);   // live pixel, forward.cu:431,437
-                    const bool stop = ok & (test_T < c1e4);                               // done; this entry is NOT applied (forward.cu:438-443)
-                    const bool app = ok & !stop;
-#if GSLIC_STRICT_FWD_BRANCH
-                    if (ok) {   // exec-masked: skipped when no pixel of the strip blends this entry
-                        if (stop) {
-                            T[q] = -T[q];
+                    // A finished pixel (T < 0) needs no test of its own: T (1 - alpha) is negative, hence "< 1e-4", and -|T| leaves it as it is
+                    if (!(power > kzero) & !(alpha < c255)) {   // forward.cu:431,437; exec-masked: skipped when no pixel of the strip blends this entry
+                        if (test_T < c1e4) {                    // done; this entry is NOT applied (forward.cu:438-443)
+                            T[q] = -__builtin_fabsf(T[q]);
                         } else {
                             Cr[q] = Cr[q] + (colr * alpha) * T[q]; Cg[q] = Cg[q] + (colg * alpha) * T[q]; Cb[q] = Cb[q] + (colb * alpha) * T[q];
                             T[q] = test_T;
                             last[q] = vcontrib;
                         }
                     }
-#else
-                    const float am = app ? alpha : kzero;
-                    Cr[q] = Cr[q] + (colr * am) * T[q]; Cg[q] = Cg[q] + (colg * am) * T[q]; Cb[q] = Cb[q] + (colb * am) * T[q];
-                    const float Tdone = stop ? -T[q] : T[q];
-                    T[q] = app ? test_T : Tdone;
-                    last[q] = app ? vcontrib : last[q];
-#endif
                 }
             } else {
                 // e1.y holds log2(opacity) here.  The operation sequence below is repeated verbatim by the backward (GS_BW_BODY), so both
@@ -228,12 +220,12 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
                     const float p2 = __builtin_fmaf(pB, dy, __builtin_fmaf(hC * dy, dy, pA));  // log2(e) * power + log2(opacity)
                     const float alpha = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(p2), ninf, c099);  // min(0.99, .) in one instruction, as GS_BW_BODY
                     const float test_T = T[q] * (1.0f - alpha);  // negative (so < 1e-4) once the pixel is done
-                    const bool ok = (T[q] > 0.f) & !(p2 > lop) & !(alpha < c255);   // forward.cu:431,437 on a live pixel
-                    const bool stop = ok & (test_T < c1e4);                         // done; this entry is NOT applied (forward.cu:438-443)
-                    const bool app = ok & !stop;
+                    const bool ok = !(p2 > lop) & !(alpha < c255);                  // forward.cu:431,437
+                    const bool stop = ok & (test_T < c1e4);                         // done; this entry is NOT applied (forward.cu:438-443) — always
+                    const bool app = ok & !stop;                                    // taken by a finished pixel: test_T < 0, and -|T| = T
                     const float w = app ? alpha * T[q] : 0.0f;
                     Cr[q] = __builtin_fmaf(colr, w, Cr[q]); Cg[q] = __builtin_fmaf(colg, w, Cg[q]); Cb[q] = __builtin_fmaf(colb, w, Cb[q]);
-                    const float Tdone = stop ? -T[q] : T[q];
+                    const float Tdone = stop ? -__builtin_fabsf(T[q]) : T[q];
                     T[q] = app ? test_T : Tdone;
                     last[q] = app ? vcontrib : last[q];
                 }
@@ -298,9 +290,10 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // What travels lane -> lane+1 is {T, A}: A = sum_ch ar[ch] * dL/dpixel[ch] replaces the colour vector ar[3] of the reference's
 // formulation (dL/dalpha only ever needs that dot product: dL/dalpha = A' / (1 - alpha) + T (c . g), A' = A + T alpha (c . g)): two
 // DPP moves per step instead of five.  Which pixel a lane works on does not travel at all: the schedule is static — lane L at step s
-// holds the pixel injected at step s - L — so the pixel's record {dL/dpixel, tag} is stored in LDS in INJECTION order and every lane
-// fetches record s - L with one ds_read_b128 at a per-lane address that advances by 16 bytes per step, one step ahead of its use
-// (64 consecutive records per read: no bank conflicts, no dependence on anything computed in the step).  alpha = min(0.99, exp2(p2 + log2 opacity)) with the SAME operation sequence as render_fwd
+// holds the pixel injected at step s - L — so the pixel's data {dL/dpixel, tag} and start state {T, A} are stored in LDS in INJECTION
+// order (three float2 arrays) and every lane fetches entry s - L with three ds_read_b64 at ONE per-lane byte offset that advances by
+// 8 per step, one step ahead of its use (64 consecutive entries per read: no bank conflicts, no dependence on anything computed in the
+// step); lane 0's {T, A} is the injection.  alpha = min(0.99, exp2(p2 + log2 opacity)) with the SAME operation sequence as render_fwd
 // (identical bits on both sides, so both take the same alpha < 1/255 decisions); the products with G = exp(power) that the reference
 // forms are written on a = opacity * G, dL/dopacity is divided by the opacity once per instance, and the conic factors of dL/dmean2D
 // (per-Gaussian constants) are applied once to sum w d instead of in every step.
@@ -315,9 +308,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 //
 // tag = rel << 16 | py << 8 | 16 px (rel = min(n_contrib - bucket start, 64) >= 1 for an injected pixel; the two low bytes are what
 // v_cvt_f32_ubyte0/1 turn into coordinates), 0 for an empty slot; kcmp < tag <=> lane < rel.
-// Before the first pixel reaches lane L (s < L) the lane reads whatever lies s - L records before the array — the start states, placed
-// there on purpose: finite numbers — while its travelling state is still T = A = 0, which makes every product of the step an exact zero
-// whatever the record says; behind the last pixel come 64 zero records.
+// The offset is clamped to [0, ninj] (one v_med3_i32): before the first pixel reaches lane L (s < L) the lane re-reads entry 0 while its
+// travelling state is still T = A = 0, which makes every product of the step an exact zero whatever the entry says (alpha <= 0.99 keeps
+// 1 / (1 - alpha) finite); behind the last pixel every lane reads entry ninj, all zeros (tag 0: nothing blends; T = A = 0 injected).
+// No slack entries, so the three arrays take 3 x 257 x 8 = 6168 bytes per wave (26 waves per CU; the unclamped layout with 64 spare
+// entries at either end took 7680: 21).
 // STRICT: delta, power and opacity * G of one (pixel, Gaussian) pair as backward.cu:539-542 / forward.cu:424-432 form them: the
 // reference's operations in source order, separately rounded (no contraction), and hipcc's expf().  -0.5f * s - c is written as ONE
 // fma(-0.5, s, -c): halving is exact (nothing is rounded before the subtraction), so the bits are those of multiply-then-subtract.
@@ -348,11 +343,16 @@ struct BwdLane {
                  "v_mov_b32_dpp %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf"                                           \
                  : "+v"(IT), "+v"(IA) : "v"(ST), "v"(SA))
 #define GS_BW_PREFETCH(NT, NA, NR)                                                                                   \
-    do { /* next injection: every lane reads the same address (a broadcast); next record: lane L reads record (step + 1) - L */ \
-        const float2 f2_ = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(smem) + ainit);            \
-        NR = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(smem) + arec);                           \
-        NT = f2_.x; NA = f2_.y;                                                                                      \
-        ainit += 8u; arec += 16u;                                                                                    \
+    do { /* entry (step + 1) - lane of the three arrays, clamped to [0, ninj]: entry 0 until the lane's first pixel arrives (its state is */ \
+         /* still T = A = 0, see above), the all-zero entry ninj once the last pixel has passed; lane 0's {T, A} is the next injection */     \
+        uint32_t oc_;                                                                                                \
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(oc_) : "v"(off), "v"(kzero_i), "v"(khi)); /* (the compiler emits min + cmp + select) */ \
+        const float2 rg_ = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(smem) + oc_);              \
+        const float2 bt_ = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(smem) + BW_OFF_BT + oc_);   \
+        const float2 ta_ = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(smem) + BW_OFF_TA + oc_);   \
+        NR = make_float4(rg_.x, rg_.y, bt_.x, bt_.y);                                                                \
+        NT = ta_.x; NA = ta_.y;                                                                                      \
+        off += keight;                                                                                               \
         __builtin_amdgcn_sched_barrier(0); /* keep the LDS reads at the top of the step: a whole step passes before they are used */ \
     } while (0)
 #define GS_BW_BODY(T_, A_, GR)                                                                                       \
@@ -400,12 +400,15 @@ struct BwdLane {
 template <bool STRICT>
 __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
 {
-    // [start states {T, A} of the pixels that reach this bucket, in injection order, + 64 empty entries][their records {dL/dpixel, tag}, same
-    // order, + 64 empty records]; the states come FIRST: they are what a lane reads as "records" before its first pixel arrives (see above)
-    constexpr int NENT = GS_TILE_PIX + 64;
-    __shared__ float4 smem[NENT / 2 + NENT];
-    float2* const init = reinterpret_cast<float2*>(smem);
-    float4* const grec = smem + NENT / 2;
+    // Three float2 arrays of 256 + 1 entries in injection order — {dL/dpixel.r, .g}, {dL/dpixel.b, tag}, {T, A} at the start of this bucket
+    // — read with ONE per-lane byte offset clamped to [0, ninj]: entry ninj is all zeros (what the pipeline takes in while the last pixels
+    // drain); no slack entries in front or behind.  6168 bytes per wave: 26 workgroups per CU (the 7.5 KB of the unclamped layout allowed 21).
+    constexpr int NENT = GS_TILE_PIX + 1;
+    constexpr uint32_t BW_OFF_BT = NENT * 8u, BW_OFF_TA = 2u * NENT * 8u;
+    __shared__ float2 smem[3 * NENT];
+    float2* const s_rg = smem;
+    float2* const s_bt = smem + NENT;
+    float2* const s_ta = smem + 2 * NENT;
     const int lane = threadIdx.x;
     const uint32_t bucket = blockIdx.x;
     if (a.status[2] != 0u || bucket >= a.bucket_offsets[a.T - 1]) return;  // capacity overflow in the forward / B was a capacity
@@ -418,12 +421,11 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     const bool valid = kit < n;
     const uint32_t slot = valid ? a.inst_slot[range.x + kit] : 0u;
 
-    // bucket entirely behind every pixel's last contributor (backward.cu:428): gradients are exactly zero
+    // bucket entirely behind every pixel's last contributor (backward.cu:428): its instances' gradients are exactly zero.  One flag byte
+    // per instance says so to preprocess_bwd (which then skips the row) instead of 36 bytes of zeros written here and read back there:
+    // on the 2M / 1080p scene 58 % of the buckets end here
     if (bstart >= a.max_contrib[tile]) {
-        if (valid) {
-            float4* o = a.partials + 3 * (size_t)slot;
-            o[0] = o[1] = o[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        if (valid) a.dead[slot] = 1;
         return;
     }
 
@@ -510,9 +512,6 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
         last = o > last ? o : last;
     }
     const uint32_t nsteps = readlane_u(last, 0);
-    // the 63 record-sized slots in front of the records (the tail of the start states: what lane L reads until its first pixel arrives)
-    // must hold finite numbers: zero them first — LDS operations of one wave complete in order, so real start states written below win
-    if (lane < 63) smem[NENT / 2 - 63 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const uint32_t pidx = (uint32_t)(c * 64 + lane);
@@ -520,12 +519,12 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
             float A0 = (ck[c].y - pf[c].x) * fg[c][0];  // ar = checkpoint colour - final colour (backward.cu:522-523), dotted with dL/dpixel
             A0 = __builtin_fmaf(ck[c].z - pf[c].y, fg[c][1], A0);
             A0 = __builtin_fmaf(ck[c].w - pf[c].z, fg[c][2], A0);
-            init[pos[c]] = make_float2(ck[c].x, A0);
-            grec[pos[c]] = make_float4(fg[c][0], fg[c][1], fg[c][2], __uint_as_float((rel[c] << 16) | ((pidx >> 4) << 8) | ((pidx & 15u) << 4)));
+            s_rg[pos[c]] = make_float2(fg[c][0], fg[c][1]);
+            s_bt[pos[c]] = make_float2(fg[c][2], __uint_as_float((rel[c] << 16) | ((pidx >> 4) << 8) | ((pidx & 15u) << 4)));
+            s_ta[pos[c]] = make_float2(ck[c].x, A0);
         }
     }
-    init[ninj + (uint32_t)lane] = make_float2(0.f, 0.f);   // what is injected while the last pixels drain (at most 63 steps)
-    grec[ninj + (uint32_t)lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane == 0) s_rg[ninj] = s_bt[ninj] = s_ta[ninj] = make_float2(0.f, 0.f);   // the drain entry (tag 0: no pair blends; T = A = 0)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -544,9 +543,9 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     // records alternate between Ra and Rb the same way.
     float T1 = 0.f, A1 = 0.f, T2, A2;
     float4 Ra, Rb;
-    uint32_t sidx = 0, ainit = 0;   // (byte offsets into smem; past the last pixel the empty entries follow: the drain needs no code of its own)
-    uint32_t arec = (uint32_t)(NENT / 2) * 16u - 16u * (uint32_t)lane;   // record (0 - lane): inside the start states for lane > 0
-    asm volatile("" : "+v"(ainit), "+v"(arec));
+    uint32_t sidx = 0;
+    int off = -8 * lane, kzero_i = 0, khi = 8 * (int)ninj, keight = 8;   // byte offset of entry (0 - lane); the clamp bounds; all in VGPRs
+    asm volatile("" : "+v"(off), "+v"(kzero_i), "+v"(khi), "+v"(keight));
     GS_BW_PREFETCH(T2, A2, Ra);
     for (;;) {
         GS_BW_SHIFT_INJ(T2, A2, T1, A1);   // set 2 = state
@@ -571,10 +570,12 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
             gx = __builtin_fmaf(2.0f * L.hAC.x, acc_S.x, L.nB * acc_S.y) * kx;
             gy = __builtin_fmaf(2.0f * L.hAC.y, acc_S.y, L.nB * acc_S.x) * ky;
         }
-        float4* o = a.partials + 3 * (size_t)slot;
-        o[0] = make_float4(gx, gy, -0.5f * acc_cxy.x, -0.5f * acc_cxy.y);
-        o[1] = make_float4(-0.5f * acc_cw, acc_op * rop, acc_rg.x, acc_rg.y);  // acc_op = sum of opacity * G * dL/dalpha (backward.cu:580 sums G * dL/dalpha)
-        o[2] = make_float4(acc_b, 0.f, 0.f, 0.f);   // (plain stores: 48-byte rows at scattered slots need the L2 to merge them — non-temporal: 0.59 -> 0.94 ms)
+        // nine floats, one 36-byte row per instance (dword-aligned wide stores; plain, not non-temporal: rows at scattered slots need the
+        // L2 to merge them — non-temporal: 0.59 -> 0.94 ms).  acc_op = sum of opacity * G * dL/dalpha (backward.cu:580 sums G * dL/dalpha)
+        float* o = a.partials + 9 * (size_t)slot;
+        *reinterpret_cast<gs_v4f_u*>(o) = (gs_v4f_u){gx, gy, -0.5f * acc_cxy.x, -0.5f * acc_cxy.y};
+        *reinterpret_cast<gs_v4f_u*>(o + 4) = (gs_v4f_u){-0.5f * acc_cw, acc_op * rop, acc_rg.x, acc_rg.y};
+        o[8] = acc_b;
     }
 }
 
@@ -585,11 +586,12 @@ int launch_render_fwd(const RenderFwdArgs& a, hipStream_t s)
     static const int forced = [] { const char* e = getenv("GSLIC_FWD_SPLIT"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
     const unsigned T = (unsigned)(a.gx * a.gy);
     const int split = forced ? forced : (T <= 16384u ? 2 : 1);
-    if (g_strict_math && split == 1) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 1>), dim3(T), dim3(64), 0, s, a);
-    else if (g_strict_math) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 2>), dim3(T, 2), dim3(64), 0, s, a);   // per-pixel arithmetic does not depend on the split
-    else if (split == 1) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<false, 1>), dim3(T), dim3(64), 0, s, a);
-    else if (split == 4) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<false, 4>), dim3(T, 4), dim3(64), 0, s, a);
-    else GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<false, 2>), dim3(T, 2), dim3(64), 0, s, a);
+    const unsigned groups = (T + 7u) / 8u;   // groups of 8 tiles x split waves (the kernel's blockIdx -> (tile rank, strips) mapping)
+    if (g_strict_math && split == 1) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 1>), dim3(groups * 8u), dim3(64), 0, s, a);
+    else if (g_strict_math) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 2>), dim3(groups * 16u), dim3(64), 0, s, a);   // per-pixel arithmetic does not depend on the split
+    else if (split == 1) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<false, 1>), dim3(groups * 8u), dim3(64), 0, s, a);
+    else if (split == 4) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<false, 4>), dim3(groups * 32u), dim3(64), 0, s, a);
+    else GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<false, 2>), dim3(groups * 16u), dim3(64), 0, s, a);
     return GSLIC_OK;
 }
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s)

@@ -7,6 +7,7 @@
 //                    tiles in parallel and reduce them to the carry-in.  Tiles are ticketed, so every tile a block waits for
 //                    has started.  Reads grow as nb^2 / 2 words, so above 1024 tiles it falls back to the three launches.
 #include "gslic_common.h"
+#include <stdlib.h>
 
 namespace gslic {
 
@@ -181,9 +182,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32
 // tiles' bucket counts and their inclusive scan in one single-block launch (rasterizer_impl.cu:433-441): T is the tile count of an
 // image, a few thousand
 __global__ __launch_bounds__(SCAN_THREADS) void bucket_scan_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ bucket_offsets,
-                                                                   uint32_t* __restrict__ max_contrib)
+                                                                   uint32_t* __restrict__ max_contrib, uint32_t* __restrict__ tile_order)
 {
     __shared__ uint32_t lds[8];
+    __shared__ uint32_t hist[256];   // tiles per bucket count (clipped to 255): a counting sort gives the longest-first launch order
+    hist[threadIdx.x] = 0;
+    __syncthreads();
     uint32_t carry = 0;
     for (int base = 0; base < T; base += SCAN_TILE) {
         const int t0 = base + (int)threadIdx.x * SCAN_ITEMS;
@@ -192,7 +196,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void bucket_scan_kernel(int T, const 
 #pragma unroll
         for (int i = 0; i < SCAN_ITEMS; i++) {
             uint32_t c = 0;
-            if (t0 + i < T) { const uint2 r = ranges[t0 + i]; c = (r.y - r.x + (GS_BUCKET - 1)) / GS_BUCKET; }
+            if (t0 + i < T) {
+                const uint2 r = ranges[t0 + i];
+                c = (r.y - r.x + (GS_BUCKET - 1)) / GS_BUCKET;
+                if (tile_order) atomicAdd(&hist[c < 255u ? c : 255u], 1u);
+            }
             v[i] = c; s += c;
         }
         uint32_t total;
@@ -204,10 +212,26 @@ __global__ __launch_bounds__(SCAN_THREADS) void bucket_scan_kernel(int T, const 
         }
         carry += total;
     }
+    if (!tile_order) return;
+    // tiles by DESCENDING bucket count: thread k owns key 255 - k; the order among equal counts is whatever the LDS atomics hand out
+    // (it only decides which workgroup index a tile gets in render_fwd, never a result)
+    __syncthreads();
+    uint32_t total;
+    const uint32_t mine = hist[255 - threadIdx.x];
+    const uint32_t start = block256_exclusive_prefix(mine, total, lds);
+    __syncthreads();
+    hist[255 - threadIdx.x] = start;
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += SCAN_THREADS) {
+        const uint2 r = ranges[t];
+        const uint32_t c = (r.y - r.x + (GS_BUCKET - 1)) / GS_BUCKET;
+        tile_order[atomicAdd(&hist[c < 255u ? c : 255u], 1u)] = (uint32_t)t;
+    }
 }
-int launch_bucket_scan(int T, const uint2* ranges, uint32_t* bucket_offsets, uint32_t* max_contrib, hipStream_t s)
+int launch_bucket_scan(int T, const uint2* ranges, uint32_t* bucket_offsets, uint32_t* max_contrib, uint32_t* tile_order, hipStream_t s)
 {
-    GS_LAUNCH(K_BUCKET_COUNT, bucket_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, T, ranges, bucket_offsets, max_contrib);
+    static const bool lpt = getenv("GSLIC_NO_TILE_ORDER") == nullptr;   // (A/B: identity order)
+    GS_LAUNCH(K_BUCKET_COUNT, bucket_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, T, ranges, bucket_offsets, max_contrib, lpt ? tile_order : (uint32_t*)nullptr);
     return GSLIC_OK;
 }
 
