@@ -48,3 +48,30 @@ def hip_backward(fwd, dL_dpix, lambda_erank=0.0):
 
 def npy(t):
     return t.detach().cpu().numpy()
+
+
+def hip_extend_rows(points, colors, depths_rsp, R_cw, t_cw, intr, W, H, final_T, M=15, scaling_scale=1.0):
+    """gslic_extend_select + gslic_extend_emit on a given transmittance image (what trainer.GaussianModel.extend runs after its no_color
+    render): returns (k, dict of the six new-Gaussian row tensors as numpy, ascending point index)."""
+    import ctypes
+    from gaussian_lic_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    pts, col, rsp, Rc, tc, fT = t(points), t(colors), t(depths_rsp), t(R_cw), t(t_cw), t(final_T)
+    n = int(pts.shape[0])
+    fx, fy, cx, cy = (float(v) for v in intr)
+    scratch = _lib.TensorAllocator(dev)
+    flags, pos, count = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int32(0)
+    p = _lib.ptr
+    _lib.check(L.gslic_extend_select(n, p(pts), p(rsp), p(Rc), p(tc), fx, fy, cx, cy, int(W), int(H), p(fT), scratch.cb, None, ctypes.byref(flags),
+                                     ctypes.byref(pos), ctypes.byref(count), _lib.current_stream_ptr()))
+    k = count.value
+    rows = dict(xyz=torch.empty(k, 3, device=dev), dc=torch.empty(k, 1, 3, device=dev), rest=torch.empty(k, M, 3, device=dev),
+                opacity=torch.empty(k, 1, device=dev), scaling=torch.empty(k, 3, device=dev), rotation=torch.empty(k, 4, device=dev))
+    if k:
+        q = lambda x: ctypes.c_void_p(x.data_ptr()) if x.numel() else None
+        _lib.check(L.gslic_extend_emit(n, flags, pos, p(pts), p(col), p(rsp), float(scaling_scale), (fx + fy) / 2.0, int(M), q(rows["xyz"]), q(rows["dc"]),
+                                       q(rows["rest"]), q(rows["opacity"]), q(rows["scaling"]), q(rows["rotation"]), _lib.current_stream_ptr()))
+    torch.cuda.synchronize()
+    return k, {key: v.cpu().numpy() for key, v in rows.items()}

@@ -51,6 +51,55 @@ def test_oracle_extend_select_properties(oracle32):
     assert np.allclose(rows["dc"][:, 0], (col[keep] - 0.5) / 0.28209479177387814, atol=1e-6)
 
 
+GOLDEN_FRAMES = ["extend_identity_96x64", "extend_rot90_160x120", "extend_ties_33x17"]
+
+
+def _golden_frame(name):
+    """tests/golden/extend_*.npz: a LiDAR frame and what the REFERENCE's own extend() (gaussian.cpp:499-638, compiled unmodified on CPU
+    LibTorch by oracle/ref_build/make_extend_golden.py) appended for it — the survivor set (ascending frame indices; the reference's own
+    order is unordered_map iteration order) and the six new-Gaussian tensors in that order."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    R_wc, t_wc = g["R_wc"], g["t_wc"]
+    R_cw = R_wc.T                                    # gaussian.cpp:527-530, in double like the reference's Eigen types, then cast (:531-539)
+    t_cw = -R_cw @ t_wc
+    return g, R_cw.astype(np.float32), t_cw.astype(np.float32)
+
+
+@pytest.mark.parametrize("name", GOLDEN_FRAMES)
+def test_oracle_extend_equals_reference_golden(oracle32, name):
+    """The oracle's selection and new-Gaussian rows against the reference's own extend(): frames with several returns per pixel,
+    equal-depth ties, points off the image / behind the camera, non-positive sensor depths, alpha exactly at the 0.99 cut."""
+    g, R_cw, t_cw = _golden_frame(name)
+    fx, fy, cx, cy = (float(v) for v in g["intr"])
+    W, H = (int(v) for v in g["size"])
+    keep = oracle32.extend_select(g["points"], g["depths_rsp"], R_cw, t_cw, fx, fy, cx, cy, W, H, g["final_T"])
+    np.testing.assert_array_equal(np.nonzero(keep)[0], g["keep"])
+    assert g["keep"].size > 100
+    rows = oracle32.extend_emit(keep, g["points"], g["colors"], g["depths_rsp"], 1.0, 0.5 * (fx + fy), 15)
+    for key in ("xyz", "rest", "rotation"):
+        np.testing.assert_array_equal(rows[key].reshape(g["row_" + key].shape), g["row_" + key])
+    for key in ("dc", "opacity", "scaling"):        # (c - 0.5) / C0, log(0.1 / 0.9), log(range / focal): libm vs LibTorch's vectorised log
+        assert rel_err(rows[key].reshape(g["row_" + key].shape), g["row_" + key]) < 1e-6, key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GOLDEN_FRAMES)
+def test_hip_extend_equals_reference_golden(name):
+    """gslic_extend_select / gslic_extend_emit (the 64-bit atomic-min z-buffer that replaces the reference's CPU hash map) against the
+    reference's own extend(): identical survivor set, identical rows."""
+    from gpu_helpers import hip_extend_rows
+    g, R_cw, t_cw = _golden_frame(name)
+    W, H = (int(v) for v in g["size"])
+    k, rows = hip_extend_rows(g["points"], g["colors"], g["depths_rsp"], R_cw, t_cw, g["intr"], W, H, g["final_T"])
+    assert k == g["keep"].size
+    np.testing.assert_array_equal(rows["xyz"], g["row_xyz"])            # ascending index on both sides: same set <=> same rows
+    np.testing.assert_array_equal(rows["rest"], g["row_rest"])
+    np.testing.assert_array_equal(rows["rotation"], g["row_rotation"])
+    for key in ("dc", "opacity", "scaling"):
+        assert rel_err(rows[key], g["row_" + key]) < 1e-6, key
+
+
 @pytest.mark.gpu
 def test_extend_matches_oracle_and_appends_in_place(oracle32):
     import gaussian_lic_amd  # noqa: F401
