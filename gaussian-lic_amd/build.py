@@ -30,7 +30,7 @@ SOURCES = {
     "knn.hip": [],
     "extend.hip": ["-ffp-contract=off"],  # pixel assignment decides integers: canonical order like preprocess.hip
 }
-COMMON = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
+COMMON = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wno-inline-asm",
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]
 HEADERS = ["gslic_common.h", "kernels.h", os.path.join("..", "..", "include", "gslic_hip.h")]
 

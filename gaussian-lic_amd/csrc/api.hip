@@ -125,6 +125,7 @@ SampleState SampleState::carve(const void* base, size_t B, size_t* bytes)
     SampleState g;
     g.bucket_to_tile = c.take<uint32_t>(B);
     g.ckpt = c.take<float4>(B * GS_TILE_PIX);
+    g.hit = c.take<uint64_t>(B * GS_TILE_PIX);
     if (bytes) *bytes = c.used(base) + 256;
     return g;
 }
@@ -457,7 +458,7 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
     ra.ranges = img.ranges; ra.point_list = bin.point_list(); ra.rec = geom.rec; ra.bucket_offsets = img.bucket_offsets;
     static const bool tile_lpt = getenv("GSLIC_NO_TILE_ORDER") == nullptr;
     ra.tile_order = (no_color || !tile_lpt) ? nullptr : img.tile_order;   // (written by the bucket scan, which a no_color forward skips)
-    ra.bucket_to_tile = smp.bucket_to_tile; ra.ckpt = smp.ckpt; ra.pix_final = img.pix_final; ra.max_contrib = img.max_contrib;
+    ra.bucket_to_tile = smp.bucket_to_tile; ra.ckpt = smp.ckpt; ra.hit = smp.hit; ra.pix_final = img.pix_final; ra.max_contrib = img.max_contrib;
     ra.out_color = out_color; ra.out_final_T = out_final_T; ra.capB = B; ra.status = geom.flags;
     GS_TRY(launch_render_fwd(ra, s));
     DEBUG_SYNC(prm, s);
@@ -545,7 +546,7 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
     RenderBwdArgs rb;
     rb.W = prm->width; rb.H = prm->height; rb.gx = gx; rb.B = B;
     rb.ranges = img.ranges; rb.point_list = bin.point_list(); rb.inst_slot = bin.inst_slot(); rb.rec = geom.rec;
-    rb.bucket_offsets = img.bucket_offsets; rb.bucket_to_tile = smp.bucket_to_tile; rb.ckpt = smp.ckpt; rb.pix_final = img.pix_final;
+    rb.bucket_offsets = img.bucket_offsets; rb.bucket_to_tile = smp.bucket_to_tile; rb.ckpt = smp.ckpt; rb.hit = smp.hit; rb.pix_final = img.pix_final;
     rb.max_contrib = img.max_contrib; rb.dL_dpix = dL_dpix; rb.partials = bin.partials; rb.dead = bin.dead; rb.status = geom.flags; rb.T = T;
     GS_TRY(launch_render_bwd(rb, s));
     DEBUG_SYNC(prm, s);

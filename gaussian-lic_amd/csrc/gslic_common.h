@@ -63,6 +63,7 @@ enum KernelId {
 void prof_begin(int id, hipStream_t s);
 void prof_end(int id, hipStream_t s);
 extern bool g_prof_on;
+#define GS_FLAG_HITBITS 4   // index into GeomState::flags: set by a forward that recorded SampleState::hit
 extern int g_strict_math;  // gslic_set_math_mode(): 1 (default) = blend kernels in the reference's arithmetic (render.hip), 0 = fast (GSLIC_FAST_MATH=1)
 
 #define GS_LAUNCH(id, kernel, grid, block, shmem, stream, ...)                                             \
@@ -180,6 +181,8 @@ struct BinningState {
 struct SampleState {
     uint32_t* bucket_to_tile; // [B]
     float4* ckpt;             // [B*256] {T, C.r, C.g, C.b} at the start of each bucket, per pixel
+    uint64_t* hit;            // [B*4*64] per bucket, 16x4 pixel strip q and list entry j: which of the strip's 64 pixels (bit = the forward's lane:
+                              // (row & 3) * 16 + column) blended entry j — written by the strict forward, read by the strict backward
     static SampleState carve(const void* base, size_t B, size_t* bytes);
 };
 

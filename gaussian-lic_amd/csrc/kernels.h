@@ -46,6 +46,7 @@ struct RenderFwdArgs {
     const uint32_t* tile_order;  // [T] tiles by descending list length (NULL: identity) — the order the workgroups are handed out in
     uint32_t* bucket_to_tile;
     float4* ckpt;
+    uint64_t* hit;             // SampleState::hit (written by the strict variant only, which then sets status[GS_FLAG_HITBITS])
     float4* pix_final;
     uint32_t* max_contrib;
     float* out_color;
@@ -64,6 +65,7 @@ struct RenderBwdArgs {
     const uint32_t* bucket_offsets;
     const uint32_t* bucket_to_tile;
     const float4* ckpt;
+    const uint64_t* hit;       // SampleState::hit (valid when status[GS_FLAG_HITBITS] != 0)
     const float4* pix_final;
     const uint32_t* max_contrib;
     const float* dL_dpix;

@@ -8,7 +8,7 @@
 //   it can reach at all; a checkpoint {T, C} per pixel is stored at every 64th entry (bucket = one wave of entries) as one coalesced
 //   1-KiB dwordx4 store per strip.  One wave per workgroup: no barrier anywhere.
 //
-// render_bwd_kernel<STRICT>  replaces PerGaussianRenderCUDA<3> (backward.cu:379-597)
+// render_bwd_kernel<BITS>  replaces PerGaussianRenderCUDA<3> (backward.cu:379-597)
 //   ONE WAVE PER BUCKET of 64 list entries: lane = Gaussian, the tile's pixels stream through the lanes as a 64-deep systolic
 //   pipeline.  Two values per pixel, {T, A = ar . dL/dpixel}, move lane -> lane+1 with one v_mov_b32 DPP wave_shr:1 each; the
 //   schedule is static, so every lane fetches the record {dL/dpixel, tag} of the pixel it holds from LDS at a per-lane address one
@@ -58,7 +58,7 @@ __device__ __forceinline__ float strip_max_p2(float hA, float hC, float nB, floa
 // longest tiles (one wave alone on a SIMD issues a VALU instruction every 4.3 cycles, half the rate of a busy SIMD), so the default
 // splits every tile over two waves: +9 % instructions (the per-entry setup is repeated), half the latency of a long tile.
 template <bool STRICT, int SPLIT>
-__global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
+__global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(RenderFwdArgs a)
 {
     constexpr int QN = 4 / SPLIT;          // strips (= pixels per lane) of this wave
     __shared__ float4 s_rec[3 * GS_BUCKET];
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
     const int lane = threadIdx.x;
     const int tx0 = (tile % a.gx) * GS_TILE, ty0 = (tile / a.gx) * GS_TILE;
     if (a.status[2] != 0u) return;  // capacity mode: the instance lists did not fit; the host re-runs the step with larger buffers
+    if (STRICT && !a.no_color && blockIdx.x == 0 && lane == 0) a.status[GS_FLAG_HITBITS] = 1u;   // this forward records SampleState::hit
     const uint2 range = a.ranges[tile];
     const int n = (int)(range.y - range.x);
     const bool color = !a.no_color;
@@ -174,6 +175,11 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
         // which leaves its colour, transmittance and last contributor unchanged bit for bit; only the per-strip skip (wave-uniform) branches
         uint32_t vcontrib = (uint32_t)base, vone = 1u;
         asm volatile("" : "+v"(vcontrib), "+v"(vone));
+        // STRICT: lane j collects, per strip, WHICH pixels blended entry j of this batch (one bit per lane = pixel of the strip).  The strict
+        // backward takes its blend / skip decisions from these bits instead of re-deriving them: they ARE the reference's decisions.
+        uint32_t hlo[QN], hhi[QN];
+#pragma unroll
+        for (int q = 0; q < QN; q++) hlo[q] = hhi[q] = 0u;
         auto blend_entry = [&](const float4 e0, const float4 e1, const float4 e2, const uint32_t contributor) {
             vcontrib += vone;  // == contributor, kept in a VGPR (an SGPR operand doubles the issue cost of the select that reads it)
             const uint32_t smask = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(e2.y));  // this wave's strips
@@ -196,8 +202,18 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
                     const float alpha = __builtin_amdgcn_fmed3f(op * expf_core(power, kL2E, kCC), ninf, c099);   // min(0.99f, con_o.w * exp(power))
                     const float test_T = T[q] * (vonef - alpha);
                     // A finished pixel (T < 0) needs no test of its own: T (1 - alpha) is negative, hence "< 1e-4", and -|T| leaves it as it is
-                    if (!(power > kzero) & !(alpha < c255)) {   // forward.cu:431,437; exec-masked: skipped when no pixel of the strip blends this entry
-                        if (test_T < c1e4) {                    // done; this entry is NOT applied (forward.cu:438-443)
+                    const bool cand = !(power > kzero) & !(alpha < c255);   // forward.cu:431,437
+                    const bool stop = test_T < c1e4;                        // done; this entry is NOT applied (forward.cu:438-443)
+                    {   // record the pixels that apply this entry: lane j of hlo / hhi <- the 64-bit mask (scalar values; SALU only)
+                        const uint64_t am = __builtin_amdgcn_ballot_w64(!(power > kzero)) & __builtin_amdgcn_ballot_w64(!(alpha < c255)) &
+                                            ~__builtin_amdgcn_ballot_w64(stop);
+                        const int jl = (int)(contributor - 1u) & (GS_BUCKET - 1);
+                        // (v_writelane_b32 with two scalar sources: the lane select goes through M0 on gfx9)
+                        asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                            : "+v"(hlo[q]), "+v"(hhi[q]) : "s"((uint32_t)am), "s"((uint32_t)(am >> 32)), "s"(jl) : "m0");
+                    }
+                    if (cand) {   // exec-masked: skipped when no pixel of the strip blends this entry
+                        if (stop) {
                             T[q] = -__builtin_fabsf(T[q]);
                         } else {
                             Cr[q] = Cr[q] + (colr * alpha) * T[q]; Cg[q] = Cg[q] + (colg * alpha) * T[q]; Cb[q] = Cb[q] + (colb * alpha) * T[q];
@@ -242,6 +258,13 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(RenderFwdArgs a)
             a0 = s_rec[3 * ja]; a1 = s_rec[3 * ja + 1]; a2 = s_rec[3 * ja + 2];
             blend_entry(b0, b1, b2, (uint32_t)(base + j + 2));
         }
+        if constexpr (STRICT) {
+            if (color && fits) {   // one coalesced 512-byte store per strip: entry j's mask from lane j (zero for skipped strips and j >= m)
+                uint64_t* hp = a.hit + ((size_t)(bbm + (uint32_t)(base / GS_BUCKET)) * 4 + (size_t)q0) * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < QN; q++) hp[q * 64] = ((uint64_t)hhi[q] << 32) | hlo[q];
+            }
+        }
     }
 
     uint32_t mymax = 0;
@@ -282,10 +305,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define GS_SPLAT(x) ((v2f){(x), (x)})
 
 // =========================================================================================================
-// Backward: ONE WAVE PER BUCKET, lane = Gaussian, the tile's pixels stream through the lanes.  STRICT (gslic_set_math_mode(1)) changes only
-// how a pair's alpha is formed — the reference's operations in source order (absolute pixel coordinates, power as backward.cu:541,
-// expf, opacity * G, IEEE divide for 1 / (1 - alpha), contraction off), so every blend / skip decision is the strict forward's and the
-// reference's — the pipeline around it is the same; the text below describes the default (fast) arithmetic.
+// Backward: ONE WAVE PER BUCKET, lane = Gaussian, the tile's pixels stream through the lanes.  The two modes (gslic_set_math_mode) differ in
+// where the blend / skip decision of a pair comes from (BITS, below), not in the pipeline or in the arithmetic of a contribution.
 //
 // What travels lane -> lane+1 is {T, A}: A = sum_ch ar[ch] * dL/dpixel[ch] replaces the colour vector ar[3] of the reference's
 // formulation (dL/dalpha only ever needs that dot product: dL/dalpha = A' / (1 - alpha) + T (c . g), A' = A + T alpha (c . g)): two
@@ -313,21 +334,14 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // 1 / (1 - alpha) finite); behind the last pixel every lane reads entry ninj, all zeros (tag 0: nothing blends; T = A = 0 injected).
 // No slack entries, so the three arrays take 3 x 257 x 8 = 6168 bytes per wave (26 waves per CU; the unclamped layout with 64 spare
 // entries at either end took 7680: 21).
-// STRICT: delta, power and opacity * G of one (pixel, Gaussian) pair as backward.cu:539-542 / forward.cu:424-432 form them: the
-// reference's operations in source order, separately rounded (no contraction), and hipcc's expf().  -0.5f * s - c is written as ONE
-// fma(-0.5, s, -c): halving is exact (nothing is rounded before the subtraction), so the bits are those of multiply-then-subtract.
-__device__ __forceinline__ void strict_pair(v2f mean, v2f pix, v2f cAC, float cB, float op, float kL2E, float kCC, float kmh, v2f& d, float& power,
-                                            float& araw)
-{
-#pragma clang fp contract(off)
-    d = mean - pix;
-    const v2f t = (cAC * d) * d;          // {A dx dx, C dy dy}
-    const float s = t.x + t.y;
-    const float c = (cB * d.x) * d.y;
-    power = __builtin_fmaf(kmh, s, -c);
-    araw = op * expf_core(power, kL2E, kCC);
-}
-
+// BITS (the strict mode, gslic_set_math_mode(1), the default): which (pixel, Gaussian) pairs blend is not re-derived at all — the strict forward
+// recorded, per bucket, strip and list entry, the 64-bit mask of the strip's pixels that applied the entry (SampleState::hit), and those bits
+// ARE the reference's decisions (lane < n_contrib - bucket start, power <= 0, alpha >= 1/255: backward.cu:538-546), since the strict forward is
+// bit-identical to the reference's.  Lane L keeps its entry's 256 bits in LDS ([dword 0..7][lane]: conflict-free) and tests the bit of the
+// pixel it holds: tag = dword << 24 | (31 - bit) << 16 | py << 8 | 16 px, so dword offset and shift come out of one v_lshrrev.  What a pair
+// CONTRIBUTES is computed with the arithmetic described above in both modes (within a few ulp of the reference's; gradients are sums
+// of ~1e2..1e4 such terms in an order that differs from the reference's atomics anyway).  A forward that recorded no bits (fast mode, or
+// the mode was switched in between) leaves status[GS_FLAG_HITBITS] = 0 and the kernel re-derives the decisions like the fast variant.
 struct BwdLane {
     v2f d0, hAC, col_rg;          // centre relative to the tile origin; log2(e)-scaled conic diagonal {-1/2 A, -1/2 C}; colour r, g
     float nB, lop, colb;          // log2(e)-scaled -B; log2(opacity); colour b
@@ -355,32 +369,31 @@ struct BwdLane {
         off += keight;                                                                                               \
         __builtin_amdgcn_sched_barrier(0); /* keep the LDS reads at the top of the step: a whole step passes before they are used */ \
     } while (0)
-#define GS_BW_BODY(T_, A_, GR)                                                                                       \
+#define GS_BW_BODY(USE_BITS, T_, A_, GR)                                                                             \
     do {                                                                                                             \
         const float4 gr = GR;                                                                                        \
         const uint32_t TAG = __float_as_uint(gr.w);                                                                  \
-        const v2f pxy16 = {(float)(TAG & 0xffu), (float)((TAG >> 8) & 0xffu)}; /* v_cvt_f32_ubyte0 / ubyte1: {16 px, py} */ \
-        v2f d;                                                                                                       \
-        float araw;                                                                                                  \
-        bool hit;                                                                                                    \
-        if constexpr (STRICT) {                                                                                      \
-            const v2f pix = GS_PK_FMA(pxy16, kneg, torg); /* exact: tile origin + {px, py} (kneg = {1/16, 1} here) */ \
-            float power;                                                                                             \
-            strict_pair(L.d0, pix, L.hAC, L.nB, L.lop, kL2E, kCC, kmh, d, power, araw);                              \
-            hit = (kcmp < TAG) & !(power > kzero) & !(araw < c255);                                                  \
-        } else {                                                                                                     \
-            d = GS_PK_FMA(pxy16, kneg, L.d0); /* exact: d0 - {px, py} */                                             \
-            float p2 = __builtin_fmaf(L.hAC.x * d.x, d.x, L.lop); /* the operation sequence of render_fwd */         \
-            p2 = __builtin_fmaf(L.hAC.y * d.y, d.y, p2);                                                             \
-            p2 = __builtin_fmaf(L.nB * d.x, d.y, p2); /* = log2(e) * power + log2(opacity) */                        \
-            araw = __builtin_amdgcn_exp2f(p2); /* opacity * G */                                                     \
-            /* lane < n_contrib - bucket start (backward.cu:538), power <= 0, alpha >= 1/255 (:543-546; min(0.99, a) < 1/255 iff a < 1/255) */ \
-            hit = (kcmp < TAG) & !(p2 > L.lop) & !(araw < c255);                                                     \
+        uint32_t hword = 0, hsel = 0;                                                                                \
+        if (USE_BITS) { /* this lane's 32 recorded bits around the pixel it holds: issued first, used after the exponential */ \
+            hsel = TAG >> 16;                                                                                        \
+            uint32_t ha_;                                                                                            \
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ha_) : "v"(hsel), "v"(k700), "v"(lane4));                       \
+            hword = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_hit) + ha_);                  \
         }                                                                                                            \
+        const v2f pxy16 = {(float)(TAG & 0xffu), (float)((TAG >> 8) & 0xffu)}; /* v_cvt_f32_ubyte0 / ubyte1: {16 px, py} */ \
+        const v2f d = GS_PK_FMA(pxy16, kneg, L.d0); /* exact: d0 - {px, py} */                                       \
+        float p2 = __builtin_fmaf(L.hAC.x * d.x, d.x, L.lop); /* the operation sequence of render_fwd<false> */      \
+        p2 = __builtin_fmaf(L.hAC.y * d.y, d.y, p2);                                                                 \
+        p2 = __builtin_fmaf(L.nB * d.x, d.y, p2); /* = log2(e) * power + log2(opacity) */                            \
+        const float araw = __builtin_amdgcn_exp2f(p2); /* opacity * G */                                             \
+        bool hit;                                                                                                    \
+        if (USE_BITS) hit = (int)(hword << (hsel & 31u)) < 0; /* the strict forward blended this pair (v_lshlrev takes the low 5 bits itself) */ \
+        /* lane < n_contrib - bucket start (backward.cu:538), power <= 0, alpha >= 1/255 (:543-546; min(0.99, a) < 1/255 iff a < 1/255) */ \
+        else hit = (kcmp < TAG) & !(p2 > L.lop) & !(araw < c255);                                                    \
         const float ah = hit ? araw : 0.0f; /* one select masks both alpha and the gradient weight */                \
         const float alpha = __builtin_amdgcn_fmed3f(ah, ninf, c099); /* min(0.99, .) without the canonicalising v_max fminf costs */ \
         const float om = 1.0f - alpha;                                                                               \
-        const float rinv = __builtin_amdgcn_rcpf(om); /* both modes: 1 / (1 - alpha) scales a gradient term, it decides nothing (<= 1 ulp) */ \
+        const float rinv = __builtin_amdgcn_rcpf(om); /* 1 / (1 - alpha) scales a gradient term, it decides nothing (<= 1 ulp) */   \
         const float Ta = T_ * alpha;                                                                                 \
         float cg = L.col_rg.x * gr.x;                                                                                \
         cg = __builtin_fmaf(L.col_rg.y, gr.y, cg);                                                                   \
@@ -397,7 +410,7 @@ struct BwdLane {
         acc_op += w; /* divided by the opacity at the end */                                                         \
     } while (0)
 
-template <bool STRICT>
+template <bool BITS>
 __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
 {
     // Three float2 arrays of 256 + 1 entries in injection order — {dL/dpixel.r, .g}, {dL/dpixel.b, tag}, {T, A} at the start of this bucket
@@ -409,9 +422,11 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     float2* const s_rg = smem;
     float2* const s_bt = smem + NENT;
     float2* const s_ta = smem + 2 * NENT;
+    __shared__ uint32_t s_hit[BITS ? 8 * 64 : 1];   // BITS: [dword k = py >> 1][lane]: the 256 recorded bits of this lane's list entry
     const int lane = threadIdx.x;
     const uint32_t bucket = blockIdx.x;
     if (a.status[2] != 0u || bucket >= a.bucket_offsets[a.T - 1]) return;  // capacity overflow in the forward / B was a capacity
+    const bool use_bits = BITS && a.status[GS_FLAG_HITBITS] != 0u;         // (wave-uniform) the forward recorded its blend decisions
     const uint32_t tile = a.bucket_to_tile[bucket];
     const uint2 range = a.ranges[tile];
     const uint32_t n = range.y - range.x;
@@ -453,21 +468,15 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     BwdLane L;
     L.d0 = L.hAC = L.col_rg = (v2f){0.f, 0.f};
     L.nB = L.colb = 0.f;
-    L.lop = STRICT ? 0.f : -__builtin_inff();  // a lane without a Gaussian: alpha = exp2(-inf) = 0 (STRICT: opacity 0), never blends
+    L.lop = -__builtin_inff();  // a lane without a Gaussian: alpha = exp2(-inf) = 0, contributes nothing whatever the decision bits say
     float rop = 0.f;            // 1 / opacity
     if (valid) {
         const uint32_t g = a.point_list[range.x + kit];
         const float4* rp = a.rec + GS_REC_F4 * (size_t)g;
         const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-        if constexpr (STRICT) {   // absolute mean, the conic and the opacity as stored
-            L.d0.x = r0.x; L.d0.y = r0.y;
-            L.hAC.x = r0.z; L.nB = r0.w; L.hAC.y = r1.x;
-            L.lop = r1.y;
-        } else {
-            L.d0.x = r0.x - (float)tx0; L.d0.y = r0.y - (float)ty0;
-            L.hAC.x = -0.5f * LOG2E * r0.z; L.nB = -LOG2E * r0.w; L.hAC.y = -0.5f * LOG2E * r1.x;
-            L.lop = __builtin_amdgcn_logf(r1.y);
-        }
+        L.d0.x = r0.x - (float)tx0; L.d0.y = r0.y - (float)ty0;
+        L.hAC.x = -0.5f * LOG2E * r0.z; L.nB = -LOG2E * r0.w; L.hAC.y = -0.5f * LOG2E * r1.x;
+        L.lop = __builtin_amdgcn_logf(r1.y);
         rop = r1.y > 0.f ? 1.0f / r1.y : 0.f;
         L.col_rg.x = r1.z; L.col_rg.y = r1.w; L.colb = r2.x;
     }
@@ -520,22 +529,33 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
             A0 = __builtin_fmaf(ck[c].z - pf[c].y, fg[c][1], A0);
             A0 = __builtin_fmaf(ck[c].w - pf[c].z, fg[c][2], A0);
             s_rg[pos[c]] = make_float2(fg[c][0], fg[c][1]);
-            s_bt[pos[c]] = make_float2(fg[c][2], __uint_as_float((rel[c] << 16) | ((pidx >> 4) << 8) | ((pidx & 15u) << 4)));
+            const uint32_t py = pidx >> 4, pxl = pidx & 15u;
+            const uint32_t hi = use_bits ? (((py >> 1) << 24) | ((31u - (((py & 1u) << 4) | pxl)) << 16)) : (rel[c] << 16);
+            s_bt[pos[c]] = make_float2(fg[c][2], __uint_as_float(hi | (py << 8) | (pxl << 4)));
             s_ta[pos[c]] = make_float2(ck[c].x, A0);
         }
     }
-    if (lane == 0) s_rg[ninj] = s_bt[ninj] = s_ta[ninj] = make_float2(0.f, 0.f);   // the drain entry (tag 0: no pair blends; T = A = 0)
+    if (lane == 0) s_rg[ninj] = s_bt[ninj] = s_ta[ninj] = make_float2(0.f, 0.f);   // the drain entry (T = A = 0 injected: nothing it meets contributes)
+    if constexpr (BITS) {
+        if (use_bits) {   // entry `lane` of this bucket: four 64-bit masks (one per 16x4 strip), coalesced 512-byte loads
+            const uint64_t* hp = a.hit + (size_t)bucket * GS_TILE_PIX + lane;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint64_t m = hp[q * 64];
+                s_hit[(2 * q) * 64 + lane] = (uint32_t)m;
+                s_hit[(2 * q + 1) * 64 + lane] = (uint32_t)(m >> 32);
+            }
+        }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     // loop constants in VGPRs: a literal or SGPR operand doubles the issue cost of the instruction that reads it
     float c099 = 0.99f, c255 = 1.0f / 255.0f, ninf = -__builtin_inff();
-    v2f kneg = STRICT ? (v2f){0.0625f, 1.0f} : (v2f){-0.0625f, -1.0f};
-    v2f torg = {(float)tx0, (float)ty0};   // (STRICT: absolute pixel coordinates = tile origin + in-tile offset)
+    v2f kneg = {-0.0625f, -1.0f};
     uint32_t kcmp = ((uint32_t)lane << 16) | 0xffffu;
-    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(ninf), "+v"(kneg), "+v"(kcmp), "+v"(torg));
-    float kL2E = GS_EXP_L2E, kCC = GS_EXP_CC, kmh = -0.5f, kzero = 0.0f;   // STRICT only (dead registers otherwise)
-    if constexpr (STRICT) asm volatile("" : "+v"(kL2E), "+v"(kCC), "+v"(kmh), "+v"(kzero));
+    uint32_t k700 = 0x700u, lane4 = 4u * (uint32_t)lane;   // BITS: dword select mask (byte offset k * 256) and this lane's column
+    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(ninf), "+v"(kneg), "+v"(kcmp), "+v"(k700), "+v"(lane4));
     v2f acc_S = {0.f, 0.f}, acc_cxy = {0.f, 0.f}, acc_rg = {0.f, 0.f};
     float acc_cw = 0, acc_op = 0, acc_b = 0;
     // {T, A}: the state travelling through the lanes (set 1) and the injection fetched one step ahead (set 2); a step shifts set 1
@@ -546,30 +566,27 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     uint32_t sidx = 0;
     int off = -8 * lane, kzero_i = 0, khi = 8 * (int)ninj, keight = 8;   // byte offset of entry (0 - lane); the clamp bounds; all in VGPRs
     asm volatile("" : "+v"(off), "+v"(kzero_i), "+v"(khi), "+v"(keight));
-    GS_BW_PREFETCH(T2, A2, Ra);
-    for (;;) {
-        GS_BW_SHIFT_INJ(T2, A2, T1, A1);   // set 2 = state
-        GS_BW_PREFETCH(T1, A1, Rb);
-        GS_BW_BODY(T2, A2, Ra);
-        if (++sidx >= nsteps) break;
-        GS_BW_SHIFT_INJ(T1, A1, T2, A2);   // set 1 = state
-        GS_BW_PREFETCH(T2, A2, Ra);
-        GS_BW_BODY(T1, A1, Rb);
-        if (++sidx >= nsteps) break;
+#define GS_BW_LOOP(USE_BITS)                                                                                         \
+    GS_BW_PREFETCH(T2, A2, Ra);                                                                                      \
+    for (;;) {                                                                                                       \
+        GS_BW_SHIFT_INJ(T2, A2, T1, A1); /* set 2 = state */                                                         \
+        GS_BW_PREFETCH(T1, A1, Rb);                                                                                  \
+        GS_BW_BODY(USE_BITS, T2, A2, Ra);                                                                            \
+        if (++sidx >= nsteps) break;                                                                                 \
+        GS_BW_SHIFT_INJ(T1, A1, T2, A2); /* set 1 = state */                                                         \
+        GS_BW_PREFETCH(T2, A2, Ra);                                                                                  \
+        GS_BW_BODY(USE_BITS, T1, A1, Rb);                                                                            \
+        if (++sidx >= nsteps) break;                                                                                 \
     }
+    if (use_bits) { GS_BW_LOOP(true) } else { GS_BW_LOOP(false) }
+#undef GS_BW_LOOP
 
     if (valid) {
         // acc_S = sum of w d (w = G dL/dG): dL/dmean2D = -(0.5 W, 0.5 H) o (A S.x + B S.y, C S.y + B S.x) (backward.cu:566-573), written on the
         // log2(e)-scaled conic the lane holds: A = -2 hA / log2 e, B = -nB / log2 e
-        float gx, gy;
-        if constexpr (STRICT) {   // the lane holds A, B, C themselves
-            gx = -(L.hAC.x * acc_S.x + L.nB * acc_S.y) * (0.5f * (float)a.W);
-            gy = -(L.hAC.y * acc_S.y + L.nB * acc_S.x) * (0.5f * (float)a.H);
-        } else {
-            const float kx = 0.5f * (float)a.W / LOG2E, ky = 0.5f * (float)a.H / LOG2E;
-            gx = __builtin_fmaf(2.0f * L.hAC.x, acc_S.x, L.nB * acc_S.y) * kx;
-            gy = __builtin_fmaf(2.0f * L.hAC.y, acc_S.y, L.nB * acc_S.x) * ky;
-        }
+        const float kx = 0.5f * (float)a.W / LOG2E, ky = 0.5f * (float)a.H / LOG2E;
+        const float gx = __builtin_fmaf(2.0f * L.hAC.x, acc_S.x, L.nB * acc_S.y) * kx;
+        const float gy = __builtin_fmaf(2.0f * L.hAC.y, acc_S.y, L.nB * acc_S.x) * ky;
         // nine floats, one 36-byte row per instance (dword-aligned wide stores; plain, not non-temporal: rows at scattered slots need the
         // L2 to merge them — non-temporal: 0.59 -> 0.94 ms).  acc_op = sum of opacity * G * dL/dalpha (backward.cu:580 sums G * dL/dalpha)
         float* o = a.partials + 9 * (size_t)slot;

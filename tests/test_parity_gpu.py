@@ -285,3 +285,33 @@ def test_degenerate_shapes(oracle32, case):
     for k in ("dL_dmean3D", "dL_dopacity", "dL_ddc", "dL_dsh", "dL_dscale"):
         if rg[k].size and np.abs(rg[k]).max() > 0:
             assert rel_err(g[k].reshape(rg[k].shape), rg[k]) < 1e-4, k
+
+
+def test_math_mode_switched_between_forward_and_backward():
+    """The strict backward takes its blend decisions from bits the strict forward recorded.  A forward that ran in the fast mode records
+    none: the strict backward must then re-derive them (= the fast backward, bit for bit) instead of reading unwritten memory; a fast
+    backward behind a strict forward ignores the bits."""
+    from gpu_helpers import hip_backward, hip_forward
+    from gaussian_lic_amd import _lib
+    from gaussian_lic_amd.synthetic import pixel_grad
+    raw, sc, camd, cam = make_scene("random", 30000, 320, 240, 3, 9)
+    dL = pixel_grad(240, 320, seed=1)
+    prev = _lib.set_math_mode(False)
+    try:
+        f_fast = hip_forward(raw, cam)
+        g_ff = hip_backward(f_fast, dL)
+        _lib.set_math_mode(True)
+        g_fs = hip_backward(f_fast, dL)            # strict backward, no recorded bits
+        f_strict = hip_forward(raw, cam)
+        g_ss = hip_backward(f_strict, dL)
+        _lib.set_math_mode(False)
+        g_sf = hip_backward(f_strict, dL)          # fast backward behind a strict forward
+    finally:
+        _lib.set_math_mode(prev)
+    for k in g_ff:
+        np.testing.assert_array_equal(g_fs[k], g_ff[k], err_msg=k)
+        assert np.all(np.isfinite(g_ss[k])) and np.all(np.isfinite(g_sf[k])), k
+        scale = max(float(np.abs(g_ss[k]).max()), 1e-30)
+        if k == "dL_drot":
+            scale = max(scale, float(np.abs(g_ss["dL_dscale"]).max() * sc["scales"].max()))
+        assert float(np.abs(g_sf[k] - g_ss[k]).max()) / scale < 2e-2, k   # the same gradients up to a handful of flipped cuts
