@@ -175,13 +175,15 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
         // which leaves its colour, transmittance and last contributor unchanged bit for bit; only the per-strip skip (wave-uniform) branches
         uint32_t vcontrib = (uint32_t)base, vone = 1u;
         asm volatile("" : "+v"(vcontrib), "+v"(vone));
-        // STRICT: lane j collects, per strip, WHICH pixels blended entry j of this batch (one bit per lane = pixel of the strip).  The strict
-        // backward takes its blend / skip decisions from these bits instead of re-deriving them: they ARE the reference's decisions.
-        uint32_t hlo[QN], hhi[QN];
+        // STRICT: every pixel collects WHICH entries of this batch it blended (bit j = entry j; one dword at a time: hcur rolls over into
+        // hfirst at entry 32).  The strict backward takes its blend / skip decisions from these bits instead of re-deriving them: they ARE the
+        // reference's decisions.
+        uint32_t hcur[QN], hfirst[QN], vbit = 0u;
 #pragma unroll
-        for (int q = 0; q < QN; q++) hlo[q] = hhi[q] = 0u;
+        for (int q = 0; q < QN; q++) hcur[q] = hfirst[q] = 0u;
         auto blend_entry = [&](const float4 e0, const float4 e1, const float4 e2, const uint32_t contributor) {
             vcontrib += vone;  // == contributor, kept in a VGPR (an SGPR operand doubles the issue cost of the select that reads it)
+            if constexpr (STRICT) vbit = 1u << ((contributor - 1u) & 31u);   // (wave-uniform; one v_mov per entry)
             const uint32_t smask = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(e2.y));  // this wave's strips
             if (smask == 0u) return;
             const float gdx = e0.x, gdy = e0.y, hA = e0.z, nB = e0.w, hC = e1.x, op = e1.y, colr = e1.z, colg = e1.w, colb = e2.x;
@@ -204,14 +206,6 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
                     // A finished pixel (T < 0) needs no test of its own: T (1 - alpha) is negative, hence "< 1e-4", and -|T| leaves it as it is
                     const bool cand = !(power > kzero) & !(alpha < c255);   // forward.cu:431,437
                     const bool stop = test_T < c1e4;                        // done; this entry is NOT applied (forward.cu:438-443)
-                    {   // record the pixels that apply this entry: lane j of hlo / hhi <- the 64-bit mask (scalar values; SALU only)
-                        const uint64_t am = __builtin_amdgcn_ballot_w64(!(power > kzero)) & __builtin_amdgcn_ballot_w64(!(alpha < c255)) &
-                                            ~__builtin_amdgcn_ballot_w64(stop);
-                        const int jl = (int)(contributor - 1u) & (GS_BUCKET - 1);
-                        // (v_writelane_b32 with two scalar sources: the lane select goes through M0 on gfx9)
-                        asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-                            : "+v"(hlo[q]), "+v"(hhi[q]) : "s"((uint32_t)am), "s"((uint32_t)(am >> 32)), "s"(jl) : "m0");
-                    }
                     if (cand) {   // exec-masked: skipped when no pixel of the strip blends this entry
                         if (stop) {
                             T[q] = -__builtin_fabsf(T[q]);
@@ -219,6 +213,7 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
                             Cr[q] = Cr[q] + (colr * alpha) * T[q]; Cg[q] = Cg[q] + (colg * alpha) * T[q]; Cb[q] = Cb[q] + (colb * alpha) * T[q];
                             T[q] = test_T;
                             last[q] = vcontrib;
+                            hcur[q] |= vbit;   // this pixel blended this entry
                         }
                     }
                 }
@@ -250,6 +245,12 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
         // two entries per trip: the records alternate between two register sets, each fetched (LDS broadcast) while the other is blended
         float4 a0 = s_rec[0], a1 = s_rec[1], a2 = s_rec[2], b0, b1, b2;
         for (int j = 0; j < m; j += 2) {
+            if constexpr (STRICT) {
+                if (j == 32) {
+#pragma unroll
+                    for (int q = 0; q < QN; q++) { hfirst[q] = hcur[q]; hcur[q] = 0u; }
+                }
+            }
             const int jb = (j + 1 < m) ? j + 1 : j;   // (no second entry: a harmless re-read)
             b0 = s_rec[3 * jb]; b1 = s_rec[3 * jb + 1]; b2 = s_rec[3 * jb + 2];
             blend_entry(a0, a1, a2, (uint32_t)(base + j + 1));
@@ -259,10 +260,11 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
             blend_entry(b0, b1, b2, (uint32_t)(base + j + 2));
         }
         if constexpr (STRICT) {
-            if (color && fits) {   // one coalesced 512-byte store per strip: entry j's mask from lane j (zero for skipped strips and j >= m)
-                uint64_t* hp = a.hit + ((size_t)(bbm + (uint32_t)(base / GS_BUCKET)) * 4 + (size_t)q0) * 64 + lane;
+            if (color && fits) {   // pixel-major like the checkpoints: one coalesced 512-byte store per strip
+                uint64_t* hp = a.hit + ((size_t)(bbm + (uint32_t)(base / GS_BUCKET)) * GS_TILE_PIX) + lane;
 #pragma unroll
-                for (int q = 0; q < QN; q++) hp[q * 64] = ((uint64_t)hhi[q] << 32) | hlo[q];
+                for (int q = 0; q < QN; q++)
+                    hp[(q0 + q) * 64] = m > 32 ? (((uint64_t)hcur[q] << 32) | hfirst[q]) : (uint64_t)hcur[q];
             }
         }
     }
@@ -335,13 +337,13 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // No slack entries, so the three arrays take 3 x 257 x 8 = 6168 bytes per wave (26 waves per CU; the unclamped layout with 64 spare
 // entries at either end took 7680: 21).
 // BITS (the strict mode, gslic_set_math_mode(1), the default): which (pixel, Gaussian) pairs blend is not re-derived at all — the strict forward
-// recorded, per bucket, strip and list entry, the 64-bit mask of the strip's pixels that applied the entry (SampleState::hit), and those bits
-// ARE the reference's decisions (lane < n_contrib - bucket start, power <= 0, alpha >= 1/255: backward.cu:538-546), since the strict forward is
-// bit-identical to the reference's.  Lane L keeps its entry's 256 bits in LDS ([dword 0..7][lane]: conflict-free) and tests the bit of the
-// pixel it holds: tag = dword << 24 | (31 - bit) << 16 | py << 8 | 16 px, so dword offset and shift come out of one v_lshrrev.  What a pair
-// CONTRIBUTES is computed with the arithmetic described above in both modes (within a few ulp of the reference's; gradients are sums
-// of ~1e2..1e4 such terms in an order that differs from the reference's atomics anyway).  A forward that recorded no bits (fast mode, or
-// the mode was switched in between) leaves status[GS_FLAG_HITBITS] = 0 and the kernel re-derives the decisions like the fast variant.
+// recorded, per bucket and pixel, the 64-bit mask of the bucket's list entries the pixel blended (SampleState::hit, pixel-major like the
+// checkpoints), and those bits ARE the reference's decisions (lane < n_contrib - bucket start, power <= 0, alpha >= 1/255:
+// backward.cu:538-546), since the strict forward is bit-identical to the reference's.  The mask travels with the pixel's other data (a fourth
+// float2-sized array at the same clamped offset) and lane L tests bit L of it: a select of the dword, one shift, one compare.  What a pair
+// CONTRIBUTES is computed with the arithmetic described above in both modes (within a few ulp of the reference's; gradients are sums of
+// 1e2..1e4 such terms in an order that differs from the reference's atomics anyway).  A forward that recorded no bits (fast mode, or the mode
+// was switched in between) leaves status[GS_FLAG_HITBITS] = 0 and the kernel re-derives the decisions like the fast variant.
 struct BwdLane {
     v2f d0, hAC, col_rg;          // centre relative to the tile origin; log2(e)-scaled conic diagonal {-1/2 A, -1/2 C}; colour r, g
     float nB, lop, colb;          // log2(e)-scaled -B; log2(opacity); colour b
@@ -356,30 +358,24 @@ struct BwdLane {
     asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                           \
                  "v_mov_b32_dpp %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf"                                           \
                  : "+v"(IT), "+v"(IA) : "v"(ST), "v"(SA))
-#define GS_BW_PREFETCH(NT, NA, NR)                                                                                   \
-    do { /* entry (step + 1) - lane of the three arrays, clamped to [0, ninj]: entry 0 until the lane's first pixel arrives (its state is */ \
-         /* still T = A = 0, see above), the all-zero entry ninj once the last pixel has passed; lane 0's {T, A} is the next injection */     \
+#define GS_BW_PREFETCH(USE_BITS, NT, NA, NR, NH)                                                                     \
+    do { /* entry (step + 1) - lane of the arrays, clamped to [0, ninj]: entry 0 until the lane's first pixel arrives (its state is still */ \
+         /* T = A = 0, see above), the all-zero entry ninj once the last pixel has passed; lane 0's {T, A} is the next injection */          \
         uint32_t oc_;                                                                                                \
         asm("v_med3_i32 %0, %1, %2, %3" : "=v"(oc_) : "v"(off), "v"(kzero_i), "v"(khi)); /* (the compiler emits min + cmp + select) */ \
         const float2 rg_ = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(smem) + oc_);              \
         const float2 bt_ = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(smem) + BW_OFF_BT + oc_);   \
         const float2 ta_ = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(smem) + BW_OFF_TA + oc_);   \
+        if (USE_BITS) NH = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(smem) + BW_OFF_HM + oc_);    \
         NR = make_float4(rg_.x, rg_.y, bt_.x, bt_.y);                                                                \
         NT = ta_.x; NA = ta_.y;                                                                                      \
         off += keight;                                                                                               \
         __builtin_amdgcn_sched_barrier(0); /* keep the LDS reads at the top of the step: a whole step passes before they are used */ \
     } while (0)
-#define GS_BW_BODY(USE_BITS, T_, A_, GR)                                                                             \
+#define GS_BW_BODY(USE_BITS, T_, A_, GR, GH)                                                                         \
     do {                                                                                                             \
         const float4 gr = GR;                                                                                        \
         const uint32_t TAG = __float_as_uint(gr.w);                                                                  \
-        uint32_t hword = 0, hsel = 0;                                                                                \
-        if (USE_BITS) { /* this lane's 32 recorded bits around the pixel it holds: issued first, used after the exponential */ \
-            hsel = TAG >> 16;                                                                                        \
-            uint32_t ha_;                                                                                            \
-            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ha_) : "v"(hsel), "v"(k700), "v"(lane4));                       \
-            hword = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_hit) + ha_);                  \
-        }                                                                                                            \
         const v2f pxy16 = {(float)(TAG & 0xffu), (float)((TAG >> 8) & 0xffu)}; /* v_cvt_f32_ubyte0 / ubyte1: {16 px, py} */ \
         const v2f d = GS_PK_FMA(pxy16, kneg, L.d0); /* exact: d0 - {px, py} */                                       \
         float p2 = __builtin_fmaf(L.hAC.x * d.x, d.x, L.lop); /* the operation sequence of render_fwd<false> */      \
@@ -387,7 +383,7 @@ struct BwdLane {
         p2 = __builtin_fmaf(L.nB * d.x, d.y, p2); /* = log2(e) * power + log2(opacity) */                            \
         const float araw = __builtin_amdgcn_exp2f(p2); /* opacity * G */                                             \
         bool hit;                                                                                                    \
-        if (USE_BITS) hit = (int)(hword << (hsel & 31u)) < 0; /* the strict forward blended this pair (v_lshlrev takes the low 5 bits itself) */ \
+        if (USE_BITS) hit = (int)((hi_half ? GH.y : GH.x) << kshl) < 0; /* bit `lane` of the pixel's mask: the strict forward blended this pair */ \
         /* lane < n_contrib - bucket start (backward.cu:538), power <= 0, alpha >= 1/255 (:543-546; min(0.99, a) < 1/255 iff a < 1/255) */ \
         else hit = (kcmp < TAG) & !(p2 > L.lop) & !(araw < c255);                                                    \
         const float ah = hit ? araw : 0.0f; /* one select masks both alpha and the gradient weight */                \
@@ -414,15 +410,16 @@ template <bool BITS>
 __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
 {
     // Three float2 arrays of 256 + 1 entries in injection order — {dL/dpixel.r, .g}, {dL/dpixel.b, tag}, {T, A} at the start of this bucket
-    // — read with ONE per-lane byte offset clamped to [0, ninj]: entry ninj is all zeros (what the pipeline takes in while the last pixels
-    // drain); no slack entries in front or behind.  6168 bytes per wave: 26 workgroups per CU (the 7.5 KB of the unclamped layout allowed 21).
+    // (BITS: a fourth with the pixels' decision masks) — read with ONE per-lane byte offset clamped to [0, ninj]: entry ninj is all zeros
+    // (what the pipeline takes in while the last pixels drain); no slack entries in front or behind.  6168 bytes per wave: 26 workgroups per CU
+    // (the 7.5 KB of the unclamped layout allowed 21).
     constexpr int NENT = GS_TILE_PIX + 1;
-    constexpr uint32_t BW_OFF_BT = NENT * 8u, BW_OFF_TA = 2u * NENT * 8u;
-    __shared__ float2 smem[3 * NENT];
+    constexpr uint32_t BW_OFF_BT = NENT * 8u, BW_OFF_TA = 2u * NENT * 8u, BW_OFF_HM = 3u * NENT * 8u;
+    __shared__ float2 smem[(BITS ? 4 : 3) * NENT];   // BITS: + the pixels' recorded 64-bit decision masks (8224 bytes per wave: 19 per CU)
     float2* const s_rg = smem;
     float2* const s_bt = smem + NENT;
     float2* const s_ta = smem + 2 * NENT;
-    __shared__ uint32_t s_hit[BITS ? 8 * 64 : 1];   // BITS: [dword k = py >> 1][lane]: the 256 recorded bits of this lane's list entry
+    uint2* const s_hm = reinterpret_cast<uint2*>(smem + 3 * NENT);   // (BITS only)
     const int lane = threadIdx.x;
     const uint32_t bucket = blockIdx.x;
     if (a.status[2] != 0u || bucket >= a.bucket_offsets[a.T - 1]) return;  // capacity overflow in the forward / B was a capacity
@@ -450,10 +447,15 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     float4 ck[4], pf[4];
     float fg[4][3];
     bool inside[4];
+    uint2 hm[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const int pidx = c * 64 + lane;
         ck[c] = a.ckpt[(size_t)bucket * GS_TILE_PIX + pidx];
+        hm[c] = make_uint2(0u, 0u);
+        if constexpr (BITS) {
+            if (use_bits) { const uint64_t m = a.hit[(size_t)bucket * GS_TILE_PIX + pidx]; hm[c] = make_uint2((uint32_t)m, (uint32_t)(m >> 32)); }
+        }
         pf[c] = a.pix_final[(size_t)tile * GS_TILE_PIX + pidx];
         const int px = tx0 + (pidx & 15), py = ty0 + (pidx >> 4);
         inside[c] = px < a.W && py < a.H;
@@ -529,23 +531,14 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
             A0 = __builtin_fmaf(ck[c].z - pf[c].y, fg[c][1], A0);
             A0 = __builtin_fmaf(ck[c].w - pf[c].z, fg[c][2], A0);
             s_rg[pos[c]] = make_float2(fg[c][0], fg[c][1]);
-            const uint32_t py = pidx >> 4, pxl = pidx & 15u;
-            const uint32_t hi = use_bits ? (((py >> 1) << 24) | ((31u - (((py & 1u) << 4) | pxl)) << 16)) : (rel[c] << 16);
-            s_bt[pos[c]] = make_float2(fg[c][2], __uint_as_float(hi | (py << 8) | (pxl << 4)));
+            s_bt[pos[c]] = make_float2(fg[c][2], __uint_as_float((rel[c] << 16) | ((pidx >> 4) << 8) | ((pidx & 15u) << 4)));
+            if constexpr (BITS) s_hm[pos[c]] = hm[c];
             s_ta[pos[c]] = make_float2(ck[c].x, A0);
         }
     }
-    if (lane == 0) s_rg[ninj] = s_bt[ninj] = s_ta[ninj] = make_float2(0.f, 0.f);   // the drain entry (T = A = 0 injected: nothing it meets contributes)
-    if constexpr (BITS) {
-        if (use_bits) {   // entry `lane` of this bucket: four 64-bit masks (one per 16x4 strip), coalesced 512-byte loads
-            const uint64_t* hp = a.hit + (size_t)bucket * GS_TILE_PIX + lane;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint64_t m = hp[q * 64];
-                s_hit[(2 * q) * 64 + lane] = (uint32_t)m;
-                s_hit[(2 * q + 1) * 64 + lane] = (uint32_t)(m >> 32);
-            }
-        }
+    if (lane == 0) {   // the drain entry (tag 0, mask 0: no pair blends; T = A = 0 injected)
+        s_rg[ninj] = s_bt[ninj] = s_ta[ninj] = make_float2(0.f, 0.f);
+        if constexpr (BITS) s_hm[ninj] = make_uint2(0u, 0u);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -554,8 +547,9 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     float c099 = 0.99f, c255 = 1.0f / 255.0f, ninf = -__builtin_inff();
     v2f kneg = {-0.0625f, -1.0f};
     uint32_t kcmp = ((uint32_t)lane << 16) | 0xffffu;
-    uint32_t k700 = 0x700u, lane4 = 4u * (uint32_t)lane;   // BITS: dword select mask (byte offset k * 256) and this lane's column
-    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(ninf), "+v"(kneg), "+v"(kcmp), "+v"(k700), "+v"(lane4));
+    uint32_t kshl = 31u - ((uint32_t)lane & 31u);   // BITS: moves bit `lane & 31` of the mask's dword into the sign position
+    const bool hi_half = lane >= 32;                // ... of the dword this lane's bit lives in
+    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(ninf), "+v"(kneg), "+v"(kcmp), "+v"(kshl));
     v2f acc_S = {0.f, 0.f}, acc_cxy = {0.f, 0.f}, acc_rg = {0.f, 0.f};
     float acc_cw = 0, acc_op = 0, acc_b = 0;
     // {T, A}: the state travelling through the lanes (set 1) and the injection fetched one step ahead (set 2); a step shifts set 1
@@ -563,19 +557,20 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     // records alternate between Ra and Rb the same way.
     float T1 = 0.f, A1 = 0.f, T2, A2;
     float4 Ra, Rb;
+    uint2 Ha = make_uint2(0u, 0u), Hb = make_uint2(0u, 0u);
     uint32_t sidx = 0;
     int off = -8 * lane, kzero_i = 0, khi = 8 * (int)ninj, keight = 8;   // byte offset of entry (0 - lane); the clamp bounds; all in VGPRs
     asm volatile("" : "+v"(off), "+v"(kzero_i), "+v"(khi), "+v"(keight));
 #define GS_BW_LOOP(USE_BITS)                                                                                         \
-    GS_BW_PREFETCH(T2, A2, Ra);                                                                                      \
+    GS_BW_PREFETCH(USE_BITS, T2, A2, Ra, Ha);                                                                        \
     for (;;) {                                                                                                       \
         GS_BW_SHIFT_INJ(T2, A2, T1, A1); /* set 2 = state */                                                         \
-        GS_BW_PREFETCH(T1, A1, Rb);                                                                                  \
-        GS_BW_BODY(USE_BITS, T2, A2, Ra);                                                                            \
+        GS_BW_PREFETCH(USE_BITS, T1, A1, Rb, Hb);                                                                    \
+        GS_BW_BODY(USE_BITS, T2, A2, Ra, Ha);                                                                        \
         if (++sidx >= nsteps) break;                                                                                 \
         GS_BW_SHIFT_INJ(T1, A1, T2, A2); /* set 1 = state */                                                         \
-        GS_BW_PREFETCH(T2, A2, Ra);                                                                                  \
-        GS_BW_BODY(USE_BITS, T1, A1, Rb);                                                                            \
+        GS_BW_PREFETCH(USE_BITS, T2, A2, Ra, Ha);                                                                    \
+        GS_BW_BODY(USE_BITS, T1, A1, Rb, Hb);                                                                        \
         if (++sidx >= nsteps) break;                                                                                 \
     }
     if (use_bits) { GS_BW_LOOP(true) } else { GS_BW_LOOP(false) }

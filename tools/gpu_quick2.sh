@@ -9,6 +9,6 @@ for cfg in "$@"; do
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); k = d['kernel_ms_per_step']; print('$cfg', d['value'], 'views/s', d['ms_per_step'], 'ms', {n: k[n] for n in ('render_bwd', 'preprocess_bwd', 'render_fwd', 'preprocess')}, 'dom', d['roofline']['kernel'], d['roofline']['avg_launch_ms'])
+        d = json.loads(l); k = d['kernel_ms_per_step_instrumented']; print('$cfg', d['value'], 'views/s', d['ms_per_step'], 'ms', {n: k[n] for n in ('render_bwd', 'preprocess_bwd', 'render_fwd', 'preprocess')}, 'dom', d['roofline']['kernel'], d['roofline']['avg_launch_ms'])
 "
 done

@@ -7,6 +7,6 @@ GSLIC_FWD_SPLIT=$sp timeout 300 python bench.py --steps 100 --no-cpu-baseline --
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); k = d['kernel_ms_per_step']; print('$cfg split $sp', d['value'], 'views/s', {n: k[n] for n in ('render_bwd', 'render_fwd')})
+        d = json.loads(l); k = d['kernel_ms_per_step_instrumented']; print('$cfg split $sp', d['value'], 'views/s', {n: k[n] for n in ('render_bwd', 'render_fwd')})
 "
 done; done

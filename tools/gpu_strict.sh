@@ -7,6 +7,6 @@ GSLIC_FWD_SPLIT=$sp GSLIC_STRICT_MATH=1 timeout 300 python bench.py --steps 100 
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); k = d['kernel_ms_per_step']; print('strict split $sp', d['value'], 'views/s', d['ms_per_step'], 'ms', {n: k[n] for n in ('render_bwd', 'preprocess_bwd', 'render_fwd', 'preprocess')})
+        d = json.loads(l); k = d['kernel_ms_per_step_instrumented']; print('strict split $sp', d['value'], 'views/s', d['ms_per_step'], 'ms', {n: k[n] for n in ('render_bwd', 'preprocess_bwd', 'render_fwd', 'preprocess')})
 "
 done
