@@ -235,3 +235,99 @@ def test_rccl_two_ranks_two_gpus():
         assert p.returncode == 0, se[-2000:]
     d = [[l for l in so.splitlines() if l.startswith("DIGEST")][-1].split()[2] for so, _ in outs]
     assert d[0] == d[1]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# N = 4 and N = 8 (one view per rank, ONE exchange per optimiser step), every rank a process of its own sharing the box's
+# one GPU, gloo on device tensors.  What can be proven without the 8-GPU node: (1) the exchanged gradients equal the sum over the views
+# of the single-GPU gradients (1e-5 of the group's max-abs; the reduction order is the backend's) and the mask is the OR of the views'
+# masks, exactly; (2) after three complete steps every replica holds the same bits, for the rank-1 and the dense exchange.
+N_RANK_SNIPPET = r"""
+import os, sys, hashlib, numpy as np, torch
+sys.path.insert(0, {root!r})
+import gaussian_lic_amd
+from gaussian_lic_amd import trainer
+from gaussian_lic_amd.camera import synthetic_camera
+from gaussian_lic_amd.synthetic import random_scene, gt_image
+rank, world, task, out = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), os.environ["GSLIC_TEST_TASK"], os.environ["GSLIC_TEST_OUT"]
+nviews = int(os.environ.get("GSLIC_TEST_VIEWS", world))
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+W, H, P = 320, 192, 30000
+bg = torch.zeros(3, device=dev)
+model = trainer.GaussianModel(random_scene(P, W, H, 3, 5), dev); model.training_setup()
+def digest(m):
+    h = hashlib.sha256()
+    for t in (m.xyz, m.features_dc, m.features_rest, m.opacity, m.scaling, m.rotation):
+        h.update(t.detach().cpu().numpy().tobytes())
+    return h.hexdigest()
+if task == "reference":      # one process: the per-view gradients of views 0..nviews-1, summed in float64, masks OR-ed
+    acc, vis = None, None
+    for k in range(nviews):
+        cam = synthetic_camera(W, H, k).to_device(dev); gt = gt_image(H, W, seed=2 + k).to(dev)
+        _, v = trainer.training_step_fused(model, cam, gt, bg, do_step=False, adam_in_backward=False)
+        f = model._grad_slab.flat.double().cpu().numpy()
+        acc = f if acc is None else acc + f
+        vis = v.cpu().numpy() if vis is None else (vis | v.cpu().numpy())
+    np.savez(out, flat=acc, vis=vis, sizes=np.array([model._grad_slab.views[n].numel() for n in model.NAMES]))
+else:
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    cam = synthetic_camera(W, H, rank).to_device(dev); gt = gt_image(H, W, seed=2 + rank).to(dev)
+    if task == "grads":      # one exchange, no optimiser: what the ranks agree on
+        model.optimizer.step = lambda *a, **k: None
+        if hasattr(model.optimizer, "step_sh_from_rgb"):
+            model.optimizer.step_sh_from_rgb = lambda *a, **k: None
+        _, v = trainer.training_step_fused(model, cam, gt, bg)
+        torch.cuda.synchronize()
+        if rank == 0:
+            np.savez(out, flat=model._grad_slab.flat.double().cpu().numpy(), vis=v.cpu().numpy())
+    else:                    # three complete steps
+        for _ in range(3):
+            trainer.training_step_fused(model, cam, gt, bg)
+        torch.cuda.synchronize()
+        print("DIGEST", rank, digest(model))
+    torch.distributed.barrier(); torch.distributed.destroy_process_group()
+"""
+
+
+def _spawn_ranks(world, task, mode, port, out, extra_env=None):
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ)
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   GSLIC_EXCHANGE=mode, GSLIC_TEST_TASK=task, GSLIC_TEST_OUT=out)
+        env.update(extra_env or {})
+        env.pop("GSLIC_FORCE_DIST", None); env.pop("GSLIC_SPARSE_EXCHANGE", None)
+        procs.append(subprocess.Popen([sys.executable, "-c", N_RANK_SNIPPET.format(root=ROOT)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=1200) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    return [so for so, _ in outs]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [4, 8])
+def test_n_ranks_exchanged_gradients_equal_the_sum_over_views(world, tmp_path):
+    import numpy as np
+    ref_file = str(tmp_path / "ref.npz")
+    _spawn_ranks(1, "reference", "dense", 29601 + world, ref_file, {"GSLIC_TEST_VIEWS": str(world)})
+    ref = np.load(ref_file)
+    offs = np.concatenate([[0], np.cumsum(ref["sizes"])])
+    for mode, port in (("dense", 29611 + world), ("rank1", 29621 + world)):
+        got_file = str(tmp_path / f"got_{mode}.npz")
+        # rank-1: rebuild the SH rows into the slab (the fused rebuild + Adam kernel never materialises them)
+        _spawn_ranks(world, "grads", mode, port, got_file, {"GSLIC_RANK1_SPLIT_ADAM": "1"})
+        got = np.load(got_file)
+        np.testing.assert_array_equal(got["vis"], ref["vis"], err_msg=f"{mode}: mask != OR of the views' masks")
+        for g in range(6):
+            a, b = got["flat"][offs[g]:offs[g + 1]], ref["flat"][offs[g]:offs[g + 1]]
+            scale = max(float(np.abs(b).max()), 1e-30)
+            assert float(np.abs(a - b).max()) / scale < 1e-5, (mode, g, float(np.abs(a - b).max()) / scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("mode", ["rank1", "dense"])
+def test_n_ranks_replicas_stay_bit_identical(world, mode):
+    outs = _spawn_ranks(world, "steps", mode, 29640 + world + (0 if mode == "rank1" else 20), "unused")
+    d = [[l for l in so.splitlines() if l.startswith("DIGEST")][-1].split()[2] for so in outs]
+    assert len(set(d)) == 1, d
