@@ -84,8 +84,8 @@ def lib():
         [ctypes.POINTER(RasterParams), i32, i32] + [vp] * 12 + [vp] * 4 + [vp] + [vp] * 10 + [f32, vp, vp, vp, vp])
     L.gslic_rasterize_backward_rgb.argtypes = (
         [ctypes.POINTER(RasterParams), i32, i32] + [vp] * 12 + [vp] * 4 + [vp] + [vp] * 5 + [f32, vp])
-    L.gslic_sh_grad_from_rgb.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp]
-    L.gslic_sh_grad_from_rgb_adam.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, vp, ctypes.POINTER(AdamFused), vp, vp, vp]
+    L.gslic_sh_grad_from_rgb.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, ctypes.c_int64, vp]
+    L.gslic_sh_grad_from_rgb_adam.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, vp, ctypes.POINTER(AdamFused), vp, vp, ctypes.c_int64, vp]
     L.gslic_adam_update.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, u32, u32, vp]
     L.gslic_adam_update_groups.argtypes = [ctypes.POINTER(AdamGroup), i32, vp, f32, f32, f32, u32, vp]
     L.gslic_fusedssim_forward.argtypes = [i32, i32, i32, i32, f32, f32] + [vp] * 6 + [vp]
@@ -100,7 +100,7 @@ def lib():
     L.gslic_l1_ssim_loss_forward.argtypes = [i32, i32, i32, i32, f32, f32] + [vp] * 7 + [vp]
     L.gslic_l1_ssim_loss_backward.argtypes = [i32, i32, i32, i32, f32] + [vp] * 6 + [vp]
     L.gslic_set_math_mode.argtypes = [i32]
-    if L.gslic_abi_version() != 4:
+    if L.gslic_abi_version() != 5:
         raise GslicError("libgslic_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -307,7 +307,7 @@ namespace gslic {
 struct ForwardCapacity {
     char *geom, *binning, *img, *sample;
     size_t geom_bytes, binning_bytes, img_bytes, sample_bytes;
-    uint32_t* status_out;  // device [4]: R, B, overflow bits, count of forwards that fitted — written by the last kernel of the forward
+    uint32_t* status_out;  // device [8]: see forward_status_kernel — written by the last kernel of the forward
 };
 // largest count whose carve fits into `bytes` (the carves are monotonic)
 template <typename F>
@@ -321,13 +321,27 @@ static uint32_t capacity_for(size_t bytes, F bytes_needed)
     }
     return (uint32_t)lo;
 }
-__global__ void forward_status_kernel(const uint32_t* __restrict__ R, const uint32_t* __restrict__ B, const uint32_t* __restrict__ flags, uint32_t* __restrict__ out)
+// The last kernel of a capacity-mode forward.  out (device uint32[8], zeroed once by the caller):
+//   [0] R, [1] B of this forward; [2] its bits: 1 instances did not fit, 2 buckets did not fit, 4 prefiltered violation, 8 a scan / sort
+//   look-back wait timed out, 16 the instance count overflowed 2^31; [3] forwards that completed (no bit of 1 | 2 | 8 | 16);
+//   [4] forwards issued; [5] bit (issue index mod 32) set for every forward that did NOT complete; [6] / [7] the largest R / B seen.
+// The device status word of the chained scans (timeout / overflow) is consumed here: the backward of a forward whose prefix sums cannot be
+// trusted stands down through flags[2] like one that overflowed, and no stale bit is left for the next, unrelated forward on this device.
+__global__ void forward_status_kernel(const uint32_t* __restrict__ R, const uint32_t* __restrict__ B, uint32_t* __restrict__ flags,
+                                      uint32_t* __restrict__ dev_status, uint32_t* __restrict__ out)
 {
-    out[0] = *R;
-    out[1] = B ? *B : 0u;
-    const uint32_t st = flags[2] | (flags[0] & 1u ? 4u : 0u);  // 1: instances did not fit, 2: buckets did not fit, 4: prefiltered violation
+    const uint32_t ds = dev_status ? atomicExch(dev_status, 0u) : 0u;
+    uint32_t st = flags[2] | (flags[0] & 1u ? 4u : 0u) | (ds & 1u ? 8u : 0u) | (ds & 2u ? 16u : 0u);
+    if (st & (8u | 16u)) flags[2] |= 4u;   // (any non-zero value makes the backward kernels of this step return at once)
+    const uint32_t r = *R, b = B ? *B : 0u;
+    out[0] = r;
+    out[1] = b;
     out[2] = st;
-    if (!(st & 3u)) out[3] += 1u;  // forwards completed in capacity (never reset here: the caller zeroes the word once)
+    if (!(st & (3u | 8u | 16u))) out[3] += 1u;
+    else out[5] |= 1u << (out[4] & 31u);
+    out[4] += 1u;
+    if (r > out[6]) out[6] = r;
+    if (b > out[7]) out[7] = b;
 }
 }  // namespace gslic
 
@@ -402,6 +416,8 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
         // R = the number of instances the caller's binning buffer holds; the kernels stop at the real count (R_dev) and raise
         // status bit 0 when it does not fit.  No host read (the reference blocks here, rasterizer_impl.cu:398).
         R = capacity_for(cap->binning_bytes, [&](uint32_t r) { size_t b; BinningState::carve(nullptr, (size_t)r, end_bit, no_color, &b); return b; });
+        if (R == 0) return set_error(GSLIC_ERR_INVALID_ARG, "capacity mode: the binning buffer (%zu bytes) does not hold a single instance", cap->binning_bytes);
+        if (!device_status_word()) return set_error(GSLIC_ERR_ALLOC, "capacity mode: the device status word could not be allocated");  // (allocated by the first call on a device: make one eager call before capturing a graph)
     } else {
         GS_TRY(fetch_counts(geom.point_offsets + (P - 1), geom.flags, hostbuf, s));  // host needs R to size the binning buffer (rasterizer_impl.cu:398)
         if (hostbuf[1] & 2u) return set_error(GSLIC_ERR_HIP, "a chained-scan look-back wait timed out (device preempted?): the forward was abandoned");
@@ -464,7 +480,7 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
     DEBUG_SYNC(prm, s);
     if (cap) {
         hipLaunchKernelGGL(forward_status_kernel, dim3(1), dim3(1), 0, s, (const uint32_t*)(geom.point_offsets + (P - 1)),
-                           no_color ? (const uint32_t*)nullptr : (const uint32_t*)(img.bucket_offsets + (T - 1)), (const uint32_t*)geom.flags,
+                           no_color ? (const uint32_t*)nullptr : (const uint32_t*)(img.bucket_offsets + (T - 1)), geom.flags, device_status_word(),
                            cap->status_out);
         GS_HIP(hipGetLastError());
     }
@@ -615,14 +631,16 @@ int gslic_rasterize_backward_rgb(const gslic_raster_params* prm, int32_t R, int3
 }
 
 int gslic_sh_grad_from_rgb(int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D, const float* campos_all,
-                           const float* rgb_all, int32_t input_is_ddc, float* dL_ddc, float* dL_dsh, void* stream)
+                           const float* rgb_all, int32_t input_is_ddc, float* dL_ddc, float* dL_dsh, int64_t view_stride, void* stream)
 {
+    if (view_stride < 0 || (view_stride > 0 && view_stride < 3 * (int64_t)P)) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_sh_grad_from_rgb: bad view_stride");
     if (P < 0 || D < 0 || D > 3 || M < 0 || n_views < 1) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_sh_grad_from_rgb: bad P / D / M / n_views");
     if (P == 0) return GSLIC_OK;
     if (!means3D || !campos_all || !rgb_all || !dL_ddc || (M > 0 && !dL_dsh)) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_sh_grad_from_rgb: NULL pointer");
     ShGradFromRgbArgs a;
     a.P = P; a.D = D; a.M = M; a.n_views = n_views; a.input_is_ddc = input_is_ddc ? 1 : 0;
     a.means3D = means3D; a.campos_all = campos_all; a.rgb_all = rgb_all; a.dL_ddc = dL_ddc; a.dL_dsh = dL_dsh;
+    a.rgb_stride = view_stride ? (size_t)view_stride : (size_t)3 * (size_t)P; a.campos_stride = view_stride ? (size_t)view_stride : 3;
     a.visible = nullptr;
     memset(&a.adam, 0, sizeof(a.adam));
     return launch_sh_grad_from_rgb(a, (hipStream_t)stream);
@@ -630,8 +648,9 @@ int gslic_sh_grad_from_rgb(int32_t P, int32_t D, int32_t M, int32_t n_views, con
 
 int gslic_sh_grad_from_rgb_adam(int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D, const float* campos_all,
                                 const float* rgb_all, int32_t input_is_ddc, const uint8_t* visible, const gslic_adam_fused* adam, float* dL_ddc,
-                                float* dL_dsh, void* stream)
+                                float* dL_dsh, int64_t view_stride, void* stream)
 {
+    if (view_stride < 0 || (view_stride > 0 && view_stride < 3 * (int64_t)P)) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_sh_grad_from_rgb_adam: bad view_stride");
     if (P < 0 || D < 0 || D > 3 || M < 0 || n_views < 1) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_sh_grad_from_rgb_adam: bad P / D / M / n_views");
     if (P == 0) return GSLIC_OK;
     if (!means3D || !campos_all || !rgb_all || !visible || !adam) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_sh_grad_from_rgb_adam: NULL pointer");
@@ -642,6 +661,7 @@ int gslic_sh_grad_from_rgb_adam(int32_t P, int32_t D, int32_t M, int32_t n_views
     ShGradFromRgbArgs a;
     a.P = P; a.D = D; a.M = M; a.n_views = n_views; a.input_is_ddc = input_is_ddc ? 1 : 0;
     a.means3D = means3D; a.campos_all = campos_all; a.rgb_all = rgb_all; a.dL_ddc = dL_ddc; a.dL_dsh = M > 0 ? dL_dsh : nullptr;
+    a.rgb_stride = view_stride ? (size_t)view_stride : (size_t)3 * (size_t)P; a.campos_stride = view_stride ? (size_t)view_stride : 3;
     a.visible = visible;
     memset(&a.adam, 0, sizeof(a.adam));
     for (int g = 1; g <= 2; g++) { a.adam.p[g] = adam->param[g]; a.adam.m[g] = adam->exp_avg[g]; a.adam.v[g] = adam->exp_avg_sq[g]; a.adam.lr[g] = adam->lr[g]; }

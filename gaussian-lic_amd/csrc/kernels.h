@@ -110,6 +110,7 @@ int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
 // product of a direction-only coefficient vector with that colour gradient.  View order 0..n_views-1, plain multiply-then-add.
 struct ShGradFromRgbArgs {
     int P, D, M, n_views, input_is_ddc;
+    size_t rgb_stride, campos_stride;   // floats between consecutive views in rgb_all / campos_all (3 P and 3 for the dense layouts)
     const float *means3D, *campos_all, *rgb_all;
     float *dL_ddc, *dL_dsh;     // outputs; both may be NULL when the Adam update below consumes the rows
     const uint8_t* visible;     // [P] the exchanged (OR-ed) visibility mask: rows the Adam update applies to

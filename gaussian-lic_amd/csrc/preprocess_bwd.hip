@@ -694,7 +694,7 @@ __global__ __launch_bounds__(64) void sh_grad_from_rgb_kernel(ShGradFromRgbArgs 
     if (idx < a.P) {
         const float px = a.means3D[3 * (size_t)idx], py = a.means3D[3 * (size_t)idx + 1], pz = a.means3D[3 * (size_t)idx + 2];
         for (int v = 0; v < a.n_views; v++) {
-            const float* g = a.rgb_all + ((size_t)v * a.P + idx) * 3;
+            const float* g = a.rgb_all + (size_t)v * a.rgb_stride + (size_t)idx * 3;
             float d[3] = {g[0], g[1], g[2]};
             if (d[0] == 0.f && d[1] == 0.f && d[2] == 0.f) continue;   // invisible in this view (or all channels clamped): adds exact zeros
             float dc_v[3];
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(64) void sh_grad_from_rgb_kernel(ShGradFromRgbArgs 
                 for (int ch = 0; ch < 3; ch++) dc_v[ch] = SHC0 * d[ch];
             }
             float dox, doy, doz, x, y, z, c[15];
-            sh_dir(px, py, pz, a.campos_all + 3 * v, dox, doy, doz, x, y, z);
+            sh_dir(px, py, pz, a.campos_all + (size_t)v * a.campos_stride, dox, doy, doz, x, y, z);
             sh_coefs(a.D, x, y, z, c);
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) adc[ch] = adc[ch] + dc_v[ch];

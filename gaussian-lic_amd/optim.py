@@ -86,17 +86,20 @@ class SparseGaussianAdam:
         d.b1, d.b2, d.eps = self.betas[0], self.betas[1], self.eps
         return d
 
-    def step_sh_from_rgb(self, means3D, campos_all, rgb_all, degree):
+    def step_sh_from_rgb(self, means3D, campos_all, rgb_all, degree, n_views=None, view_stride=0):
         """Groups 1 and 2 (features_dc, features_rest) of an N > 1 step: their summed gradients are rebuilt from the views' exchanged colour
         gradients and consumed by the masked Adam update in the same kernel (gslic_sh_grad_from_rgb_adam) — bit-identical to rebuilding the
-        rows and calling step(only=[1, 2]), without writing and re-reading 192 B per Gaussian.  set_visibility_and_N() first."""
-        P, n = means3D.size(0), rgb_all.size(0)
+        rows and calling step(only=[1, 2]), without writing and re-reading 192 B per Gaussian.  set_visibility_and_N() first.
+        view_stride > 0 (floats): the views' blocks sit view_stride apart inside an all-gathered payload (see rasterizer.sh_grad_from_rgb)."""
+        P = means3D.size(0)
+        n = rgb_all.size(0) if n_views is None else int(n_views)
         M = self.params[2].size(1) if self.params[2].numel() else 0
-        assert rgb_all.is_contiguous() and campos_all.is_contiguous() and tuple(rgb_all.shape) == (n, P, 3)
+        if not view_stride:
+            assert rgb_all.is_contiguous() and campos_all.is_contiguous() and tuple(rgb_all.shape) == (n, P, 3)
         d = self.fused_descriptor()
         vis = self.visibility.contiguous()
         _lib.check(_lib.lib().gslic_sh_grad_from_rgb_adam(P, int(degree), M, n, _lib.ptr(means3D.contiguous()), _lib.ptr(campos_all), _lib.ptr(rgb_all), 0,
-                                                          _lib.ptr(vis), ctypes.byref(d), None, None, _lib.current_stream_ptr()))
+                                                          _lib.ptr(vis), ctypes.byref(d), None, None, int(view_stride), _lib.current_stream_ptr()))
         for i in (1, 2):
             if self.state[i] is not None:
                 self.state[i]["step"] += 1

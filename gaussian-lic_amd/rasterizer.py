@@ -93,16 +93,22 @@ class CapacityBuffers:
         self.img = mk(L.gslic_img_bytes(self.W, self.H))
         self.binning = mk(L.gslic_binning_bytes(int(cap_R), int(no_color)))
         self.sample = mk(L.gslic_sample_bytes(int(cap_B)) if not no_color else 0)
-        self.status = torch.zeros(4, dtype=torch.int32, device=device)
+        self.status = torch.zeros(8, dtype=torch.int32, device=device)
         self.color = torch.zeros(3, self.H, self.W, dtype=torch.float32, device=device)
         self.final_T = torch.empty(self.H, self.W, dtype=torch.float32, device=device)
         self.radii = torch.empty(self.P, dtype=torch.int32, device=device)
         self.cap_R = self.cap_B = 0   # filled by the first forward (what the library derives from the buffer sizes)
 
     def read_status(self):
-        """(R, B, overflow bits, forwards that fitted) — synchronises."""
-        r, b, bits, good = (int(v) for v in self.status.cpu().tolist())
+        """(R, B, bits, forwards that completed) of the status words — synchronises."""
+        r, b, bits, good = (int(v) for v in self.status.cpu().tolist()[:4])
         return r & 0xffffffff, b & 0xffffffff, bits, good & 0xffffffff
+
+    def read_window(self):
+        """(forwards issued, bit mask of the issue indices mod 32 that did not complete, largest R, largest B) since the words were zeroed
+        — synchronises."""
+        w = [int(v) & 0xffffffff for v in self.status.cpu().tolist()]
+        return w[4], w[5], w[6], w[7]
 
 
 def rasterize_gaussians_capacity(bufs, background, means3D, opacity, scales, rotations, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
@@ -268,16 +274,19 @@ def render(camera, model, bg_color, no_color=False, scaling_modifier=1.0):
     return image, final_T, screenspace_points, radii > 0, radii
 
 
-def sh_grad_from_rgb(means3D, campos_all, rgb_all, degree, dL_ddc, dL_dsh, input_is_ddc=False):
+def sh_grad_from_rgb(means3D, campos_all, rgb_all, degree, dL_ddc, dL_dsh, input_is_ddc=False, n_views=None, view_stride=0):
     """gslic_sh_grad_from_rgb: dL_ddc [P,1,3] and dL_dsh [P,M,3] summed over the views from the views' masked colour gradients
-    rgb_all [n_views,P,3] and camera centres campos_all [n_views,3] (all device fp32, contiguous); written in place."""
-    P, n = means3D.size(0), rgb_all.size(0)
+    rgb_all [n_views,P,3] and camera centres campos_all [n_views,3] (all device fp32, contiguous); written in place.
+    view_stride > 0 (floats): rgb_all / campos_all point at view 0's block inside an all-gathered payload, n_views blocks view_stride apart."""
+    P = means3D.size(0)
+    n = rgb_all.size(0) if n_views is None else int(n_views)
     M = dL_dsh.size(1) if dL_dsh is not None and dL_dsh.numel() else 0
-    assert rgb_all.is_contiguous() and campos_all.is_contiguous() and dL_ddc.is_contiguous() and (M == 0 or dL_dsh.is_contiguous())
-    assert tuple(rgb_all.shape) == (n, P, 3) and tuple(campos_all.shape) == (n, 3)
+    assert dL_ddc.is_contiguous() and (M == 0 or dL_dsh.is_contiguous())
+    if not view_stride:
+        assert rgb_all.is_contiguous() and campos_all.is_contiguous() and tuple(rgb_all.shape) == (n, P, 3) and tuple(campos_all.shape) == (n, 3)
     p = _lib.ptr
     _lib.check(_lib.lib().gslic_sh_grad_from_rgb(P, int(degree), M, n, p(_f32c(means3D)), p(campos_all), p(rgb_all), int(bool(input_is_ddc)), p(dL_ddc),
-                                                 p(dL_dsh) if M else None, _lib.current_stream_ptr()))
+                                                 p(dL_dsh) if M else None, int(view_stride), _lib.current_stream_ptr()))
 
 
 def debug_export(settings, P, M, R, B, geom, binning, img, sample, what=("tiles_touched", "point_list", "ranges")):

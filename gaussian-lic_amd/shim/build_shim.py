@@ -7,6 +7,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libgslic_torch_shim.so")
+# gslic_stream.h: hand LibTorch's CURRENT HIP stream to the C-ABI (c10::hip::getCurrentHIPStream: needs the HIP headers and c10_hip)
+STREAM_FLAGS = ["-DGSLIC_SHIM_CURRENT_STREAM", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM", "-isystem", "/opt/rocm/include"]
 
 
 def build(force=False):
@@ -14,16 +16,16 @@ def build(force=False):
     from torch.utils import cpp_extension
     src = os.path.join(HERE, "gslic_torch_shim.cpp")
     deps = [src, os.path.join(PKG, "..", "include", "gslic_hip.h")] + [os.path.join(HERE, "include", p) for p in
-                                                                       ("rasterizer/rasterize_points.h", "fused-ssim/ssim.h", "simple-knn/spatial.h")]
+                                                                       ("rasterizer/rasterize_points.h", "fused-ssim/ssim.h", "simple-knn/spatial.h", "gslic_stream.h")]
     deps.append(os.path.join(PKG, "libgslic_hip.so"))
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(d) for d in deps):
         return OUT
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"] + STREAM_FLAGS
     for inc in cpp_extension.include_paths():
         cmd += ["-isystem", inc]
     cmd += ["-I", os.path.join(HERE, "include"), src, "-o", OUT, "-L", PKG, "-lgslic_hip", f"-Wl,-rpath,$ORIGIN", "-L", tlib,
-            "-ltorch", "-ltorch_cpu", "-lc10", f"-Wl,-rpath,{tlib}"]
+            "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", f"-Wl,-rpath,{tlib}"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout[-3000:] + r.stderr[-6000:])
@@ -62,7 +64,7 @@ def _build_check(CHECK, first_includes, force):
     if not force and os.path.exists(CHECK) and os.path.getmtime(CHECK) > newest:
         return CHECK
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
-    cmd = ["g++", "-O1", "-std=c++17", "-w", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    cmd = ["g++", "-O1", "-std=c++17", "-w", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"] + STREAM_FLAGS
     for inc in cpp_extension.include_paths():
         cmd += ["-isystem", inc]
     cmd += first_includes
@@ -92,7 +94,7 @@ def build_fused_check(force=False):
     if not force and os.path.exists(CHECK_FUSED) and os.path.getmtime(CHECK_FUSED) > newest:
         return CHECK_FUSED
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
-    cmd = ["g++", "-O1", "-std=c++17", "-w", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    cmd = ["g++", "-O1", "-std=c++17", "-w", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"] + STREAM_FLAGS
     for inc in cpp_extension.include_paths():
         cmd += ["-isystem", inc]
     cmd += ["-isystem", sysconfig.get_paths()["include"], "-I", os.path.join(HERE, "include"), src, "-o", CHECK_FUSED, "-L", PKG, "-lgslic_hip",

@@ -2,7 +2,9 @@
 // (src/rasterizer/rasterize_points.{h,cu}, src/fused-ssim/ssim.{h,cu}, src/simple-knn/spatial.{h,cu}) with their exact
 // signatures; each body only unwraps pointers, provides torch-backed allocator callbacks and calls the C-ABI of
 // include/gslic_hip.h.  No HIP headers, no kernels here: plain C++ compiled by g++ against LibTorch.
-// Launches go to the legacy default stream (stream = NULL), exactly like the reference's bare <<<grid, block>>>.
+// Launches go to gslic::current_stream() (include/gslic_stream.h): LibTorch's current HIP stream in this build — the legacy default stream,
+// like the reference's bare <<<grid, block>>>, unless the host installed a stream guard.
+#include "gslic_stream.h"
 #include "rasterizer/rasterize_points.h"
 #include "fused-ssim/ssim.h"
 #include "simple-knn/spatial.h"
@@ -74,7 +76,7 @@ RasterizeGaussiansCUDA(const torch::Tensor& background, const torch::Tensor& mea
         check(gslic_rasterize_forward(&prm, resize_cb, &geomBuffer, resize_cb, &binningBuffer, resize_cb, &imgBuffer, resize_cb,
                                       &sampleBuffer, fptr(bg), fptr(m3), fptr(dcc), fptr(shc), fptr(col), fptr(op), fptr(sc), fptr(rot),
                                       fptr(cov), fptr(vm), fptr(pm), fptr(cp), fptr_mut(out_color), fptr_mut(out_final_T),
-                                      radii.data_ptr<int>(), &rendered, &num_buckets, nullptr),
+                                      radii.data_ptr<int>(), &rendered, &num_buckets, gslic::current_stream()),
               "gslic_rasterize_forward");
     }
     return std::make_tuple(rendered, num_buckets, out_color, out_final_T, radii, geomBuffer, binningBuffer, imgBuffer, sampleBuffer);
@@ -114,7 +116,7 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                        reinterpret_cast<char*>(s.data_ptr()), fptr(dl), fptr_mut(dL_dmeans2D), fptr_mut(dL_dconic),
                                        fptr_mut(dL_dopacities), fptr_mut(dL_dcolors), fptr_mut(dL_dmeans3D), fptr_mut(dL_dcov3D),
                                        fptr_mut(dL_ddc), fptr_mut(dL_dsh), fptr_mut(dL_dscales), fptr_mut(dL_drotations), lambda_erank,
-                                       nullptr),
+                                       gslic::current_stream()),
               "gslic_rasterize_backward");
     }
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacities, dL_dmeans3D, dL_dcov3D, dL_ddc, dL_dsh, dL_dscales, dL_drotations);
@@ -132,7 +134,7 @@ void adamUpdate(torch::Tensor& param, torch::Tensor& param_grad, torch::Tensor& 
                 "adamUpdate: fp32 tensors expected");
     at::Tensor vis = visible.contiguous(), grad = param_grad.contiguous();
     check(gslic_adam_update(param.data_ptr<float>(), grad.data_ptr<float>(), exp_avg.data_ptr<float>(), exp_avg_sq.data_ptr<float>(),
-                            reinterpret_cast<const uint8_t*>(vis.data_ptr<bool>()), lr, b1, b2, eps, N, M, nullptr),
+                            reinterpret_cast<const uint8_t*>(vis.data_ptr<bool>()), lr, b1, b2, eps, N, M, gslic::current_stream()),
           "gslic_adam_update");
 }
 
@@ -159,7 +161,7 @@ void adamUpdateGroups(std::vector<torch::Tensor>& params, std::vector<torch::Ten
         groups[i].M = (uint32_t)(params[i].numel() / (int64_t)N);
     }
     at::Tensor vis = visible.contiguous();
-    check(gslic_adam_update_groups(groups.data(), (int32_t)n, reinterpret_cast<const uint8_t*>(vis.data_ptr<bool>()), b1, b2, eps, N, nullptr),
+    check(gslic_adam_update_groups(groups.data(), (int32_t)n, reinterpret_cast<const uint8_t*>(vis.data_ptr<bool>()), b1, b2, eps, N, gslic::current_stream()),
           "gslic_adam_update_groups");
 }
 
@@ -173,7 +175,7 @@ fusedssim(float C1, float C2, torch::Tensor& img1, torch::Tensor& img2, bool tra
     at::Tensor dm_dsigma1_sq = train ? at::empty_like(a) : at::empty({0}, a.options());
     at::Tensor dm_dsigma12 = train ? at::empty_like(a) : at::empty({0}, a.options());
     check(gslic_fusedssim_forward(B, CH, H, W, C1, C2, fptr(a), fptr(b), fptr_mut(target), fptr_mut(dm_dmu1), fptr_mut(dm_dsigma1_sq),
-                                  fptr_mut(dm_dsigma12), nullptr),
+                                  fptr_mut(dm_dsigma12), gslic::current_stream()),
           "gslic_fusedssim_forward");
     return std::make_tuple(target, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
 }
@@ -185,7 +187,7 @@ torch::Tensor fusedssim_backward(float C1, float C2, torch::Tensor& img1, torch:
     at::Tensor a = img1.contiguous(), b = img2.contiguous(), dl = dL_dmap.contiguous();
     at::Tensor d1 = dm_dmu1.contiguous(), d2 = dm_dsigma1_sq.contiguous(), d3 = dm_dsigma12.contiguous();
     at::Tensor out = at::empty_like(a);
-    check(gslic_fusedssim_backward(B, CH, H, W, C1, C2, fptr(a), fptr(b), fptr(dl), fptr(d1), fptr(d2), fptr(d3), fptr_mut(out), nullptr),
+    check(gslic_fusedssim_backward(B, CH, H, W, C1, C2, fptr(a), fptr(b), fptr(dl), fptr(d1), fptr(d2), fptr(d3), fptr_mut(out), gslic::current_stream()),
           "gslic_fusedssim_backward");
     return out;
 }
@@ -196,7 +198,7 @@ torch::Tensor distCUDA2(const torch::Tensor& points)
     at::Tensor pts = points.contiguous();
     at::Tensor means = at::zeros({P}, points.options().dtype(at::kFloat));
     at::Tensor scratch = at::empty({0}, points.options().dtype(at::kByte));
-    check(gslic_knn_mean_dist2(P, fptr(pts), fptr_mut(means), resize_cb, &scratch, nullptr), "gslic_knn_mean_dist2");
+    check(gslic_knn_mean_dist2(P, fptr(pts), fptr_mut(means), resize_cb, &scratch, gslic::current_stream()), "gslic_knn_mean_dist2");
     return means;
 }
 

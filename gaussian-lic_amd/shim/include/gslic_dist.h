@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#include "gslic_stream.h"
 #include "../../../include/gslic_hip.h"   // gslic_sh_grad_from_rgb (exchange_gradients_rank1)
 
 namespace gslic {
@@ -102,7 +103,7 @@ inline torch::Tensor exchange_gradients_rank1(c10d::Backend& pg, const std::vect
     at::Tensor xyz = params[0].detach().contiguous();
     int rc = gslic_sh_grad_from_rgb((int32_t)P, sh_degree, (int32_t)M, (int32_t)world, xyz.data_ptr<float>(), campos_all.data_ptr<float>(),
                                     dc_all.data_ptr<float>(), /*input_is_ddc=*/1, grads[1].data_ptr<float>(), M ? grads[2].data_ptr<float>() : nullptr,
-                                    /*stream=*/nullptr);
+                                    /*view_stride=*/0, /*stream=*/current_stream());
     TORCH_CHECK(rc == GSLIC_OK, "gslic_sh_grad_from_rgb failed: ", gslic_last_error());
     w_small->wait();
     int64_t off = 0;

@@ -21,6 +21,7 @@
 #include <array>
 #include <vector>
 
+#include "gslic_stream.h"
 #include "../../../include/gslic_hip.h"
 
 namespace gslic {
@@ -91,7 +92,7 @@ public:
         check(gslic_rasterize_forward(&rp, grow_cb, &scratch_[0], grow_cb, &scratch_[1], grow_cb, &scratch_[2], grow_cb, &scratch_[3], f(bg_), f(prm_[0]),
                                       f(prm_[1]), f(prm_[2]), nullptr, f(op), f(sc), f(rot), nullptr, f(cam.world_view_transform),
                                       f(cam.full_proj_transform), f(cam.camera_center), color.data_ptr<float>(), final_T.data_ptr<float>(),
-                                      radii.data_ptr<int32_t>(), &R, &B, nullptr),
+                                      radii.data_ptr<int32_t>(), &R, &B, current_stream()),
               "gslic_rasterize_forward (no_color)");
         torch::Tensor pts = points.to(fo).contiguous(), col = colors.to(fo).contiguous(), rsp = depths_rsp.to(fo).contiguous();
         torch::Tensor Rc = R_cw.to(fo).contiguous(), tc = t_cw.to(fo).contiguous();
@@ -99,14 +100,14 @@ public:
         uint32_t *flags = nullptr, *pos = nullptr;
         int32_t count = 0;
         check(gslic_extend_select((int32_t)n, f(pts), f(rsp), f(Rc), f(tc), fx, fy, cx, cy, W, H, f(final_T), grow_cb, &sel_scratch, &flags, &pos, &count,
-                                  nullptr),
+                                  current_stream()),
               "gslic_extend_select");
         if (count == 0) return 0;
         reserve(P + count);
         const int64_t M = buf_[2].numel() ? buf_[2].size(1) : 0;
         auto row = [&](int g) { return buf_[g].numel() ? buf_[g].data_ptr<float>() + P * (buf_[g].numel() / buf_[g].size(0)) : nullptr; };
         check(gslic_extend_emit((int32_t)n, flags, pos, f(pts), f(col), f(rsp), scaling_scale, (fx + fy) / 2.0f, (int32_t)M, row(0), row(1), row(2), row(3),
-                                row(4), row(5), nullptr),
+                                row(4), row(5), current_stream()),
               "gslic_extend_emit");
         for (int g = 0; g < 6; g++) {   // new rows start with zero moments (gaussian.cpp:458-459)
             mbuf_[g].narrow(0, P, count).zero_();
@@ -147,14 +148,14 @@ public:
         int32_t R = 0, B = 0;
         check(gslic_rasterize_forward(&rp, grow_cb, &scratch_[0], grow_cb, &scratch_[1], grow_cb, &scratch_[2], grow_cb, &scratch_[3], f(bg_), xyz, dc,
                                       rest, nullptr, op, sc, rot, nullptr, view, proj, cpos, image_.data_ptr<float>(), final_T_.data_ptr<float>(),
-                                      radii_.data_ptr<int32_t>(), &R, &B, nullptr),
+                                      radii_.data_ptr<int32_t>(), &R, &B, current_stream()),
               "gslic_rasterize_forward");
         const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;   // loss_utils.h:187-188
         check(gslic_l1_ssim_loss_forward(1, 3, H, W, C1, C2, f(image_), f(gt_image), dm_[0].data_ptr<float>(), dm_[1].data_ptr<float>(),
-                                         dm_[2].data_ptr<float>(), partials_.data_ptr<float>(), terms.data_ptr<float>(), nullptr),
+                                         dm_[2].data_ptr<float>(), partials_.data_ptr<float>(), terms.data_ptr<float>(), current_stream()),
               "gslic_l1_ssim_loss_forward");
         check(gslic_l1_ssim_loss_backward(1, 3, H, W, lambda_dssim_, f(image_), f(gt_image), f(dm_[0]), f(dm_[1]), f(dm_[2]),
-                                          dL_dimage_.data_ptr<float>(), nullptr),
+                                          dL_dimage_.data_ptr<float>(), current_stream()),
               "gslic_l1_ssim_loss_backward");
         gslic_adam_fused ad{};
         for (int i = 0; i < 6; i++) {
@@ -167,7 +168,7 @@ public:
         ad.b1 = b1_; ad.b2 = b2_; ad.eps = eps_;
         check(gslic_rasterize_backward_adam(&rp, R, B, f(bg_), xyz, dc, rest, nullptr, sc, rot, nullptr, view, proj, cpos, radii_.data_ptr<int32_t>(),
                                             cptr(scratch_[0]), cptr(scratch_[1]), cptr(scratch_[2]), cptr(scratch_[3]), f(dL_dimage_), nullptr, nullptr,
-                                            nullptr, nullptr, nullptr, nullptr, lambda_erank_, &ad, nullptr),
+                                            nullptr, nullptr, nullptr, nullptr, lambda_erank_, &ad, current_stream()),
               "gslic_rasterize_backward_adam");
         return terms;
     }

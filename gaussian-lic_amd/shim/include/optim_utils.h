@@ -57,6 +57,7 @@ public:
         std::vector<torch::Tensor> params, grads, m1, m2;
         std::vector<double> lrs;
         double eps = 1e-15;
+        bool have_eps = false;
         for (auto& group : param_groups_) {
             TORCH_CHECK(group.params().size() == 1, "More than one tensor in group");
             auto& opt = static_cast<SparseGaussianAdamOptions&>(group.options());
@@ -76,7 +77,11 @@ public:
             m1.push_back(st.exp_avg);
             m2.push_back(st.exp_avg_sq);
             lrs.push_back(opt.get_lr());
+            // one launch carries ONE epsilon: the reference passes each group's own eps_ to adamUpdate (optim_utils.h:126-131), which is the
+            // same value for every group of trainingSetup (gaussian.cpp:399-418); a host that sets them apart must not be folded silently
+            TORCH_CHECK(!have_eps || opt.get_eps() == eps, "SparseGaussianAdam: the parameter groups use different eps values; the one-launch step applies a single one");
             eps = opt.get_eps();
+            have_eps = true;
         }
         if (!params.empty()) adamUpdateGroups(params, grads, m1, m2, visibility_, lrs, 0.9f, 0.999f, (float)eps, (uint32_t)N_);
         return loss;

@@ -138,6 +138,16 @@ def exchange_mode():
     return "sparse" if os.environ.get("GSLIC_SPARSE_EXCHANGE") == "1" else "rank1"
 
 
+DIST_TIMING = None   # bench.py sets this to a dict: the N > 1 step then records CUDA events at its three phase boundaries
+
+
+def _dist_mark(name):
+    if DIST_TIMING is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        DIST_TIMING.setdefault(name, []).append(ev)
+
+
 def _dist_on():
     """True when the per-step gradient exchange has to run.  GSLIC_FORCE_DIST=1 also takes the exchange path in a process group of
     ONE rank (the RCCL smoke test on a single-GPU box: same code path as N > 1, the all-reduce degenerates to a copy)."""
@@ -156,7 +166,14 @@ class GradSlab:
         shapes = [tuple(p.shape) for p in model.parameters()]
         sizes = [int(torch.tensor(s).prod()) for s in shapes]
         self.flat = torch.empty(sum(sizes), device=model.device)
-        self.rgb = torch.empty(self.P, 3, device=model.device)   # this view's clamp-masked colour gradient (exchange_rank1)
+        # exchange_rank1's all-gather payload of THIS rank, one contiguous block: {colour gradient [P,3] fp32, camera centre [3] fp32,
+        # visibility [P] bytes, padding to 4 bytes}; `rgb` (what the backward writes), `pay_campos` and `pay_vis` are views into it
+        self.pay_bytes = (12 * self.P + 12 + self.P + 3) // 4 * 4
+        self.payload = torch.zeros(self.pay_bytes, dtype=torch.uint8, device=model.device)
+        self.rgb = self.payload[:12 * self.P].view(torch.float32).view(self.P, 3)
+        self.pay_campos = self.payload[12 * self.P:12 * self.P + 12].view(torch.float32)
+        self.pay_vis = self.payload[12 * self.P + 12:12 * self.P + 12 + self.P]
+        self.payload_all = None
         self.rgb_all, self.campos_all = None, None
         self.views, off = {}, 0
         for name, shp, n in zip(model.NAMES, shapes, sizes):
@@ -236,34 +253,43 @@ def exchange_rank1(slab, rgb_local, visible, model, campos):
     """The N > 1 exchange with the SH gradients shipped as what they are — rank-1.  computeColorFromSH's backward (backward.cu:27-136) is
     linear in the clamp-masked colour gradient dRGB: dL_ddc = SH_C0 dRGB, dL_dsh[k] = c_k(dir) dRGB with c_k a function of the view
     direction only.  So of the 59 gradient floats per Gaussian only 11 (xyz, opacity, scaling, rotation) are all-reduced; each rank
-    all-gathers the views' 3-float dRGB and camera centres and rebuilds the summed dL_ddc / dL_dsh itself (gslic_sh_grad_from_rgb:
-    the backward's own products, summed in view order — at N = 2 bit-identical to the dense all-reduce).  Bytes on a rank's links per
-    step: 2 (N-1)/N 44 P + (N-1) 12 P instead of 2 (N-1)/N 236 P — 4.2x less at N = 2, 2.6x less at N = 8 (xGMI is point-to-point: the
-    dense slab is per-link bound).
-    Returns (OR-ed visibility, works) like allreduce_slab_async: wait on a work, then run Adam on its groups; the rebuild of the SH
-    rows runs behind the all-gather (first work) while the small all-reduces are still on the links."""
+    all-gathers the views' 3-float dRGB and rebuilds the summed dL_ddc / dL_dsh itself (gslic_sh_grad_from_rgb: the backward's own
+    products, summed in view order — at N = 2 bit-identical to the dense all-reduce).  Bytes on a rank's links per step:
+    2 (N-1)/N 44 P + (N-1) 13 P instead of 2 (N-1)/N 236 P — 4.1x less at N = 2, 2.5x less at N = 8 (xGMI is point-to-point: the dense
+    slab is per-link bound).
+
+    THREE collectives per step, all asynchronous, none in front of the others: ONE all-gather of a per-rank payload {dRGB, camera centre,
+    visibility bytes} (the rebuild kernel reads the gathered blocks in place through a view stride; the masks are OR-ed locally, so no
+    separate MAX-reduce blocks the step), and the all-reduces of the two contiguous runs of the gradient slab that hold the 11 small
+    floats (xyz | ... | opacity, scaling, rotation).  Returns (OR-ed visibility, works) like allreduce_slab_async: wait on a work, then run
+    Adam on its groups; the rebuild of the SH rows runs behind the all-gather while the all-reduces are still on the links."""
     from . import rasterizer as rz
     dist = torch.distributed
     n = dist.get_world_size()
-    vis = visible.to(torch.uint8)
-    dist.all_reduce(vis, op=dist.ReduceOp.MAX)
-    if slab.rgb_all is None or slab.rgb_all.size(0) != n:
-        slab.rgb_all = torch.empty(n, slab.P, 3, device=slab.flat.device)
-        slab.campos_all = torch.empty(n, 3, device=slab.flat.device)
-    w_cam = dist.all_gather_into_tensor(slab.campos_all, campos.reshape(1, 3).contiguous(), async_op=True)
-    w_rgb = dist.all_gather_into_tensor(slab.rgb_all, rgb_local.view(1, slab.P, 3), async_op=True)
+    assert rgb_local.data_ptr() == slab.rgb.data_ptr(), "the colour gradient must have been written into the slab's payload"
+    slab.pay_campos.copy_(campos.reshape(3))
+    slab.pay_vis.copy_(visible)
+    if slab.payload_all is None or slab.payload_all.size(0) != n:
+        slab.payload_all = torch.empty(n, slab.pay_bytes, dtype=torch.uint8, device=slab.flat.device)
+    w_pay = dist.all_gather_into_tensor(slab.payload_all, slab.payload.view(1, slab.pay_bytes), async_op=True)
     works = [(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True), idx) for seg, idx in (slab.run(model, 0, 1), slab.run(model, 3, 6))]
+    P = slab.P
+    w_pay.wait()   # (orders the current stream behind the gather; the host does not block on RCCL)
+    vis = slab.payload_all[:, 12 * P + 12:12 * P + 12 + P].max(0).values.bool()   # OR of the views' masks
+    rgb0 = slab.payload_all[0, :12 * P].view(torch.float32)            # view 0's block; view v sits pay_bytes / 4 floats further
+    cam0 = slab.payload_all[0, 12 * P:12 * P + 12].view(torch.float32)
+    stride = slab.pay_bytes // 4
 
     fused = getattr(model, "optimizer", None) is not None and os.environ.get("GSLIC_RANK1_SPLIT_ADAM") != "1"
 
-    class _Rebuild:   # waits for the gathered colour gradients, then rebuilds dL_ddc / dL_dsh of all views
+    class _Rebuild:   # rebuilds dL_ddc / dL_dsh of all views from the gathered colour gradients (the mask has to be set first: see the caller)
         def wait(self_inner):
-            w_cam.wait(); w_rgb.wait()
             if fused:   # ... and applies the masked Adam to features_dc / features_rest in the same kernel: the rows are never materialised
-                model.optimizer.step_sh_from_rgb(model.xyz.detach(), slab.campos_all, slab.rgb_all, model.sh_degree)
+                model.optimizer.step_sh_from_rgb(model.xyz.detach(), cam0, rgb0, model.sh_degree, n_views=n, view_stride=stride)
             else:       # ... into the slab, for a following optimizer.step(only=[1, 2])
-                rz.sh_grad_from_rgb(model.xyz.detach(), slab.campos_all, slab.rgb_all, model.sh_degree, slab.views["features_dc"], slab.views["features_rest"])
-    return vis.bool(), [(_Rebuild(), [] if fused else [1, 2])] + works
+                rz.sh_grad_from_rgb(model.xyz.detach(), cam0, rgb0, model.sh_degree, slab.views["features_dc"], slab.views["features_rest"],
+                                    n_views=n, view_stride=stride)
+    return vis, [(_Rebuild(), [] if fused else [1, 2])] + works
 
 
 def allreduce_gradients(grads, visible):
@@ -309,6 +335,8 @@ def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=Tr
     fl = fused_loss or _default_fused_loss()
     dev = model.device
     e = torch.empty(0, device=dev)
+    if DIST_TIMING is not None and do_step and _dist_on():
+        _dist_mark("start")
     with torch.no_grad():
         xyz, dc, rest = model.xyz.detach(), model.features_dc.detach(), model.features_rest.detach()
         op, sc, rot = model.opacity.detach(), model.scaling.detach(), model.rotation.detach()
@@ -338,12 +366,14 @@ def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=Tr
                 bg, xyz, radii, e, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
                 float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dL_dimage, dc, rest, model.sh_degree,
                 cam.d_camera_center, geom, R, binning, img, B, sample, model.lambda_erank, False, raw_params=True, out=slab.views, rgb_out=slab.rgb)
+            _dist_mark("bwd_done")
             visible, works = exchange_rank1(slab, slab.rgb, radii > 0, model, cam.d_camera_center)
             model.optimizer.set_visibility_and_N(visible, model.P)
             grads = slab.grads(model)
             for work, idx in works:
                 work.wait()
                 model.optimizer.step(grads, only=idx)
+            _dist_mark("end")
             return terms, visible
         rz.rasterize_gaussians_backward(
             bg, xyz, radii, e, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
@@ -351,6 +381,8 @@ def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=Tr
             cam.d_camera_center, geom, R, binning, img, B, sample, model.lambda_erank, False, raw_params=True, out=slab.views)
         visible = radii > 0
         if do_step:
+            if _dist_on():
+                _dist_mark("bwd_done")
             if mode == "sparse":
                 visible, _rows = allreduce_slab_sparse(slab, visible, model)   # visible rows only: fewer bytes on the links, one gather / scatter pass
                 model.optimizer.set_visibility_and_N(visible, model.P)
@@ -365,6 +397,8 @@ def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=Tr
             else:
                 model.optimizer.set_visibility_and_N(visible, model.P)
                 model.optimizer.step(slab.grads(model))       # group order of gaussian.cpp:399-418
+            if _dist_on():
+                _dist_mark("end")
     return terms, visible
 
 
@@ -395,10 +429,12 @@ class GraphedStep:
 
     The scratch capacities come from one eager forward (R, B) with `headroom`; the instance / bucket counts of a step stay on the
     device.  If they outgrow the buffers the step turns itself into a no-op (status bits; no gradients, no Adam) and `check()` —
-    called every `check_every` steps, and by the caller at the end — grows the buffers, re-captures and repeats exactly the steps
-    that did not fit.  extend() changes P: build a new GraphedStep afterwards."""
+    called every `check_every` steps (at most 32: the device keeps one did-not-fit bit per issued step), and by the caller at the
+    end — grows the buffers from the largest counts seen, re-captures and repeats exactly the steps that did not fit, each with ITS
+    camera and ground truth (kept by reference since the last check: do not overwrite those tensors in between), after the ones that
+    did.  extend() changes P: build a new GraphedStep afterwards."""
 
-    def __init__(self, model, camera, gt_image, bg, headroom=1.25, check_every=16):
+    def __init__(self, model, camera, gt_image, bg, headroom=1.25, check_every=16, cap_R=None, cap_B=None):
         from . import rasterizer as rz
         assert not _dist_on(), "GraphedStep is the single-GPU path"
         self.model, self.bg, self.headroom, self.check_every = model, bg, float(headroom), int(check_every)
@@ -419,9 +455,14 @@ class GraphedStep:
                                           model.features_dc.detach(), model.features_rest.detach(), model.sh_degree, self.campos, False, False,
                                           False, raw_params=True)[:2]
         self.cap_R, self.cap_B = int(R * self.headroom) + 65536, int(B * self.headroom) + 1024
+        if cap_R is not None:
+            self.cap_R = int(cap_R)
+        if cap_B is not None:
+            self.cap_B = int(cap_B)
+        assert self.check_every <= 32, "the device keeps one did-not-fit bit per step of a window of 32"
         self.graph, self.bufs = None, None
         self.steps_issued = 0      # replays since the last check
-        self.good_seen = 0         # value of status[3] at the last check
+        self.window = []           # (camera, ground truth) of those replays, in issue order
         self.recaptures = 0
         self._capture()
 
@@ -443,7 +484,6 @@ class GraphedStep:
         dev = self.model.device
         self.bufs = rz.CapacityBuffers(self.model.P, self.W, self.H, self.cap_R, self.cap_B, dev)
         self._adam = self.model.optimizer.fused_descriptor()
-        self.good_seen = 0
         # warm-up on a side stream (allocations of the loss scratch, library one-offs), then capture.  The warm-up and the capture
         # pass both execute the step, so the parameters are saved and restored around them.
         names = self.model.NAMES
@@ -464,36 +504,61 @@ class GraphedStep:
         self.bufs.status.zero_()
         self.graph = g
         self.steps_issued = 0
+        self.window = []
+
+    def _load(self, camera, gt_image):
+        """Refresh the static buffers the captured step reads."""
+        if camera is not None and camera is not self.cam:
+            assert (float(camera.tanfovx), float(camera.tanfovy)) == (float(self.cam.tanfovx), float(self.cam.tanfovy)), "intrinsics are baked into the graph"
+            self.view.copy_(camera.d_world_view_transform); self.proj.copy_(camera.d_full_proj_transform); self.campos.copy_(camera.d_camera_center)
+            self.cam = camera
+        if gt_image is not None and gt_image.data_ptr() != self.gt.data_ptr():
+            self.gt.copy_(gt_image)
 
     def step(self, camera=None, gt_image=None):
         """One optimiser step (replay).  Returns the device tensor [mean L1, mean SSIM] of this step's loss terms."""
-        if camera is not None and camera is not self.cam:
-            self.view.copy_(camera.d_world_view_transform); self.proj.copy_(camera.d_full_proj_transform); self.campos.copy_(camera.d_camera_center)
-            assert (float(camera.tanfovx), float(camera.tanfovy)) == (float(self.cam.tanfovx), float(self.cam.tanfovy)), "intrinsics are baked into the graph"
-        if gt_image is not None and gt_image.data_ptr() != self.gt.data_ptr():
-            self.gt.copy_(gt_image)
+        self._load(camera, gt_image)
         self.graph.replay()
         self.steps_issued += 1
+        if len(self.window) < 32:
+            self.window.append((self.cam, gt_image))
         self.model.optimizer.count_step()
         if self.check_every and self.steps_issued >= self.check_every:
             self.check()
         return self.terms
 
     def check(self):
-        """Synchronise, read the status words; steps that did not fit were no-ops: grow the buffers, re-capture and repeat them.
+        """Synchronise and read the status words.  Steps that did not fit were no-ops: grow the buffers from the largest counts seen,
+        re-capture and repeat THOSE steps — each with the camera and ground truth it was issued with — until all of them fitted.
         Returns the number of steps that had to be repeated."""
-        R, B, bits, good = self.bufs.read_status()
-        missed = self.steps_issued - (good - self.good_seen)
-        self.good_seen, self.steps_issued = good, 0
-        if bits & 3 or missed > 0:
-            self.cap_R = max(self.cap_R, int(R * self.headroom) + 65536)
-            self.cap_B = max(self.cap_B, int(B * self.headroom) + 1024) if not (bits & 1) else int(self.cap_B * 1.5) + 1024
+        repeated = 0
+        for _round in range(8):
+            issued, failed_mask, max_R, max_B = self.bufs.read_window()
+            _R, _B, bits, good = self.bufs.read_status()
+            missed = issued - good
+            if missed <= 0:
+                break
+            # which steps: one bit per issue index while the window is at most 32 steps long; a longer unchecked run (check_every = 0)
+            # can only be repeated on the view that is loaded now
+            todo = [self.window[i] for i in range(min(issued, len(self.window))) if (failed_mask >> i) & 1] if issued <= 32 else [(self.cam, None)] * missed
+            self.cap_R = max(self.cap_R, int(max_R * self.headroom) + 65536)
+            self.cap_B = max(self.cap_B, int(max_B * self.headroom) + 1024)
+            if max_R > 0x7fffffff // 2 or bits & 16:
+                raise RuntimeError("GraphedStep: the instance count does not fit 31 bits")
             self.recaptures += 1
-            self._capture()
-            for _ in range(max(missed, 0)):
+            self._capture()                     # (zeroes the status words, empties the window)
+            for cam, gt in todo:
+                self._load(cam, gt)
                 self.graph.replay()
-            self.steps_issued = max(missed, 0)
-        return max(missed, 0)
+                self.steps_issued += 1
+                self.window.append((self.cam, gt))
+            repeated += len(todo)
+        else:
+            raise RuntimeError("GraphedStep: steps keep overflowing their capacity buffers")
+        self.bufs.status.zero_()
+        self.steps_issued = 0
+        self.window = []
+        return repeated
 
     @property
     def visible(self):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSLIC_ABI_VERSION 4
+#define GSLIC_ABI_VERSION 5
 
 typedef enum gslic_status {
     GSLIC_OK = 0,
@@ -123,10 +123,14 @@ int gslic_rasterize_forward(
  *
  *  capacity_R, capacity_B   host ints: the capacities in use.  Pass THEM as R and B to gslic_rasterize_backward* (the buffer
  *                           layout depends on them); the backward stops at the real counts on the device.
- *  status                   DEVICE uint32[4], written by the last kernel of the call: [0] = R, [1] = B (real counts), [2] = bits —
- *                           1: the instances did not fit into `binning`, 2: the buckets did not fit into `sample`, 4: prefiltered
- *                           violation — [3] += 1 when bits 1 and 2 are clear (zero the word once; it counts the forwards that fitted).
- *  On overflow (bit 1 or 2) nothing is written out of bounds, out_color / out_final_T are unspecified, and a following
+ *  status                   DEVICE uint32[8], updated by the last kernel of the call (zero the words once; they accumulate):
+ *                           [0] = R, [1] = B (real counts of THIS forward), [2] = its bits — 1: the instances did not fit into `binning`,
+ *                           2: the buckets did not fit into `sample`, 4: prefiltered violation, 8: a scan / sort look-back wait timed out
+ *                           (device preempted), 16: more than 2^31 instances — [3] += 1 when none of 1 | 2 | 8 | 16 is set (forwards
+ *                           that completed), [4] += 1 always (forwards issued), [5] |= 1 << (issue index mod 32) for a forward that
+ *                           did not complete, [6] / [7] = the largest R / B seen (what to size a retry from).
+ *  The first call on a device allocates one status word (hipMalloc): make one eager call before capturing the step in a graph.
+ *  On overflow or timeout (bit 1, 2, 8 or 16) nothing is written out of bounds, out_color / out_final_T are unspecified, and a following
  *  gslic_rasterize_backward* on these buffers does NOTHING (no gradients, no Adam update): the host re-runs the step with larger
  *  buffers once it has seen the bits.  All other arguments as gslic_rasterize_forward; results are bit-identical to it.
  */
@@ -233,6 +237,10 @@ int gslic_rasterize_backward_adam(
  *                                 arithmetic (bit-identical to summing the per-view gslic_rasterize_backward outputs in that order).
  *                                 input_is_ddc = 1: rgb_all holds the views' dL_ddc instead (hosts that only see the reference's
  *                                 gradient tensors); dRGB is then recovered as dL_ddc * (1 / SH_C0), exact to 1 ulp.
+ *                                 view_stride = 0: the dense layouts above.  view_stride > 0 (floats, >= 3 P): view v's colour gradients
+ *                                 start at rgb_all + v * view_stride and its camera centre at campos_all + v * view_stride — one
+ *                                 all-gather of a per-rank payload {dRGB [P,3], camera centre [3], ...} needs no unpacking
+ *                                 (pass campos_all = rgb_all + 3 P).
  */
 int gslic_rasterize_backward_rgb(
     const gslic_raster_params* prm, int32_t R, int32_t B,
@@ -244,14 +252,14 @@ int gslic_rasterize_backward_rgb(
     float lambda_erank, void* stream);
 int gslic_sh_grad_from_rgb(
     int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D, const float* campos_all /*[n_views,3]*/,
-    const float* rgb_all /*[n_views,P,3]*/, int32_t input_is_ddc, float* dL_ddc, float* dL_dsh, void* stream);
+    const float* rgb_all /*[n_views,P,3]*/, int32_t input_is_ddc, float* dL_ddc, float* dL_dsh, int64_t view_stride, void* stream);
 /* The same rebuild with the masked Adam update of features_dc / features_rest (groups 1 and 2 of `adam`; the other groups are ignored)
  * applied straight from the rebuilt rows: the 192 B/Gaussian of dL_ddc / dL_dsh are neither written nor re-read.  `visible` = the
  * exchanged (OR-ed) mask, one byte per Gaussian.  dL_ddc / dL_dsh may be NULL (not materialised) or non-NULL (also written).
  * Bit-identical to gslic_sh_grad_from_rgb followed by gslic_adam_update_groups on the two groups. */
 int gslic_sh_grad_from_rgb_adam(
     int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D, const float* campos_all, const float* rgb_all,
-    int32_t input_is_ddc, const uint8_t* visible, const gslic_adam_fused* adam, float* dL_ddc, float* dL_dsh, void* stream);
+    int32_t input_is_ddc, const uint8_t* visible, const gslic_adam_fused* adam, float* dL_ddc, float* dL_dsh, int64_t view_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * gslic_rasterize_backward_camera — gslic_rasterize_backward plus the gradient w.r.t. the CAMERA inputs (the "cam" of the

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in gslic_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names
-    assert _lib.lib().gslic_abi_version() == 4
+    assert _lib.lib().gslic_abi_version() == 5
 
 
 def test_scratch_sizes_and_errors_without_gpu():
@@ -56,13 +56,13 @@ def test_exchange_entry_points_validate_without_gpu():
     import gaussian_lic_amd  # noqa: F401
     from gaussian_lic_amd import _lib
     L = _lib.lib()
-    assert L.gslic_sh_grad_from_rgb(0, 3, 15, 2, None, None, None, 0, None, None, None) == 0
-    assert L.gslic_sh_grad_from_rgb(10, 4, 15, 2, None, None, None, 0, None, None, None) == -1        # SH degree > 3
-    assert L.gslic_sh_grad_from_rgb(10, 3, 15, 0, None, None, None, 0, None, None, None) == -1        # no views
-    assert L.gslic_sh_grad_from_rgb(10, 3, 15, 2, None, None, None, 0, None, None, None) == -1 and b"NULL" in L.gslic_last_error()
+    assert L.gslic_sh_grad_from_rgb(0, 3, 15, 2, None, None, None, 0, None, None, 0, None) == 0
+    assert L.gslic_sh_grad_from_rgb(10, 4, 15, 2, None, None, None, 0, None, None, 0, None) == -1        # SH degree > 3
+    assert L.gslic_sh_grad_from_rgb(10, 3, 15, 0, None, None, None, 0, None, None, 0, None) == -1        # no views
+    assert L.gslic_sh_grad_from_rgb(10, 3, 15, 2, None, None, None, 0, None, None, 0, None) == -1 and b"NULL" in L.gslic_last_error()
     ad = _lib.AdamFused()
-    assert L.gslic_sh_grad_from_rgb_adam(0, 3, 15, 2, None, None, None, 0, None, ctypes.byref(ad), None, None, None) == 0
-    assert L.gslic_sh_grad_from_rgb_adam(10, 3, 15, 2, None, None, None, 0, None, None, None, None, None) == -1
+    assert L.gslic_sh_grad_from_rgb_adam(0, 3, 15, 2, None, None, None, 0, None, ctypes.byref(ad), None, None, 0, None) == 0
+    assert L.gslic_sh_grad_from_rgb_adam(10, 3, 15, 2, None, None, None, 0, None, None, None, None, 0, None) == -1
     prm = _lib.RasterParams(10, 3, 15, 64, 48, 1.0, 1.0, -1, 1, -1, 1, 1.0, 0, 0, 0, 1)
     rc = L.gslic_rasterize_backward_rgb(ctypes.byref(prm), 0, 0, *([None] * 12), *([None] * 4), None, *([None] * 5), 0.0, None)
     assert rc == -1 and b"dL_drgb" in L.gslic_last_error()

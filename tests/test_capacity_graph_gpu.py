@@ -106,3 +106,57 @@ def test_graphed_step_equals_eager_steps():
             assert torch.equal(getattr(model, n).detach(), getattr(eager, n).detach()), (n, headroom)
             assert torch.equal(model._m[n][:P], eager._m[n][:P]) and torch.equal(model._v[n][:P], eager._v[n][:P]), (n, headroom)
         assert torch.equal(terms_g, terms_e)
+
+
+def test_graphed_step_repeats_overflowed_steps_with_their_own_views():
+    """A different camera and target every step, capacity buffers sized so that SOME views overflow: every view must be trained exactly
+    once — the views that fitted in issue order, then the ones that did not (each with ITS camera and ground truth, not the last one's)
+    — i.e. the parameters equal an eager run over that order bit for bit.  Also: the status words report the did-not-fit steps."""
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import rasterizer as rz
+    from gaussian_lic_amd import trainer
+    from gaussian_lic_amd.camera import synthetic_camera
+    from gaussian_lic_amd.synthetic import gt_image
+    dev = torch.device("cuda:0")
+    P, W, H = 40000, 320, 240
+    raw, sc, camd, cam0 = make_scene("random", P, W, H, 3, 8)
+    cams = [synthetic_camera(W, H, k).to_device(dev) for k in range(8)]
+    gts = [gt_image(H, W, seed=10 + k).to(dev) for k in range(8)]
+    bg = torch.zeros(3, device=dev)
+
+    def fresh():
+        m = trainer.GaussianModel(raw, dev)
+        m.training_setup()
+        return m
+    # instance counts of the eight views on the initial map: pick a capacity between the smallest and the largest
+    probe = fresh()
+    e = torch.empty(0, device=dev)
+    Rs = []
+    with torch.no_grad():
+        for c in cams:
+            Rs.append(rz.rasterize_gaussians(bg, probe.xyz.detach(), e, probe.opacity.detach(), probe.scaling.detach(), probe.rotation.detach(), 1.0, e,
+                                             c.d_world_view_transform, c.d_full_proj_transform, float(c.tanfovx), float(c.tanfovy), H, W,
+                                             float(c.limx_neg), float(c.limx_pos), float(c.limy_neg), float(c.limy_pos), probe.features_dc.detach(),
+                                             probe.features_rest.detach(), 3, c.d_camera_center, False, False, False, raw_params=True)[0])
+    assert max(Rs) > min(Rs) + 64
+    cap_R = (max(Rs) + sorted(Rs)[len(Rs) // 2]) // 2      # the larger views do not fit
+    fits = [r <= cap_R - 64 for r in Rs]
+    assert any(fits) and not all(fits)
+    model = fresh()
+    first_fit = fits.index(True)
+    gs = trainer.GraphedStep(model, cams[first_fit], gts[first_fit], bg, check_every=0, cap_R=cap_R)
+    order = list(range(8))
+    for k in order:
+        gs.step(cams[k], gts[k])
+    issued, mask, max_R, _max_B = gs.bufs.read_window()
+    assert issued == 8 and max_R >= max(Rs) - 4096
+    failed = [k for k in order if (mask >> k) & 1]
+    assert failed and all(not fits[k] or Rs[k] > cap_R - 4096 for k in failed)   # (counts drift a little as the map trains)
+    repeated = gs.check()
+    assert repeated == len(failed) and gs.recaptures >= 1
+    eager = fresh()
+    for k in [k for k in order if k not in failed] + failed:
+        trainer.training_step_fused(eager, cams[k], gts[k], bg)
+    for n in model.NAMES:
+        assert torch.equal(getattr(model, n).detach(), getattr(eager, n).detach()), n
+        assert torch.equal(model._m[n][:P], eager._m[n][:P]) and torch.equal(model._v[n][:P], eager._v[n][:P]), n

@@ -86,14 +86,18 @@ def _worker(rank, world, port, q):
     for v, x in zip(slab.grads(_M()), keep):
         v.copy_(x)
     slab.views["features_dc"].fill_(float("nan")); slab.views["features_rest"].fill_(float("nan"))   # not shipped: rebuilt after the exchange
-    def _rebuild(means3D, campos_all, rgb_all, degree, dL_ddc, dL_dsh, input_is_ddc=False):
-        a, b = ref.rows_from_rgb(means3D, campos_all, rgb_all, degree, dL_dsh.shape[1])
+    def _rebuild(means3D, campos_all, rgb_all, degree, dL_ddc, dL_dsh, input_is_ddc=False, n_views=None, view_stride=0):
+        # the kernel reads the all-gathered payload in place: view v's colour gradients / camera centre start view_stride floats further
+        rgb_v = rgb_all.as_strided((n_views, means3D.shape[0], 3), (view_stride, 3, 1))
+        cam_v = campos_all.as_strided((n_views, 3), (view_stride, 1))
+        a, b = ref.rows_from_rgb(means3D, cam_v, rgb_v, degree, dL_dsh.shape[1])
         dL_ddc.copy_(a); dL_dsh.copy_(b)
     rz.sh_grad_from_rgb = _rebuild
     class _Model(_M):
         xyz = means
         sh_degree = 3
-    r1vis, works = trainer.exchange_rank1(slab, rgb.contiguous(), vis, _Model(), campos)
+    slab.rgb.copy_(rgb)    # (the backward writes the colour gradient straight into the slab's all-gather payload)
+    r1vis, works = trainer.exchange_rank1(slab, slab.rgb, vis, _Model(), campos)
     order = []
     for work, idx in works:
         work.wait()
