@@ -98,7 +98,6 @@ ImageState ImageState::carve(const void* base, size_t T, size_t* bytes)
     g.ranges = c.take<uint2>(T);
     g.bucket_offsets = c.take<uint32_t>(T);
     g.max_contrib = c.take<uint32_t>(T);
-    g.tile_order = c.take<uint32_t>(T);
     g.pix_final = c.take<float4>(T * GS_TILE_PIX);
     if (bytes) *bytes = c.used(base) + 256;
     return g;
@@ -454,7 +453,7 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
     memset(&smp, 0, sizeof(smp));
     uint32_t B = 0;
     if (!no_color) {
-        GS_TRY(launch_bucket_scan(T, img.ranges, img.bucket_offsets, img.max_contrib, img.tile_order, s));
+        GS_TRY(launch_bucket_scan(T, img.ranges, img.bucket_offsets, img.max_contrib, s));
         if (cap) {
             B = capacity_for(cap->sample_bytes, [&](uint32_t b) { size_t n; SampleState::carve(nullptr, (size_t)b, &n); return n; });
         } else {
@@ -472,8 +471,6 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
     RenderFwdArgs ra;
     ra.W = prm->width; ra.H = prm->height; ra.gx = gx; ra.gy = gy; ra.no_color = prm->no_color;
     ra.ranges = img.ranges; ra.point_list = bin.point_list(); ra.rec = geom.rec; ra.bucket_offsets = img.bucket_offsets;
-    static const bool tile_lpt = getenv("GSLIC_NO_TILE_ORDER") == nullptr;
-    ra.tile_order = (no_color || !tile_lpt) ? nullptr : img.tile_order;   // (written by the bucket scan, which a no_color forward skips)
     ra.bucket_to_tile = smp.bucket_to_tile; ra.ckpt = smp.ckpt; ra.hit = smp.hit; ra.pix_final = img.pix_final; ra.max_contrib = img.max_contrib;
     ra.out_color = out_color; ra.out_final_T = out_final_T; ra.capB = B; ra.status = geom.flags;
     GS_TRY(launch_render_fwd(ra, s));

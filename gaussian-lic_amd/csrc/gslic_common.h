@@ -160,7 +160,6 @@ struct ImageState {
     uint2* ranges;            // [T]
     uint32_t* bucket_offsets; // [T] inclusive scan of ceil(n_t / GS_BUCKET)
     uint32_t* max_contrib;    // [T]
-    uint32_t* tile_order;     // [T] tile ids by descending bucket count (render_fwd hands out its workgroups in this order)
     float4* pix_final;        // [T*256] tile-major {C.r,C.g,C.b, n_contrib bits}
     static ImageState carve(const void* base, size_t T, size_t* bytes);
 };

@@ -34,8 +34,7 @@ int launch_keybuild(const KeybuildArgs& a, hipStream_t s);
 // R_dev != NULL: the real instance count is read on the device and R is the capacity the launch is sized for
 // dead != NULL: also clears the per-slot dead flags of the backward (BinningState::dead)
 int launch_finalize_ranges(uint32_t R, const uint32_t* R_dev, const uint32_t* sorted_tiles, uint2* ranges, uint8_t* dead, hipStream_t s);
-// per-tile bucket counts + their scan, max_contrib zeroed, and tile_order = the tiles by descending bucket count (scan.hip)
-int launch_bucket_scan(int T, const uint2* ranges, uint32_t* bucket_offsets, uint32_t* max_contrib /* zeroed */, uint32_t* tile_order, hipStream_t s);
+int launch_bucket_scan(int T, const uint2* ranges, uint32_t* bucket_offsets, uint32_t* max_contrib /* zeroed */, hipStream_t s);  // scan.hip
 
 struct RenderFwdArgs {
     int W, H, gx, gy, no_color;
@@ -43,7 +42,6 @@ struct RenderFwdArgs {
     const uint32_t* point_list;
     const float4* rec;
     const uint32_t* bucket_offsets;
-    const uint32_t* tile_order;  // [T] tiles by descending list length (NULL: identity) — the order the workgroups are handed out in
     uint32_t* bucket_to_tile;
     float4* ckpt;
     uint64_t* hit;             // SampleState::hit (written by the strict variant only, which then sets status[GS_FLAG_HITBITS])

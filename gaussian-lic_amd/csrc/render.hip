@@ -62,14 +62,12 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
 {
     constexpr int QN = 4 / SPLIT;          // strips (= pixels per lane) of this wave
     __shared__ float4 s_rec[3 * GS_BUCKET];
-    // 1-D grid in groups of 8 * SPLIT workgroups: workgroup b of a group works on tile rank 8 * group + b % 8, strips (b / 8) * QN...:
+    // 1-D grid in groups of 8 * SPLIT workgroups: workgroup b of a group works on tile 8 * group + b % 8, strips (b / 8) * QN...:
     // consecutive workgroups go to consecutive XCDs (eight L2s), so the SPLIT waves of one tile land on the SAME XCD, a few dispatches
-    // apart — the second wave's fetch of the tile's records hits the L2 the first one filled.  tile_order (optional) lists the tiles by
-    // descending list length: the longest tiles start first and the short ones fill the tail of the launch.
+    // apart — the second wave's fetch of the tile's records hits the L2 the first one filled (render_fwd 0.30 -> 0.265 ms).
     const uint32_t grp = blockIdx.x / (8u * SPLIT), rem = blockIdx.x % (8u * SPLIT);
-    const uint32_t rank = grp * 8u + (rem & 7u);
-    if (rank >= (uint32_t)(a.gx * a.gy)) return;
-    const int tile = a.tile_order ? (int)a.tile_order[rank] : (int)rank;
+    const int tile = (int)(grp * 8u + (rem & 7u));
+    if (tile >= a.gx * a.gy) return;
     const int q0 = (int)(rem >> 3) * QN;   // first strip of this wave
     const int lane = threadIdx.x;
     const int tx0 = (tile % a.gx) * GS_TILE, ty0 = (tile / a.gx) * GS_TILE;

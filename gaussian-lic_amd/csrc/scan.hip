@@ -182,12 +182,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32
 // tiles' bucket counts and their inclusive scan in one single-block launch (rasterizer_impl.cu:433-441): T is the tile count of an
 // image, a few thousand
 __global__ __launch_bounds__(SCAN_THREADS) void bucket_scan_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ bucket_offsets,
-                                                                   uint32_t* __restrict__ max_contrib, uint32_t* __restrict__ tile_order)
+                                                                   uint32_t* __restrict__ max_contrib)
 {
     __shared__ uint32_t lds[8];
-    __shared__ uint32_t hist[256];   // tiles per bucket count (clipped to 255): a counting sort gives the longest-first launch order
-    hist[threadIdx.x] = 0;
-    __syncthreads();
     uint32_t carry = 0;
     for (int base = 0; base < T; base += SCAN_TILE) {
         const int t0 = base + (int)threadIdx.x * SCAN_ITEMS;
@@ -196,11 +193,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void bucket_scan_kernel(int T, const 
 #pragma unroll
         for (int i = 0; i < SCAN_ITEMS; i++) {
             uint32_t c = 0;
-            if (t0 + i < T) {
-                const uint2 r = ranges[t0 + i];
-                c = (r.y - r.x + (GS_BUCKET - 1)) / GS_BUCKET;
-                if (tile_order) atomicAdd(&hist[c < 255u ? c : 255u], 1u);
-            }
+            if (t0 + i < T) { const uint2 r = ranges[t0 + i]; c = (r.y - r.x + (GS_BUCKET - 1)) / GS_BUCKET; }
             v[i] = c; s += c;
         }
         uint32_t total;
@@ -212,26 +205,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void bucket_scan_kernel(int T, const 
         }
         carry += total;
     }
-    if (!tile_order) return;
-    // tiles by DESCENDING bucket count: thread k owns key 255 - k; the order among equal counts is whatever the LDS atomics hand out
-    // (it only decides which workgroup index a tile gets in render_fwd, never a result)
-    __syncthreads();
-    uint32_t total;
-    const uint32_t mine = hist[255 - threadIdx.x];
-    const uint32_t start = block256_exclusive_prefix(mine, total, lds);
-    __syncthreads();
-    hist[255 - threadIdx.x] = start;
-    __syncthreads();
-    for (int t = threadIdx.x; t < T; t += SCAN_THREADS) {
-        const uint2 r = ranges[t];
-        const uint32_t c = (r.y - r.x + (GS_BUCKET - 1)) / GS_BUCKET;
-        tile_order[atomicAdd(&hist[c < 255u ? c : 255u], 1u)] = (uint32_t)t;
-    }
 }
-int launch_bucket_scan(int T, const uint2* ranges, uint32_t* bucket_offsets, uint32_t* max_contrib, uint32_t* tile_order, hipStream_t s)
+// (A longest-first launch order of the tiles — counting sort by bucket count in this kernel, render_fwd's workgroups handed out in that
+// order — was built and measured in round 3: render_fwd -5 % on a scene of long, faint lists, nothing on the default scene, and the sort
+// itself costs this single-block kernel 7 us on every forward: a net loss on four of five workloads.  Not in the tree.)
+int launch_bucket_scan(int T, const uint2* ranges, uint32_t* bucket_offsets, uint32_t* max_contrib, hipStream_t s)
 {
-    static const bool lpt = getenv("GSLIC_NO_TILE_ORDER") == nullptr;   // (A/B: identity order)
-    GS_LAUNCH(K_BUCKET_COUNT, bucket_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, T, ranges, bucket_offsets, max_contrib, lpt ? tile_order : (uint32_t*)nullptr);
+    GS_LAUNCH(K_BUCKET_COUNT, bucket_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, T, ranges, bucket_offsets, max_contrib);
     return GSLIC_OK;
 }
 
