@@ -880,7 +880,7 @@ __global__ __launch_bounds__(256) void export_ncontrib_kernel(int W, int H, int 
     const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= W || y >= H) return;
     const int tile = blockIdx.y * gx + blockIdx.x;
-    o[(size_t)y * W + x] = __float_as_uint(pix_final[(size_t)tile * GS_TILE_PIX + threadIdx.x].w);
+    o[(size_t)y * W + x] = __float_as_uint(pix_final[(size_t)tile * GS_TILE_PIX + tile_pix_index((int)(threadIdx.x & 15), (int)(threadIdx.x >> 4))].w);
 }
 }  // namespace gslic
 

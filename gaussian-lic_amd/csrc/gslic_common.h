@@ -196,6 +196,13 @@ namespace gslic {
 
 __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// Pixel of element i (0..255) of the tile-major per-pixel arrays (pix_final, checkpoints, decision masks), inside its 16x16 tile: four
+// 8x8 quadrants of 64 elements each — quadrant Q = i >> 6 at (8 (Q & 1), 8 (Q >> 1)), element l = i & 63 of it at (l & 7, l >> 3).
+// render_fwd's lane l owns element l of every quadrant of its wave (8x8 quadrants cull list entries better than 16x4 strips).
+__device__ __forceinline__ int tile_pix_x(int i) { return ((i >> 6) & 1) * 8 + (i & 7); }
+__device__ __forceinline__ int tile_pix_y(int i) { return (i >> 7) * 8 + ((i >> 3) & 7); }
+__device__ __forceinline__ int tile_pix_index(int x, int y) { return ((y >> 3) * 2 + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7); }
+
 
 // 64-lane inclusive scan and 256-thread block exclusive prefix (lds: >= 4 u32, reusable after return)
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)

@@ -1,8 +1,8 @@
 // render.hip — the two alpha-blend kernels, designed for 64-lane waves.
 //
 // render_fwd_kernel<STRICT, SPLIT>  replaces renderCUDA<3> (forward.cu:321-481)
-//   SPLIT WAVES PER 16x16 TILE (default 2), each blending 4 / SPLIT of the tile's four 16x4-row pixel strips per lane (lane l owns
-//   column l&15, rows (l>>4) + 4q).  A wave fetches 64 list entries at a time (one 48-byte record per lane, three dwordx4 loads),
+//   SPLIT WAVES PER 16x16 TILE (default 2), each blending 4 / SPLIT of the tile's four 8x8 pixel quadrants per lane (lane l owns
+//   pixel (l & 7, l >> 3) of every quadrant of its wave: quadrants cull better than 16x4 strips, -9 % pairs evaluated).  A wave fetches 64 list entries at a time (one 48-byte record per lane, three dwordx4 loads),
 //   pre-scales them, parks them in LDS and fetches entry j with three ds_read_b128 at a wave-uniform address (LDS broadcast, next
 //   entry prefetched): the kernel is VALU-issue bound and LDS reads cost no issue slot.  A 4-bit mask per entry says which strips
 //   it can reach at all; a checkpoint {T, C} per pixel is stored at every 64th entry (bucket = one wave of entries) as one coalesced
@@ -60,7 +60,7 @@ __device__ __forceinline__ float strip_max_p2(float hA, float hC, float nB, floa
 template <bool STRICT, int SPLIT>
 __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(RenderFwdArgs a)
 {
-    constexpr int QN = 4 / SPLIT;          // strips (= pixels per lane) of this wave
+    constexpr int QN = 4 / SPLIT;          // quadrants (= pixels per lane) of this wave
     __shared__ float4 s_rec[3 * GS_BUCKET];
     // 1-D grid in groups of 8 * SPLIT workgroups: workgroup b of a group works on tile 8 * group + b % 8, strips (b / 8) * QN...:
     // consecutive workgroups go to consecutive XCDs (eight L2s), so the SPLIT waves of one tile land on the SAME XCD, a few dispatches
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
     const uint32_t grp = blockIdx.x / (8u * SPLIT), rem = blockIdx.x % (8u * SPLIT);
     const int tile = (int)(grp * 8u + (rem & 7u));
     if (tile >= a.gx * a.gy) return;
-    const int q0 = (int)(rem >> 3) * QN;   // first strip of this wave
+    const int q0 = (int)(rem >> 3) * QN;   // first quadrant of this wave
     const int lane = threadIdx.x;
     const int tx0 = (tile % a.gx) * GS_TILE, ty0 = (tile / a.gx) * GS_TILE;
     if (a.status[2] != 0u) return;  // capacity mode: the instance lists did not fit; the host re-runs the step with larger buffers
@@ -88,38 +88,37 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
             for (int b = lane; b < nb; b += 64) a.bucket_to_tile[bbm + b] = (uint32_t)tile;
     }
 
-    const int px = tx0 + (lane & 15);
-    const int pyb = ty0 + (lane >> 4);
+    // this lane's pixel in quadrant Q = q0 + q of the tile: (8 (Q & 1) + (lane & 7), 8 (Q >> 1) + (lane >> 3)) — tile_pix_x / tile_pix_y of
+    // element Q * 64 + lane of the tile-major per-pixel arrays (gslic_common.h).  With two waves per tile a wave's two quadrants share
+    // their rows: the y terms of the exponent are formed once per entry.
+    constexpr int MY = QN == 4 ? 2 : 1;    // distinct pixel rows per lane
+    int pxi[QN], pyi[QN];
+#pragma unroll
+    for (int q = 0; q < QN; q++) { pxi[q] = tx0 + tile_pix_x((q0 + q) * 64 + lane); pyi[q] = ty0 + tile_pix_y((q0 + q) * 64 + lane); }
     // The sign of T carries the `done` flag (forward.cu:352,439-443): T > 0 = still blending, T < 0 = finished with
     // transmittance |T| (T never reaches 0: blending stops below 1e-4).  One register and no flag bookkeeping per pixel.
     float T[QN], Cr[QN], Cg[QN], Cb[QN];
     uint32_t last[QN];
 #pragma unroll
     for (int q = 0; q < QN; q++) {
-        const int py = pyb + 4 * (q0 + q);
-        T[q] = (px < a.W && py < a.H) ? 1.0f : -1.0f;
+        T[q] = (pxi[q] < a.W && pyi[q] < a.H) ? 1.0f : -1.0f;
         Cr[q] = Cg[q] = Cb[q] = 0.0f;
         last[q] = 0;
     }
     const float LOG2E = 1.4426950408889634f;
     // loop constants in VGPRs (a literal or SGPR operand doubles the issue cost of the instruction that reads it: tools/ubench/issue_rate)
     float c099 = 0.99f, c255 = 1.0f / 255.0f, c1e4 = 0.0001f, ninf = -__builtin_inff();
-    float lyq[QN];
-#pragma unroll
-    for (int q = 0; q < QN; q++) {
-        lyq[q] = (float)((lane >> 4) + 4 * (q0 + q));
-        asm volatile("" : "+v"(lyq[q]));
-    }
     asm volatile("" : "+v"(c099), "+v"(c255), "+v"(c1e4), "+v"(ninf));
-    // STRICT only: absolute pixel coordinates and the constants of expf_core, in VGPRs like the others
-    float pxf = (float)px, pyq[QN], kL2E = GS_EXP_L2E, kCC = GS_EXP_CC, kmh = -0.5f, kzero = 0.0f, vonef = 1.0f;
+    // pixel coordinates as floats: tile-relative (default arithmetic) or absolute (STRICT), per quadrant column / per row
+    float fxq[QN], fym[MY];
 #pragma unroll
-    for (int q = 0; q < QN; q++) pyq[q] = (float)(pyb + 4 * (q0 + q));
-    if constexpr (STRICT) {
+    for (int q = 0; q < QN; q++) { fxq[q] = (float)(STRICT ? pxi[q] : pxi[q] - tx0); asm volatile("" : "+v"(fxq[q])); }
 #pragma unroll
-        for (int q = 0; q < QN; q++) asm volatile("" : "+v"(pyq[q]));
-        asm volatile("" : "+v"(pxf), "+v"(kL2E), "+v"(kCC), "+v"(kmh), "+v"(kzero), "+v"(vonef));
-    }
+    for (int m = 0; m < MY; m++) { fym[m] = (float)(STRICT ? pyi[QN == 4 ? 2 * m : 0] : pyi[QN == 4 ? 2 * m : 0] - ty0); asm volatile("" : "+v"(fym[m])); }
+    // STRICT: the constants of expf_core; default: the exponent below which no pixel reaches alpha >= 1/255 (with a margin: the early-out only)
+    float kL2E = GS_EXP_L2E, kCC = GS_EXP_CC, kmh = -0.5f, kzero = 0.0f, vonef = 1.0f, kp2min = -7.9943534f - 0.001f /* log2(1/255) */;
+    if constexpr (STRICT) asm volatile("" : "+v"(kL2E), "+v"(kCC), "+v"(kmh), "+v"(kzero), "+v"(vonef));
+    else asm volatile("" : "+v"(kp2min), "+v"(kzero));
 
     for (int base = 0; base < n; base += GS_BUCKET) {
         bool alldone = true;
@@ -136,6 +135,7 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
         // each lane fetches one record and pre-scales its conic: exponent in base 2, relative to this lane-independent tile origin
         float fdx = 0, fdy = 0, fhA = 0, fhC = 0, fnB = 0, fop = 0, flop = -__builtin_inff(), fr = 0, fg = 0, fb = 0;
         uint32_t fmask = 0;
+        float fthr = 0.f;
         if (lane < m) {
             const uint32_t g = a.point_list[range.x + (uint32_t)(base + lane)];
             const float4* rp = a.rec + GS_REC_F4 * (size_t)g;
@@ -144,14 +144,17 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
             fhA = -0.5f * LOG2E * r0.z; fnB = -LOG2E * r0.w; fhC = -0.5f * LOG2E * r1.x;
             fop = r1.y; fr = r1.z; fg = r1.w; fb = r2.x;
             flop = __builtin_amdgcn_logf(fop);  // log2(opacity): alpha = exp2(p2 + log2 opacity), one multiply less per (pixel, entry)
-            // which of this wave's 16x4 strips (= the QN pixels of every lane) can this entry reach at all (bit q = strip q0 + q)
+            // which of this wave's 8x8 quadrants (= the QN pixels of every lane) can this entry reach at all (bit q = quadrant q0 + q)
 #pragma unroll
             for (int q = 0; q < QN; q++) {
-                const float pm = strip_max_p2(fhA, fhC, fnB, fdx, fdy, 0.0f, 15.0f, (float)(4 * (q0 + q)), (float)(4 * (q0 + q) + 3));
+                const float x0 = (float)(8 * ((q0 + q) & 1)), y0 = (float)(8 * ((q0 + q) >> 1));
+                const float pm = strip_max_p2(fhA, fhC, fnB, fdx, fdy, x0, x0 + 7.0f, y0, y0 + 7.0f);
                 if (!(fop * __builtin_amdgcn_exp2f(pm) < 0.999f * (1.0f / 255.0f))) fmask |= 1u << q;
             }
+            // STRICT: the power below which alpha = opacity exp(power) < 1/255 for certain (log evaluated to ~1e-6, margin 1e-3): the
+            // early-out of blend_entry compares against it, it decides nothing else
+            fthr = -0.6931472f * (flop + 7.9943534f) - 0.001f;
         }
-        const float lx = (float)(lane & 15), ly = (float)(lane >> 4);
         if constexpr (STRICT) {  // raw record: absolute mean, unscaled conic
             if (lane < m) {
                 const uint32_t g = a.point_list[range.x + (uint32_t)(base + lane)];
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
         // issue slots, which is what bounds this kernel — LDS reads do not
         s_rec[3 * lane] = make_float4(fdx, fdy, fhA, fnB);
         s_rec[3 * lane + 1] = make_float4(fhC, STRICT ? fop : flop, fr, fg);
-        s_rec[3 * lane + 2] = make_float4(fb, __uint_as_float(fmask), 0.f, 0.f);
+        s_rec[3 * lane + 2] = make_float4(fb, __uint_as_float(fmask), fthr, 0.f);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // one list entry against this lane's four pixels.  STRICT: the reference's arithmetic with its branches.  Default: straight-line
@@ -190,21 +193,26 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
                 // forward.cu:424-445 operation for operation: d from absolute coordinates, the three products of the power rounded one by
                 // one, hipcc's expf (expf_core), opacity * exp, (colour * alpha) * T added to C; the entry is applied under an exec mask
                 // (measured against select-masked straight-line code: 0.39 vs 0.40 ms).  (-0.5f * s - c as one fma: halving is exact.)
-                const float dxs = gdx - pxf;              // float2 d = { xy.x - pixf.x, xy.y - pixf.y } (forward.cu:424)
-                const float ax = (hA * dxs) * dxs;        // con_o.x * d.x * d.x
-                const float bx = nB * dxs;                // con_o.y * d.x
+                const float thr = e2.z;
+                float dys[MY], cy[MY];
+#pragma unroll
+                for (int m = 0; m < MY; m++) { dys[m] = gdy - fym[m]; cy[m] = (hC * dys[m]) * dys[m]; }   // d.y; con_o.z * d.y * d.y
 #pragma unroll
                 for (int q = 0; q < QN; q++) {
-                    if (!(smask & (1u << q))) continue;  // wave-uniform; conservative (no pixel of the strip reaches alpha >= 1/255)
-                    const float dys = gdy - pyq[q];
-                    const float s2 = ax + (hC * dys) * dys;
-                    const float power = __builtin_fmaf(kmh, s2, -(bx * dys));
+                    if (!(smask & (1u << q))) continue;  // wave-uniform; conservative (no pixel of the quadrant reaches alpha >= 1/255)
+                    const int m = QN == 4 ? q >> 1 : 0;
+                    const float dxs = gdx - fxq[q];                       // float2 d = { xy.x - pixf.x, xy.y - pixf.y } (forward.cu:424)
+                    const float s2 = (hA * dxs) * dxs + cy[m];            // con_o.x * d.x * d.x + con_o.z * d.y * d.y
+                    const float power = __builtin_fmaf(kmh, s2, -((nB * dxs) * dys[m]));
+                    // early-out: no live pixel of the quadrant can reach alpha >= 1/255 (21 % of the reachable (entry, quadrant) pairs of the
+                    // 2M / 1080p scene: mostly quadrants whose pixels are all finished) — everything below would change nothing
+                    if (!__builtin_amdgcn_ballot_w64((power >= thr) & (T[q] > kzero))) continue;
                     const float alpha = __builtin_amdgcn_fmed3f(op * expf_core(power, kL2E, kCC), ninf, c099);   // min(0.99f, con_o.w * exp(power))
                     const float test_T = T[q] * (vonef - alpha);
                     // A finished pixel (T < 0) needs no test of its own: T (1 - alpha) is negative, hence "< 1e-4", and -|T| leaves it as it is
                     const bool cand = !(power > kzero) & !(alpha < c255);   // forward.cu:431,437
                     const bool stop = test_T < c1e4;                        // done; this entry is NOT applied (forward.cu:438-443)
-                    if (cand) {   // exec-masked: skipped when no pixel of the strip blends this entry
+                    if (cand) {   // exec-masked: skipped when no pixel of the quadrant blends this entry
                         if (stop) {
                             T[q] = -__builtin_fabsf(T[q]);
                         } else {
@@ -219,14 +227,18 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
                 // e1.y holds log2(opacity) here.  The operation sequence below is repeated verbatim by the backward (GS_BW_BODY), so both
                 // sides compute bit-identical alphas and take the same alpha < 1/255 decisions for every (pixel, entry) pair
                 const float lop = op;
-                const float dx = gdx - lx;
-                const float pA = __builtin_fmaf(hA * dx, dx, lop);  // log2(e) * (-1/2 A dx^2) + log2(opacity)
-                const float pB = nB * dx;                           // log2(e) * (-B dx)
+                float dy[MY], tC[MY];
+#pragma unroll
+                for (int m = 0; m < MY; m++) { dy[m] = gdy - fym[m]; tC[m] = hC * dy[m]; }   // one rounding, as d0.y - py in the backward
 #pragma unroll
                 for (int q = 0; q < QN; q++) {
                     if (!(smask & (1u << q))) continue;  // wave-uniform
-                    const float dy = gdy - lyq[q];  // one rounding, as d0.y - py in the backward
-                    const float p2 = __builtin_fmaf(pB, dy, __builtin_fmaf(hC * dy, dy, pA));  // log2(e) * power + log2(opacity)
+                    const int m = QN == 4 ? q >> 1 : 0;
+                    const float dx = gdx - fxq[q];
+                    float p2 = __builtin_fmaf(hA * dx, dx, lop);      // log2(e) * (-1/2 A dx^2) + log2(opacity)
+                    p2 = __builtin_fmaf(tC[m], dy[m], p2);
+                    p2 = __builtin_fmaf(nB * dx, dy[m], p2);          // log2(e) * power + log2(opacity)
+                    if (!__builtin_amdgcn_ballot_w64((p2 >= kp2min) & (T[q] > kzero))) continue;   // early-out, as above
                     const float alpha = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(p2), ninf, c099);  // min(0.99, .) in one instruction, as GS_BW_BODY
                     const float test_T = T[q] * (1.0f - alpha);  // negative (so < 1e-4) once the pixel is done
                     const bool ok = !(p2 > lop) & !(alpha < c255);                  // forward.cu:431,437
@@ -271,9 +283,8 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
     const size_t plane = (size_t)a.H * a.W;
 #pragma unroll
     for (int q = 0; q < QN; q++) {
-        const int py = pyb + 4 * (q0 + q);
-        if (px < a.W && py < a.H) {
-            const size_t pid = (size_t)py * a.W + px;
+        if (pxi[q] < a.W && pyi[q] < a.H) {
+            const size_t pid = (size_t)pyi[q] * a.W + pxi[q];
             a.out_final_T[pid] = fabsf(T[q]);
             if (color) {
                 a.out_color[pid] = Cr[q];
@@ -455,7 +466,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
             if (use_bits) { const uint64_t m = a.hit[(size_t)bucket * GS_TILE_PIX + pidx]; hm[c] = make_uint2((uint32_t)m, (uint32_t)(m >> 32)); }
         }
         pf[c] = a.pix_final[(size_t)tile * GS_TILE_PIX + pidx];
-        const int px = tx0 + (pidx & 15), py = ty0 + (pidx >> 4);
+        const int px = tx0 + tile_pix_x(pidx), py = ty0 + tile_pix_y(pidx);
         inside[c] = px < a.W && py < a.H;
         fg[c][0] = fg[c][1] = fg[c][2] = 0.f;
         if (inside[c]) {
@@ -529,7 +540,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
             A0 = __builtin_fmaf(ck[c].z - pf[c].y, fg[c][1], A0);
             A0 = __builtin_fmaf(ck[c].w - pf[c].z, fg[c][2], A0);
             s_rg[pos[c]] = make_float2(fg[c][0], fg[c][1]);
-            s_bt[pos[c]] = make_float2(fg[c][2], __uint_as_float((rel[c] << 16) | ((pidx >> 4) << 8) | ((pidx & 15u) << 4)));
+            s_bt[pos[c]] = make_float2(fg[c][2], __uint_as_float((rel[c] << 16) | ((uint32_t)tile_pix_y((int)pidx) << 8) | ((uint32_t)tile_pix_x((int)pidx) << 4)));
             if constexpr (BITS) s_hm[pos[c]] = hm[c];
             s_ta[pos[c]] = make_float2(ck[c].x, A0);
         }
