@@ -351,25 +351,27 @@ __device__ __forceinline__ void tile_power_prep(float cA, float cC, float& rcpx,
 }
 __device__ __forceinline__ float tile_min_power_p(float cA, float cB, float cC, float mx, float my, float rcpx, float rcpy, int tx, int ty)
 {
-    const float rminx = (float)(tx * GS_TILE), rminy = (float)(ty * GS_TILE);
-    const float rmaxx = (float)((tx + 1) * GS_TILE - 1), rmaxy = (float)((ty + 1) * GS_TILE - 1);
-    const float x_min_diff = rminx - mx;
-    const float x_left = (x_min_diff > 0.0f) ? 1.0f : 0.0f;
-    const float not_in_x = x_left + ((mx > rmaxx) ? 1.0f : 0.0f);
-    const float y_min_diff = rminy - my;
-    const float y_above = (y_min_diff > 0.0f) ? 1.0f : 0.0f;
-    const float not_in_y = y_above + ((my > rmaxy) ? 1.0f : 0.0f);
-    if (!((not_in_y + not_in_x) > 0.0f)) return 0.0f;
-    const float sx = rmaxx - rminx, sy = rmaxy - rminy;  // = GS_TILE - 1
-    const float px = x_left * rminx + (1.0f - x_left) * rmaxx;
-    const float py = y_above * rminy + (1.0f - y_above) * rmaxy;
-    const float dx = copysignf(sx, x_min_diff);
-    const float dy = copysignf(sy, y_min_diff);
-    const float diffx = mx - px;
-    const float diffy = my - py;
-    const float tx_ = not_in_y * saturate_f((dx * cA * diffx + dx * cB * diffy) * rcpx);
-    const float ty_ = not_in_x * saturate_f((dy * cB * diffx + dy * cC * diffy) * rcpy);
-    const float qx = px + tx_ * dx, qy = py + ty_ * dy;
+    // (operation order is part of the tile-list contract: every sum and product below is rounded where the reference's is)
+    const float lo_x = (float)(tx * GS_TILE), lo_y = (float)(ty * GS_TILE);                          // first pixel centre of the tile
+    const float hi_x = (float)((tx + 1) * GS_TILE - 1), hi_y = (float)((ty + 1) * GS_TILE - 1);      // last one
+    const float gap_x = lo_x - mx;
+    const float left_of = (gap_x > 0.0f) ? 1.0f : 0.0f;                    // the mean lies left of the tile
+    const float outside_x = left_of + ((mx > hi_x) ? 1.0f : 0.0f);         // ... or right of it
+    const float gap_y = lo_y - my;
+    const float above = (gap_y > 0.0f) ? 1.0f : 0.0f;
+    const float outside_y = above + ((my > hi_y) ? 1.0f : 0.0f);
+    if (!((outside_y + outside_x) > 0.0f)) return 0.0f;                    // mean inside the rectangle: the minimum is 0 at the mean
+    const float span_x = hi_x - lo_x, span_y = hi_y - lo_y;                // = GS_TILE - 1
+    const float near_x = left_of * lo_x + (1.0f - left_of) * hi_x;         // the rectangle's corner nearest to the mean
+    const float near_y = above * lo_y + (1.0f - above) * hi_y;
+    const float step_x = copysignf(span_x, gap_x);                         // direction along each edge away from that corner
+    const float step_y = copysignf(span_y, gap_y);
+    const float off_x = mx - near_x;
+    const float off_y = my - near_y;
+    // slide along the nearest edge(s): parameter of the 1-D minimum, clamped to the edge (NaN -> 0 through saturate_f)
+    const float u = outside_y * saturate_f((step_x * cA * off_x + step_x * cB * off_y) * rcpx);
+    const float v = outside_x * saturate_f((step_y * cB * off_x + step_y * cC * off_y) * rcpy);
+    const float qx = near_x + u * step_x, qy = near_y + v * step_y;        // closest point of the rectangle in the conic's metric
     const float ex = mx - qx, ey = my - qy;
     return 0.5f * (cA * ex * ex + cC * ey * ey) + cB * ex * ey;
 }

@@ -387,11 +387,11 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
     float t0 = V[0] * mx3 + V[4] * my3 + V[8] * mz3 + V[12];
     float t1 = V[1] * mx3 + V[5] * my3 + V[9] * mz3 + V[13];
     const float t2 = V[2] * mx3 + V[6] * my3 + V[10] * mz3 + V[14];
-    const float txtz = t0 / t2, tytz = t1 / t2;
-    t0 = fminf(a.limx_pos, fmaxf(a.limx_neg, txtz)) * t2;
-    t1 = fminf(a.limy_pos, fmaxf(a.limy_neg, tytz)) * t2;
-    const float x_grad_mul = (txtz < a.limx_neg || txtz > a.limx_pos) ? 0.f : 1.f;
-    const float y_grad_mul = (tytz < a.limy_neg || tytz > a.limy_pos) ? 0.f : 1.f;
+    const float tx_over_tz = t0 / t2, ty_over_tz = t1 / t2;
+    t0 = fminf(a.limx_pos, fmaxf(a.limx_neg, tx_over_tz)) * t2;
+    t1 = fminf(a.limy_pos, fmaxf(a.limy_neg, ty_over_tz)) * t2;
+    const float keep_x = (tx_over_tz < a.limx_neg || tx_over_tz > a.limx_pos) ? 0.f : 1.f;
+    const float keep_y = (ty_over_tz < a.limy_neg || ty_over_tz > a.limy_pos) ? 0.f : 1.f;
     const float fx = a.focal_x, fy = a.focal_y;
     const float J00 = fx / t2, J02 = -(fx * t0) / (t2 * t2), J11 = fy / t2, J12 = -(fy * t1) / (t2 * t2);
     float T0[3], T1[3];
@@ -411,48 +411,48 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
     const float cb = VT1[0] * T0[0] + VT1[1] * T0[1] + VT1[2] * T0[2];
     const float cc = (VT1[0] * T1[0] + VT1[1] * T1[1] + VT1[2] * T1[2]) + 0.3f;
     const float denom = ca * cc - cb * cb;
-    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    const float inv_det2 = 1.0f / ((denom * denom) + 0.0000001f);
+    float g_ca = 0, g_cb = 0, g_cc = 0;
     float dcv[6] = {0, 0, 0, 0, 0, 0};
-    if (denom2inv != 0) {
-        dL_da = denom2inv * (-cc * cc * s_cx + 2 * cb * cc * s_cy + (denom - ca * cc) * s_cw);
-        dL_dc = denom2inv * (-ca * ca * s_cw + 2 * ca * cb * s_cy + (denom - ca * cc) * s_cx);
-        dL_db = denom2inv * 2 * (cb * cc * s_cx - (denom + 2 * cb * cb) * s_cy + ca * cb * s_cw);
-        dcv[0] = (T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc);
-        dcv[3] = (T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc);
-        dcv[5] = (T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc);
-        dcv[1] = 2 * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2 * T1[0] * T1[1] * dL_dc;
-        dcv[2] = 2 * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2 * T1[0] * T1[2] * dL_dc;
-        dcv[4] = 2 * T0[2] * T0[1] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2 * T1[1] * T1[2] * dL_dc;
+    if (inv_det2 != 0) {
+        g_ca = inv_det2 * (-cc * cc * s_cx + 2 * cb * cc * s_cy + (denom - ca * cc) * s_cw);
+        g_cc = inv_det2 * (-ca * ca * s_cw + 2 * ca * cb * s_cy + (denom - ca * cc) * s_cx);
+        g_cb = inv_det2 * 2 * (cb * cc * s_cx - (denom + 2 * cb * cb) * s_cy + ca * cb * s_cw);
+        dcv[0] = (T0[0] * T0[0] * g_ca + T0[0] * T1[0] * g_cb + T1[0] * T1[0] * g_cc);
+        dcv[3] = (T0[1] * T0[1] * g_ca + T0[1] * T1[1] * g_cb + T1[1] * T1[1] * g_cc);
+        dcv[5] = (T0[2] * T0[2] * g_ca + T0[2] * T1[2] * g_cb + T1[2] * T1[2] * g_cc);
+        dcv[1] = 2 * T0[0] * T0[1] * g_ca + (T0[0] * T1[1] + T0[1] * T1[0]) * g_cb + 2 * T1[0] * T1[1] * g_cc;
+        dcv[2] = 2 * T0[0] * T0[2] * g_ca + (T0[0] * T1[2] + T0[2] * T1[0]) * g_cb + 2 * T1[0] * T1[2] * g_cc;
+        dcv[4] = 2 * T0[2] * T0[1] * g_ca + (T0[1] * T1[2] + T0[2] * T1[1]) * g_cb + 2 * T1[1] * T1[2] * g_cc;
     }
     if (a.dL_dcov3D)
 #pragma unroll
         for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * idx + k] = dcv[k];
 
-    const float dL_dT00 = 2 * VT0[0] * dL_da + VT1[0] * dL_db;
-    const float dL_dT01 = 2 * VT0[1] * dL_da + VT1[1] * dL_db;
-    const float dL_dT02 = 2 * VT0[2] * dL_da + VT1[2] * dL_db;
-    const float dL_dT10 = 2 * VT1[0] * dL_dc + VT0[0] * dL_db;
-    const float dL_dT11 = 2 * VT1[1] * dL_dc + VT0[1] * dL_db;
-    const float dL_dT12 = 2 * VT1[2] * dL_dc + VT0[2] * dL_db;
-    const float dL_dJ00 = V[0] * dL_dT00 + V[4] * dL_dT01 + V[8] * dL_dT02;
-    const float dL_dJ02 = V[2] * dL_dT00 + V[6] * dL_dT01 + V[10] * dL_dT02;
-    const float dL_dJ11 = V[1] * dL_dT10 + V[5] * dL_dT11 + V[9] * dL_dT12;
-    const float dL_dJ12 = V[2] * dL_dT10 + V[6] * dL_dT11 + V[10] * dL_dT12;
+    const float gT0x = 2 * VT0[0] * g_ca + VT1[0] * g_cb;
+    const float gT0y = 2 * VT0[1] * g_ca + VT1[1] * g_cb;
+    const float gT0z = 2 * VT0[2] * g_ca + VT1[2] * g_cb;
+    const float gT1x = 2 * VT1[0] * g_cc + VT0[0] * g_cb;
+    const float gT1y = 2 * VT1[1] * g_cc + VT0[1] * g_cb;
+    const float gT1z = 2 * VT1[2] * g_cc + VT0[2] * g_cb;
+    const float gJ00 = V[0] * gT0x + V[4] * gT0y + V[8] * gT0z;
+    const float gJ02 = V[2] * gT0x + V[6] * gT0y + V[10] * gT0z;
+    const float gJ11 = V[1] * gT1x + V[5] * gT1y + V[9] * gT1z;
+    const float gJ12 = V[2] * gT1x + V[6] * gT1y + V[10] * gT1z;
     const float tz = 1.f / t2, tz2 = tz * tz, tz3 = tz2 * tz;
-    const float dL_dtx = x_grad_mul * -fx * tz2 * dL_dJ02;
-    const float dL_dty = y_grad_mul * -fy * tz2 * dL_dJ12;
-    const float dL_dtz = -fx * tz2 * dL_dJ00 - fy * tz2 * dL_dJ11 + (2 * fx * t0) * tz3 * dL_dJ02 + (2 * fy * t1) * tz3 * dL_dJ12;
+    const float g_tx = keep_x * -fx * tz2 * gJ02;
+    const float g_ty = keep_y * -fy * tz2 * gJ12;
+    const float g_tz = -fx * tz2 * gJ00 - fy * tz2 * gJ11 + (2 * fx * t0) * tz3 * gJ02 + (2 * fy * t1) * tz3 * gJ12;
     if constexpr (CAM) {
         const float pc[4] = {mx3, my3, mz3, 1.0f};
-        const float gt[3] = {dL_dtx, dL_dty, dL_dtz};
+        const float gt[3] = {g_tx, g_ty, g_tz};
         // t = V [p, 1]: d/dV[4c + r] = dL/dt_r * p_c
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
             for (int r = 0; r < 3; r++) cg[3 * c + r] += gt[r] * pc[c];
         // W = rotation part of V inside T = W J (T0[i] = V[4i] J00 + V[4i+2] J02, T1[i] = V[4i+1] J11 + V[4i+2] J12)
-        const float gT0[3] = {dL_dT00, dL_dT01, dL_dT02}, gT1[3] = {dL_dT10, dL_dT11, dL_dT12};
+        const float gT0[3] = {gT0x, gT0y, gT0z}, gT1[3] = {gT1x, gT1y, gT1z};
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             cg[3 * i + 0] += gT0[i] * J00;
@@ -461,9 +461,9 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
         }
     }
     float dmean[3];
-    dmean[0] = V[0] * dL_dtx + V[1] * dL_dty + V[2] * dL_dtz;
-    dmean[1] = V[4] * dL_dtx + V[5] * dL_dty + V[6] * dL_dtz;
-    dmean[2] = V[8] * dL_dtx + V[9] * dL_dty + V[10] * dL_dtz;
+    dmean[0] = V[0] * g_tx + V[1] * g_ty + V[2] * g_tz;
+    dmean[1] = V[4] * g_tx + V[5] * g_ty + V[6] * g_tz;
+    dmean[2] = V[8] * g_tx + V[9] * g_ty + V[10] * g_tz;
 
     // ---- mean2D -> mean3D through the projection (backward.cu:339-350) ----
     {

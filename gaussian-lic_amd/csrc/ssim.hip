@@ -102,6 +102,31 @@ __device__ __forceinline__ void ssim_fwd_column4(const FwdLds& L, int ly0, int l
     for (int k = 0; k < 4; k++) { out[k].mu1 = v02[k].x; out[k].mu2 = v02[k].y; out[k].e11 = v13[k].x; out[k].e22 = v13[k].y; out[k].e12 = v4[k]; }
 }
 
+// SSIM of one pixel from its five window statistics, and the three derivative maps the backward consumes (ssim.cu:261-282).
+// SSIM = (lum_n * con_n) / (lum_d * con_d): luminance and contrast-structure terms, numerators and denominators; every quotient keeps the
+// reference's association (the CPU oracle reproduces the reference's maps bit for bit; this file is compiled with fma contraction and
+// agrees with the reference's kernels to 1.5e-5).  One definition for the drop-in kernel and the fused loss kernel.
+struct SsimTerms { float map, d_mu1, d_sigma1_sq, d_sigma12; };
+__device__ __forceinline__ SsimTerms ssim_terms(const FwdStats& st, float C1, float C2)
+{
+    const float mu1 = st.mu1, mu2 = st.mu2;
+    const float sigma1_sq = st.e11 - mu1 * mu1;
+    const float sigma2_sq = st.e22 - mu2 * mu2;
+    const float sigma12 = st.e12 - mu1 * mu2;
+    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu1_mu2 = mu1 * mu2;
+    const float lum_n = (2.0f * mu1_mu2 + C1);
+    const float con_n = (2.0f * sigma12 + C2);
+    const float lum_d = (mu1_sq + mu2_sq + C1);
+    const float con_d = (sigma1_sq + sigma2_sq + C2);
+    SsimTerms t;
+    t.map = (lum_n * con_n) / (lum_d * con_d);
+    t.d_mu1 = ((mu2 * 2.0f * con_n) / (lum_d * con_d) - (mu2 * 2.0f * lum_n) / (lum_d * con_d) - (mu1 * 2.0f * lum_n * con_n) / (lum_d * lum_d * con_d) +
+               (mu1 * 2.0f * lum_n * con_n) / (lum_d * con_d * con_d));
+    t.d_sigma1_sq = ((-lum_n * con_n) / (lum_d * con_d * con_d));
+    t.d_sigma12 = ((2 * lum_n) / (lum_d * con_d));
+    return t;
+}
+
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, float C1, float C2, const float* __restrict__ img1,
                                                        const float* __restrict__ img2, float* __restrict__ ssim_map,
                                                        float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
@@ -121,22 +146,13 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, float C1, f
         const FwdStats st = st4[q];
         const int px = x0 + lx, py = y0 + ly;
         if (px < W && py < H) {
-            const float mu1 = st.mu1, mu2 = st.mu2;
-            const float sigma1_sq = st.e11 - mu1 * mu1;
-            const float sigma2_sq = st.e22 - mu2 * mu2;
-            const float sigma12 = st.e12 - mu1 * mu2;
-            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu1_mu2 = mu1 * mu2;
-            const float C = (2.0f * mu1_mu2 + C1);
-            const float D = (2.0f * sigma12 + C2);
-            const float A = (mu1_sq + mu2_sq + C1);
-            const float B = (sigma1_sq + sigma2_sq + C2);
+            const SsimTerms t = ssim_terms(st, C1, C2);
             const size_t o = plane + (size_t)py * W + px;
-            ssim_map[o] = (C * D) / (A * B);
+            ssim_map[o] = t.map;
             if (dm_dmu1) {
-                dm_dmu1[o] = ((mu2 * 2.0f * D) / (A * B) - (mu2 * 2.0f * C) / (A * B) - (mu1 * 2.0f * C * D) / (A * A * B) +
-                              (mu1 * 2.0f * C * D) / (A * B * B));
-                dm_dsigma1_sq[o] = ((-C * D) / (A * B * B));
-                dm_dsigma12[o] = ((2 * C) / (A * B));
+                dm_dmu1[o] = t.d_mu1;
+                dm_dsigma1_sq[o] = t.d_sigma1_sq;
+                dm_dsigma12[o] = t.d_sigma12;
             }
         }
     }
@@ -256,23 +272,14 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(int H, int W, float C1, f
         const FwdStats st = st4[q];
         const int px = x0 + lx, py = y0 + ly;
         if (px < W && py < H) {
-            const float mu1 = st.mu1, mu2 = st.mu2;
-            const float sigma1_sq = st.e11 - mu1 * mu1;
-            const float sigma2_sq = st.e22 - mu2 * mu2;
-            const float sigma12 = st.e12 - mu1 * mu2;
-            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu1_mu2 = mu1 * mu2;
-            const float C = (2.0f * mu1_mu2 + C1);
-            const float D = (2.0f * sigma12 + C2);
-            const float A = (mu1_sq + mu2_sq + C1);
-            const float B = (sigma1_sq + sigma2_sq + C2);
+            const SsimTerms t = ssim_terms(st, C1, C2);
             const size_t o = plane + (size_t)py * W + px;
-            sum_ssim += (C * D) / (A * B);
+            sum_ssim += t.map;
             const v2f c = L.ab[ly + 5][lx + 5];
             sum_l1 += fabsf(c.x - c.y);
-            dm_dmu1[o] = ((mu2 * 2.0f * D) / (A * B) - (mu2 * 2.0f * C) / (A * B) - (mu1 * 2.0f * C * D) / (A * A * B) +
-                          (mu1 * 2.0f * C * D) / (A * B * B));
-            dm_dsigma1_sq[o] = ((-C * D) / (A * B * B));
-            dm_dsigma12[o] = ((2 * C) / (A * B));
+            dm_dmu1[o] = t.d_mu1;
+            dm_dsigma1_sq[o] = t.d_sigma1_sq;
+            dm_dsigma12[o] = t.d_sigma12;
         }
     }
     const float bl1 = block256_sum(sum_l1, red);
