@@ -130,6 +130,99 @@ def test_gradient_allreduce_two_ranks_gloo():
     np.testing.assert_array_equal(vis0, v0 | v1)              # mask = OR of the views
 
 
+def _worker_n(rank, world, port, q):
+    """World size > 2: the reduction order is the backend's, so the variants are held to each other by tolerance (1e-6 of the group's max-abs)
+    instead of bit for bit; what stays exact is the mask (OR) and that every rank ends with the same bits (checked by the parent)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    import gaussian_lic_amd  # noqa: F401
+    import sh_rank1_ref as ref
+    from gaussian_lic_amd import rasterizer as rz
+    from gaussian_lic_amd import trainer
+    P = 321
+    g = torch.Generator().manual_seed(200 + rank)
+    shapes = [(P, 3), (P, 1, 3), (P, 15, 3), (P, 1), (P, 3), (P, 4)]
+    vis = torch.rand(P, generator=g) < 0.4
+
+    class _M:
+        NAMES = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")
+        device = torch.device("cpu")
+        P = 321
+        xyz = torch.randn(321, 3, generator=torch.Generator().manual_seed(7)) * 3.0    # replicated map
+        sh_degree = 3
+        def parameters(self): return [torch.empty(*s) for s in shapes]
+    m = _M()
+    campos = torch.tensor([0.25 * rank - 0.1, 0.05 * rank, -0.3])
+    rgb = torch.randn(P, 3, generator=g) * vis.view(-1, 1)
+    dc_v, sh_v = ref.rows_one_view(m.xyz, campos, rgb, 3, 15)
+    mask = vis.view(-1, 1).float()
+    local = [torch.randn(P, 3, generator=g) * mask, dc_v, sh_v, torch.randn(P, 1, generator=g) * mask, torch.randn(P, 3, generator=g) * mask,
+             torch.randn(P, 4, generator=g) * mask]
+    slab = trainer.GradSlab(m)
+    def load():
+        for v, x in zip(slab.grads(m), local):
+            v.copy_(x)
+    load()
+    dvis = trainer.allreduce_slab(slab, vis)
+    dense = [v.clone() for v in slab.grads(m)]
+    load()
+    avis, works = trainer.allreduce_slab_async(slab, vis, m)
+    for work, _idx in works:
+        work.wait()
+    asyncr = [v.clone() for v in slab.grads(m)]
+    load()
+    slab.views["features_dc"].fill_(float("nan")); slab.views["features_rest"].fill_(float("nan"))
+    def _rebuild(means3D, campos_all, rgb_all, degree, dL_ddc, dL_dsh, input_is_ddc=False, n_views=None, view_stride=0):
+        rgb_v = rgb_all.as_strided((n_views, means3D.shape[0], 3), (view_stride, 3, 1))
+        cam_v = campos_all.as_strided((n_views, 3), (view_stride, 1))
+        a, b = ref.rows_from_rgb(means3D, cam_v, rgb_v, degree, dL_dsh.shape[1])
+        dL_ddc.copy_(a); dL_dsh.copy_(b)
+    rz.sh_grad_from_rgb = _rebuild
+    slab.rgb.copy_(rgb)
+    rvis, works = trainer.exchange_rank1(slab, slab.rgb, vis, m, campos)
+    for work, _idx in works:
+        work.wait()
+    rank1 = [v.clone() for v in slab.grads(m)]
+    assert torch.equal(avis, dvis) and torch.equal(rvis, dvis)
+    for i in range(6):
+        scale = float(dense[i].abs().max()) + 1e-30
+        assert float((asyncr[i] - dense[i]).abs().max()) / scale < 1e-6, ("async", i)
+        assert float((rank1[i] - dense[i]).abs().max()) / scale < 2e-6, ("rank1", i)
+    q.put((rank, [x.numpy() for x in dense], [x.numpy() for x in rank1], dvis.numpy(), [x.numpy() for x in local], vis.numpy()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_gradient_exchange_four_ranks_gloo():
+    """World size 4 on the CPU: dense, pipelined and rank-1 exchange agree (tolerance: the backend's reduction order), every rank holds
+    the identical result of each, it equals the sum over the ranks' local gradients, and the mask is the OR of the views' masks."""
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_n, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res[1:]:
+        for a, b in zip(res[0][1], r[1]):
+            np.testing.assert_array_equal(a, b)            # dense: identical on every rank
+        for a, b in zip(res[0][2], r[2]):
+            np.testing.assert_array_equal(a, b)            # rank-1: identical on every rank
+        np.testing.assert_array_equal(res[0][3], r[3])
+    for i in range(6):
+        total = sum(r[4][i].astype(np.float64) for r in res)
+        scale = np.abs(total).max() + 1e-30
+        assert np.abs(res[0][1][i] - total).max() / scale < 1e-6
+    np.testing.assert_array_equal(res[0][3], np.logical_or.reduce([r[5] for r in res]))
+
+
 def test_view_sharding_rule():
     """bench.py: rank k of an N-rank job renders synthetic view k % 8; a single rank renders the identity pose."""
     import gaussian_lic_amd  # noqa: F401
