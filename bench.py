@@ -235,10 +235,13 @@ def main():
             # ring all-reduce: 2 (n-1)/n of the buffer per rank; all-gather: (n-1) x the per-rank payload
             sent = {"rank1": 2.0 * (n - 1) / n * 44 * Pn + (n - 1) * (13 * Pn + 12),
                     "dense": 2.0 * (n - 1) / n * 236 * Pn + 2.0 * (n - 1) / n * Pn}.get(mode)
-            exchange = {"mode": mode, "collectives_per_step": {"rank1": 3, "dense": 4, "sparse": 2}[mode], "compute_ms": round(comp, 3),
+            chunks = trainer.exchange_chunks() if mode == "rank1" else 1
+            exchange = {"mode": mode, "chunks": chunks, "collectives_per_step": {"rank1": 3 if chunks == 1 else 2 * chunks, "dense": 4, "sparse": 2}[mode],
+                        "compute_ms": round(comp, 3),
                         "exchange_window_ms": round(tail, 3),
-                        "window_note": "GPU time from the end of the backward to the end of the step: the collectives AND the Adam / SH-rebuild kernels that run "
-                                       "behind them (0.43 ms of kernels at 2M Gaussians in a one-rank group, where the collectives are copies)",
+                        "window_note": "GPU time from the end of the backward (chunks > 1: of its FIRST chunk) to the end of the step: the collectives AND the "
+                                       "Adam / SH-rebuild kernels (and remaining backward chunks) that run behind them; 0.43 ms of Adam / rebuild kernels at 2M "
+                                       "Gaussians in a one-rank group, where the collectives are copies",
                         "exposed_fraction_upper_bound": round(tail / max(comp + tail, 1e-9), 4), "bytes_sent_per_rank_per_step": None if sent is None else int(sent),
                         "world": n}
     if graphed["gs"] is not None:

@@ -522,7 +522,7 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
                              char* sample_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                              float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_ddc, float* dL_dsh, float* dL_dscale,
                              float* dL_drot, float lambda_erank, const gslic_adam_fused* adam, float* const dL_dcam[3], void* stream,
-                             float* dL_drgb = nullptr)
+                             float* dL_drgb = nullptr, int32_t row_begin = 0, int32_t row_end = -1, bool skip_blend = false)
 {
     (void)background; (void)dc;
     GS_TRY(check_params(prm));
@@ -561,11 +561,14 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
     rb.ranges = img.ranges; rb.point_list = bin.point_list(); rb.inst_slot = bin.inst_slot(); rb.rec = geom.rec;
     rb.bucket_offsets = img.bucket_offsets; rb.bucket_to_tile = smp.bucket_to_tile; rb.ckpt = smp.ckpt; rb.hit = smp.hit; rb.pix_final = img.pix_final;
     rb.max_contrib = img.max_contrib; rb.dL_dpix = dL_dpix; rb.partials = bin.partials; rb.dead = bin.dead; rb.status = geom.flags; rb.T = T;
-    GS_TRY(launch_render_bwd(rb, s));
+    if (!skip_blend) GS_TRY(launch_render_bwd(rb, s));   // (a chunked per-Gaussian backward runs the blend backward with its first chunk only)
     DEBUG_SYNC(prm, s);
 
     PreprocessBwdArgs pb;
     pb.P = P; pb.D = prm->D; pb.M = prm->M; pb.W = prm->width; pb.H = prm->height; pb.raw = prm->raw_params;
+    pb.row_begin = row_begin; pb.row_end = row_end < 0 ? P : row_end;
+    if (pb.row_begin < 0 || pb.row_end > P || pb.row_begin > pb.row_end || (pb.row_begin & 63))
+        return set_error(GSLIC_ERR_INVALID_ARG, "row range [%d, %d) of %d Gaussians (row_begin must be a multiple of 64)", pb.row_begin, pb.row_end, P);
     pb.focal_y = prm->height / (2.0f * prm->tan_fovy);
     pb.focal_x = prm->width / (2.0f * prm->tan_fovx);
     pb.limx_neg = prm->limx_neg; pb.limx_pos = prm->limx_pos; pb.limy_neg = prm->limy_neg; pb.limy_pos = prm->limy_pos;
@@ -625,6 +628,21 @@ int gslic_rasterize_backward_rgb(const gslic_raster_params* prm, int32_t R, int3
                                    projmatrix, cam_pos, radii, geom_buffer, binning_buffer, img_buffer, sample_buffer, dL_dpix, nullptr,
                                    nullptr, dL_dopacity, nullptr, dL_dmean3D, nullptr, nullptr, nullptr, dL_dscale, dL_drot, lambda_erank,
                                    nullptr, nullptr, stream, dL_drgb);
+}
+
+int gslic_rasterize_backward_rgb_rows(const gslic_raster_params* prm, int32_t R, int32_t B, const float* background, const float* means3D,
+                                      const float* dc, const float* shs, const float* colors_precomp, const float* scales,
+                                      const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                      const float* cam_pos, const int32_t* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
+                                      char* sample_buffer, const float* dL_dpix, float* dL_dopacity, float* dL_dmean3D, float* dL_drgb,
+                                      float* dL_dscale, float* dL_drot, float lambda_erank, int32_t row_begin, int32_t row_end, int32_t skip_blend,
+                                      void* stream)
+{
+    if (!dL_drgb) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_rasterize_backward_rgb_rows: dL_drgb is NULL");
+    return rasterize_backward_impl(prm, R, B, background, means3D, dc, shs, colors_precomp, scales, rotations, cov3D_precomp, viewmatrix,
+                                   projmatrix, cam_pos, radii, geom_buffer, binning_buffer, img_buffer, sample_buffer, dL_dpix, nullptr,
+                                   nullptr, dL_dopacity, nullptr, dL_dmean3D, nullptr, nullptr, nullptr, dL_dscale, dL_drot, lambda_erank,
+                                   nullptr, nullptr, stream, dL_drgb, row_begin, row_end, skip_blend != 0);
 }
 
 int gslic_sh_grad_from_rgb(int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D, const float* campos_all,

@@ -83,6 +83,8 @@ struct AdamFusedArgs {
 
 struct PreprocessBwdArgs {
     int P, D, M, W, H, raw;
+    int row_begin, row_end;   // Gaussians [row_begin, row_end) of the P are processed (the whole range by default; row_begin % 64 == 0): the N > 1
+                              // exchange runs the per-Gaussian backward in chunks and ships a chunk while the next one is computed
     float focal_x, focal_y;
     float limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier, lambda_erank;
     const float *means, *scales, *rots, *dc, *shs, *view, *proj, *campos;

@@ -134,11 +134,11 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
     // cooperative float4 Adam below: per-thread 4-byte accesses at stride 12 / 16 B cost this kernel 0.29 ms of 0.86
     float* const lds_g = lds_sh;  // overlays the head of lds_sh between "SH rows consumed" and "dL_dsh rows written" (LDS per wave 15.2 -> 11.6 KB)
     if (a.status[2] != 0u) return;  // capacity overflow in the forward: nothing of this step is valid — no gradients, no Adam
-    const int idx = blockIdx.x * BS + threadIdx.x;
+    const int idx = a.row_begin + blockIdx.x * BS + threadIdx.x;
     const int M = a.M;
-    lds_vis[threadIdx.x] = (idx < a.P && a.radii[idx] > 0) ? 1 : 0;
-    const int row0 = blockIdx.x * BS;
-    const int rows = (a.P - row0) < BS ? (a.P - row0) : BS;
+    lds_vis[threadIdx.x] = (idx < a.row_end && a.radii[idx] > 0) ? 1 : 0;
+    const int row0 = a.row_begin + blockIdx.x * BS;
+    const int rows = (a.row_end - row0) < BS ? (a.row_end - row0) : BS;
     if constexpr (LDS_SH) {
         const float* src = a.shs + (size_t)row0 * 45;
         if (rows == BS) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
 #pragma unroll
         for (int k = 0; k < 27; k++) cg[k] = 0.f;
     }
-    if (idx < a.P) bwd_phase_a<LDS_SH, CAM>(a, idx, M, sh_row, so, LDS_SH ? sg : nullptr, cg);
+    if (idx < a.row_end) bwd_phase_a<LDS_SH, CAM>(a, idx, M, sh_row, so, LDS_SH ? sg : nullptr, cg);
     if constexpr (CAM) {
 #pragma unroll
         for (int k = 0; k < 27; k++) {
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
     // ---- phase B: this Gaussian's dL_dsh row (zeros when invisible, when shs == NULL, and above the active degree)
     if constexpr (LDS_SH) {
         if (!a.dL_dsh && !a.adam.on) return;   // (dL_drgb mode: the rows are rebuilt after the exchange)
-        if (idx < a.P) {
+        if (idx < a.row_end) {
             float* drow = lds_sh + threadIdx.x * 45;
             if (so.on) {
                 float c[15];
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
                 if (A.on && lds_vis[i / 45]) adam_scalar(A.p[2][base + i], g, A.m[2][base + i], A.v[2][base + i], A.lr[2], A.b1, A.b2, A.eps);
             }
         }
-    } else if (idx < a.P && M > 0 && (a.dL_dsh || a.adam.on)) {
+    } else if (idx < a.row_end && M > 0 && (a.dL_dsh || a.adam.on)) {
         // generic row width: per-thread strided rows (dL_dsh zeros when invisible, when shs == NULL, above the active degree)
         const AdamFusedArgs& A = a.adam;
         float c[15];
@@ -656,15 +656,17 @@ __global__ __launch_bounds__(256) void cam_reduce_kernel(size_t rows, const floa
 int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
 {
     const bool cam = a.cam_partials != nullptr;
+    const int nrows = a.row_end - a.row_begin;
+    if (nrows <= 0) return GSLIC_OK;
     if (cam) GS_HIP(hipMemsetAsync(a.cam_out, 0, 35 * sizeof(float), s));  // row 3 of the view matrix, row 2 of the projection: untouched terms
     if (a.M == 15 && a.shs && (a.dL_dsh || a.adam.on || a.dL_drgb)) {
         // one wave per workgroup: 64 Gaussians' SH rows (11.25 KiB) + small-group gradients in LDS, the phase barriers are wave-level,
         // and ten workgroups per CU sit in different phases (measured 0.72 ms against 0.75 at 128 and 0.88 at 256 threads)
-        if (cam) GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64, true>), dim3(div_up(a.P, 64)), dim3(64), 0, s, a);
-        else GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64, false>), dim3(div_up(a.P, 64)), dim3(64), 0, s, a);
+        if (cam) GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64, true>), dim3(div_up(nrows, 64)), dim3(64), 0, s, a);
+        else GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64, false>), dim3(div_up(nrows, 64)), dim3(64), 0, s, a);
     } else {
-        if (cam) GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<false, 256, true>), dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
-        else GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<false, 256, false>), dim3(div_up(a.P, 256)), dim3(256), 0, s, a);
+        if (cam) GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<false, 256, true>), dim3(div_up(nrows, 256)), dim3(256), 0, s, a);
+        else GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<false, 256, false>), dim3(div_up(nrows, 256)), dim3(256), 0, s, a);
     }
     if (cam) {
         const size_t rows = (a.M == 15 && a.shs && (a.dL_dsh || a.adam.on || a.dL_drgb)) ? (size_t)div_up(a.P, 64) : (size_t)div_up(a.P, 256) * 4;

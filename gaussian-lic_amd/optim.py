@@ -50,29 +50,38 @@ class SparseGaussianAdam:
             self.state[i] = dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
         return self.state[i]
 
-    def step(self, grads=None, only=None):
+    def step(self, grads=None, only=None, rows=None, grad_addr=None):
         """grads: optional list of gradient tensors (defaults to each param's .grad); only: optional subset of group indices
-        (the pipelined N > 1 exchange updates a group as soon as its gradients have been reduced)."""
+        (the pipelined N > 1 exchange updates a group as soon as its gradients have been reduced).
+        rows = (p0, p1): update Gaussians [p0, p1) only — the chunked exchange; grad_addr = {group index: device address of the chunk's
+        gradient block, row p0 first} when the chunk's gradients do not live at their rows of `grads`."""
         groups, keep = [], []
+        p0, p1 = (0, self.N) if rows is None else (int(rows[0]), int(rows[1]))
         for i, prm in enumerate(self.params):
             if only is not None and i not in only:
                 continue
             g = grads[i] if grads is not None else prm.grad
-            if g is None or prm.numel() == 0:   # an empty group (features_rest [P,0,3] at SH degree 0) is a no-op, as in the reference
+            if (g is None and not (grad_addr and i in grad_addr)) or prm.numel() == 0:   # an empty group (features_rest [P,0,3] at SH degree 0) is a no-op, as in the reference
                 continue
             st = self._ensure_state(i)
-            g = g.contiguous()
-            keep.append(g)
             M = prm.numel() // self.N
-            groups.append(_lib.AdamGroup(prm.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+            if grad_addr and i in grad_addr:
+                g_ptr = int(grad_addr[i])
+            else:
+                g = g.contiguous()
+                keep.append(g)
+                g_ptr = g.data_ptr() + 4 * M * p0
+            off = 4 * M * p0
+            groups.append(_lib.AdamGroup(prm.data_ptr() + off, g_ptr, st["exp_avg"].data_ptr() + off, st["exp_avg_sq"].data_ptr() + off,
                                          self.lrs[i], M))
-            st["step"] += 1
-        if not groups:
+            if rows is None or p1 == self.N:
+                st["step"] += 1
+        if not groups or p1 <= p0:
             return
         arr = (_lib.AdamGroup * len(groups))(*groups)
         vis = self.visibility.contiguous()
-        _lib.check(_lib.lib().gslic_adam_update_groups(arr, len(groups), _lib.ptr(vis), self.betas[0], self.betas[1], self.eps,
-                                                       self.N, _lib.current_stream_ptr()))
+        _lib.check(_lib.lib().gslic_adam_update_groups(arr, len(groups), ctypes.c_void_p(vis.data_ptr() + p0), self.betas[0], self.betas[1], self.eps,
+                                                       p1 - p0, _lib.current_stream_ptr()))
 
     def fused_descriptor(self):
         """gslic_adam_fused for gslic_rasterize_backward_adam: the six groups' parameters and moments, learning rates, betas, eps."""
@@ -86,7 +95,7 @@ class SparseGaussianAdam:
         d.b1, d.b2, d.eps = self.betas[0], self.betas[1], self.eps
         return d
 
-    def step_sh_from_rgb(self, means3D, campos_all, rgb_all, degree, n_views=None, view_stride=0):
+    def step_sh_from_rgb(self, means3D, campos_all, rgb_all, degree, n_views=None, view_stride=0, rows=None):
         """Groups 1 and 2 (features_dc, features_rest) of an N > 1 step: their summed gradients are rebuilt from the views' exchanged colour
         gradients and consumed by the masked Adam update in the same kernel (gslic_sh_grad_from_rgb_adam) — bit-identical to rebuilding the
         rows and calling step(only=[1, 2]), without writing and re-reading 192 B per Gaussian.  set_visibility_and_N() first.
@@ -98,11 +107,23 @@ class SparseGaussianAdam:
             assert rgb_all.is_contiguous() and campos_all.is_contiguous() and tuple(rgb_all.shape) == (n, P, 3)
         d = self.fused_descriptor()
         vis = self.visibility.contiguous()
-        _lib.check(_lib.lib().gslic_sh_grad_from_rgb_adam(P, int(degree), M, n, _lib.ptr(means3D.contiguous()), _lib.ptr(campos_all), _lib.ptr(rgb_all), 0,
-                                                          _lib.ptr(vis), ctypes.byref(d), None, None, int(view_stride), _lib.current_stream_ptr()))
-        for i in (1, 2):
-            if self.state[i] is not None:
-                self.state[i]["step"] += 1
+        means3D = means3D.contiguous()
+        vp = ctypes.c_void_p
+        if rows is None:
+            p0, nrow = 0, P
+        else:   # Gaussians [p0, p1) only (p0 a multiple of 64): rgb_all / campos_all then hold THAT chunk's gathered payload, row p0 first
+            p0, nrow = int(rows[0]), int(rows[1]) - int(rows[0])
+            assert p0 % 64 == 0
+            for i, w in ((1, 3), (2, 3 * M)):
+                if d.param[i]:
+                    d.param[i] += 4 * w * p0; d.exp_avg[i] += 4 * w * p0; d.exp_avg_sq[i] += 4 * w * p0
+        if nrow > 0:
+            _lib.check(_lib.lib().gslic_sh_grad_from_rgb_adam(nrow, int(degree), M, n, vp(means3D.data_ptr() + 12 * p0), _lib.ptr(campos_all), _lib.ptr(rgb_all), 0,
+                                                              vp(vis.data_ptr() + p0), ctypes.byref(d), None, None, int(view_stride), _lib.current_stream_ptr()))
+        if rows is None or int(rows[1]) == P:
+            for i in (1, 2):
+                if self.state[i] is not None:
+                    self.state[i]["step"] += 1
 
     def count_step(self):
         for st in self.state:

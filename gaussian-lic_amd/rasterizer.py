@@ -139,7 +139,8 @@ def rasterize_gaussians_capacity(bufs, background, means3D, opacity, scales, rot
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                                  projmatrix, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, dL_dout_color, dc, sh,
                                  degree, campos, geomBuffer, R, binningBuffer, imageBuffer, B, sampleBuffer, lambda_erank, debug,
-                                 raw_params=False, out=None, adam=None, camera_grads=False, rgb_out=None):
+                                 raw_params=False, out=None, adam=None, camera_grads=False, rgb_out=None, rows=None, skip_blend=False,
+                                 out_addr=None):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:151-246): returns (dL_dmeans2D, dL_dcolors_precomp,
     dL_dopacities, dL_dmeans3D, dL_dcov3Ds_precomp, dL_ddc, dL_dsh, dL_dscales, dL_drotations).
     raw_params=True: scales / rotations are raw and dL_dopacities / dL_dscales / dL_drotations are w.r.t. the raw parameters.
@@ -175,6 +176,19 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             viewmatrix, projmatrix, campos, background = map(_f32c, (viewmatrix, projmatrix, campos, background))
             prm = _params(P, degree, M, H, W, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier, False, debug, False, raw_params)
             p = _lib.ptr
+            if rows is not None:
+                # chunked (gslic_rasterize_backward_rgb_rows): Gaussians [rows[0], rows[1]) only; the kernels index the gradient pointers by the
+                # ABSOLUTE Gaussian index, so a caller that keeps its chunks in separate blocks passes `out_addr` = {name: address of row 0}
+                addr = out_addr or {k: out[k].data_ptr() for k in ("opacity", "xyz", "scaling", "rotation")}
+                rgb_addr = (out_addr or {}).get("rgb", rgb_out.data_ptr())
+                vp = ctypes.c_void_p
+                _lib.check(L.gslic_rasterize_backward_rgb_rows(
+                    ctypes.byref(prm), int(R), int(B), p(background), p(means3D), p(dc), p(sh_c), p(colors), p(scales), p(rotations),
+                    p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos), p(radii.contiguous()),
+                    vp(geomBuffer.data_ptr()), vp(binningBuffer.data_ptr()), vp(imageBuffer.data_ptr()), vp(sampleBuffer.data_ptr()), p(dL),
+                    vp(addr["opacity"]), vp(addr["xyz"]), vp(rgb_addr), vp(addr["scaling"]), vp(addr["rotation"]),
+                    float(lambda_erank), int(rows[0]), int(rows[1]), int(bool(skip_blend)), _lib.current_stream_ptr()))
+                return None
             _lib.check(L.gslic_rasterize_backward_rgb(
                 ctypes.byref(prm), int(R), int(B), p(background), p(means3D), p(dc), p(sh_c), p(colors), p(scales), p(rotations),
                 p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos), p(radii.contiguous()),

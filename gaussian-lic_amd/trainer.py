@@ -148,6 +148,15 @@ def _dist_mark(name):
         DIST_TIMING.setdefault(name, []).append(ev)
 
 
+def exchange_chunks():
+    """GSLIC_EXCHANGE_CHUNKS = C > 1: the rank-1 exchange runs the per-Gaussian backward in C row chunks and puts chunk c on the wire (one
+    all-gather + one all-reduce per chunk) while chunk c + 1 is computed; the Adam updates of a chunk follow its collectives.  Default 1."""
+    try:
+        return max(1, int(os.environ.get("GSLIC_EXCHANGE_CHUNKS", "1")))
+    except ValueError:
+        return 1
+
+
 def _dist_on():
     """True when the per-step gradient exchange has to run.  GSLIC_FORCE_DIST=1 also takes the exchange path in a process group of
     ONE rank (the RCCL smoke test on a single-GPU box: same code path as N > 1, the all-reduce degenerates to a copy)."""
@@ -292,6 +301,85 @@ def exchange_rank1(slab, rgb_local, visible, model, campos):
     return vis, [(_Rebuild(), [] if fused else [1, 2])] + works
 
 
+class _ChunkedExchange:
+    """Buffers of the chunked rank-1 exchange for one (P, world, chunks): per chunk c = rows [p0, p1) a block of the 11 small gradient floats
+    {xyz [n,3] | opacity [n] | scaling [n,3] | rotation [n,4]} (ONE all-reduce) and an all-gather payload {dRGB [n,3], camera centre [3],
+    visibility [n] bytes}.  The backward kernels index their outputs by the absolute Gaussian index: they get the blocks' addresses moved back
+    by p0 rows."""
+
+    def __init__(self, P, world, chunks, device):
+        self.P, self.world, self.chunks = P, world, chunks
+        step = -(-P // chunks)
+        step = -(-step // 256) * 256
+        self.bounds = [(p0, min(p0 + step, P)) for p0 in range(0, P, step)]
+        self.small = torch.empty(11 * P, device=device)
+        self.vis = torch.zeros(P, dtype=torch.uint8, device=device)
+        self.pay, self.pay_all, self.small_off = [], [], []
+        off = 0
+        for p0, p1 in self.bounds:
+            n = p1 - p0
+            nbytes = (12 * n + 12 + n + 3) // 4 * 4
+            self.pay.append(torch.zeros(nbytes, dtype=torch.uint8, device=device))
+            self.pay_all.append(torch.empty(world, nbytes, dtype=torch.uint8, device=device))
+            self.small_off.append(off)
+            off += 11 * n
+
+
+def training_step_rank1_chunked(model, cam, bg, dL_dimage, fwd, chunks):
+    """The N > 1 step behind the forward and the loss, with the exchange overlapped chunk by chunk (exchange_chunks()).  Per chunk: the
+    per-Gaussian backward of its rows (the blend backward runs once, with the first chunk), then — asynchronously, on RCCL's streams — ONE
+    all-gather of the chunk's {dRGB, camera centre, mask} and ONE all-reduce of its 11 small gradient floats, while the next chunk is being
+    computed.  Then, chunk by chunk as the collectives land: OR of the masks, SH rows rebuilt and consumed by the masked Adam of
+    features_dc / features_rest, Adam of the four small groups.  Same arithmetic per Gaussian as the unchunked step."""
+    from . import rasterizer as rz
+    dist = torch.distributed
+    R, B, radii, geom, binning, img, sample = fwd
+    dev = model.device
+    e = torch.empty(0, device=dev)
+    n_world = dist.get_world_size()
+    cx = getattr(model, "_chunk_xchg", None)
+    if cx is None or cx.P != model.P or cx.world != n_world or cx.chunks != chunks:
+        cx = model._chunk_xchg = _ChunkedExchange(model.P, n_world, chunks, dev)
+    xyz, dc, rest = model.xyz.detach(), model.features_dc.detach(), model.features_rest.detach()
+    sc, rot = model.scaling.detach(), model.rotation.detach()
+    slab = model._grad_slab
+    visible_local = (radii > 0).to(torch.uint8)
+    works = []
+    for c, (p0, p1) in enumerate(cx.bounds):
+        n = p1 - p0
+        sm = cx.small.data_ptr() + 4 * cx.small_off[c]
+        pay = cx.pay[c]
+        addr = {"xyz": sm - 12 * p0, "opacity": sm + 12 * n - 4 * p0, "scaling": sm + 16 * n - 12 * p0, "rotation": sm + 28 * n - 16 * p0,
+                "rgb": pay.data_ptr() - 12 * p0}
+        rz.rasterize_gaussians_backward(
+            bg, xyz, radii, e, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
+            float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dL_dimage, dc, rest, model.sh_degree,
+            cam.d_camera_center, geom, R, binning, img, B, sample, model.lambda_erank, False, raw_params=True, out=slab.views, rgb_out=slab.rgb,
+            rows=(p0, p1), skip_blend=(c > 0), out_addr=addr)
+        pay[12 * n:12 * n + 12].view(torch.float32).copy_(cam.d_camera_center.reshape(3))
+        pay[12 * n + 12:12 * n + 12 + n].copy_(visible_local[p0:p1])
+        if c == 0:
+            _dist_mark("bwd_done")   # (first chunk on the wire: everything behind it overlaps with the remaining chunks' compute)
+        w_pay = dist.all_gather_into_tensor(cx.pay_all[c], pay.view(1, -1), async_op=True)
+        w_red = dist.all_reduce(cx.small[cx.small_off[c]:cx.small_off[c] + 11 * n], op=dist.ReduceOp.SUM, async_op=True)
+        works.append((w_pay, w_red))
+    model.optimizer.set_visibility_and_N(cx.vis, model.P)
+    for c, (p0, p1) in enumerate(cx.bounds):
+        n = p1 - p0
+        w_pay, w_red = works[c]
+        w_pay.wait()
+        pa = cx.pay_all[c]
+        cx.vis[p0:p1] = pa[:, 12 * n + 12:12 * n + 12 + n].max(0).values
+        rgb0 = pa[0, :12 * n].view(torch.float32)
+        cam0 = pa[0, 12 * n:12 * n + 12].view(torch.float32)
+        model.optimizer.step_sh_from_rgb(xyz, cam0, rgb0, model.sh_degree, n_views=n_world, view_stride=pa.shape[1] // 4, rows=(p0, p1))
+        w_red.wait()
+        sm = cx.small.data_ptr() + 4 * cx.small_off[c]
+        model.optimizer.step(None, only=[0, 3, 4, 5], rows=(p0, p1), grad_addr={0: sm, 3: sm + 12 * n, 4: sm + 16 * n, 5: sm + 28 * n})
+    _dist_mark("end")
+    return cx.vis.bool()
+
+
 def allreduce_gradients(grads, visible):
     """The per-step exchange: SUM of the concatenated gradient slab [P x (11+3K)] and MAX (= OR) of the visibility
     bytes.  One collective each; returns (list of reduced gradient views, reduced visibility)."""
@@ -360,6 +448,9 @@ def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=Tr
         if slab is None or slab.P != model.P:
             slab = model._grad_slab = GradSlab(model)
         mode = exchange_mode() if (do_step and _dist_on()) else None
+        if mode == "rank1" and exchange_chunks() > 1 and os.environ.get("GSLIC_RANK1_SPLIT_ADAM") != "1":
+            visible = training_step_rank1_chunked(model, cam, bg, dL_dimage, (R, B, radii, geom, binning, img, sample), exchange_chunks())
+            return terms, visible
         if mode == "rank1":
             # the SH gradients travel as the 3-float colour gradient they are the outer product of (exchange_rank1)
             rz.rasterize_gaussians_backward(

@@ -250,6 +250,18 @@ int gslic_rasterize_backward_rgb(
     char* geom_buffer, char* binning_buffer, char* img_buffer, char* sample_buffer, const float* dL_dpix,
     float* dL_dopacity, float* dL_dmean3D, float* dL_drgb, float* dL_dscale, float* dL_drot,
     float lambda_erank, void* stream);
+/* gslic_rasterize_backward_rgb in row chunks: the per-Gaussian half of the backward for Gaussians [row_begin, row_end) only (row_begin a
+ * multiple of 64; the gradient pointers are still indexed by the ABSOLUTE Gaussian index), the blend half (one pass over the whole image) unless
+ * skip_blend.  A host that exchanges gradients calls it once per chunk — the first call with skip_blend = 0 — and puts chunk c on the wire
+ * while chunk c + 1 is computed. */
+int gslic_rasterize_backward_rgb_rows(
+    const gslic_raster_params* prm, int32_t R, int32_t B,
+    const float* background, const float* means3D, const float* dc, const float* shs, const float* colors_precomp,
+    const float* scales, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos, const int32_t* radii,
+    char* geom_buffer, char* binning_buffer, char* img_buffer, char* sample_buffer, const float* dL_dpix,
+    float* dL_dopacity, float* dL_dmean3D, float* dL_drgb, float* dL_dscale, float* dL_drot,
+    float lambda_erank, int32_t row_begin, int32_t row_end, int32_t skip_blend, void* stream);
 int gslic_sh_grad_from_rgb(
     int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D, const float* campos_all /*[n_views,3]*/,
     const float* rgb_all /*[n_views,P,3]*/, int32_t input_is_ddc, float* dL_ddc, float* dL_dsh, int64_t view_stride, void* stream);
