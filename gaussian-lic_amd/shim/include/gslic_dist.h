@@ -70,9 +70,12 @@ inline torch::Tensor exchange_gradients(c10d::Backend& pg, const std::vector<tor
 
 // The same exchange with the SH gradients shipped as what they are — rank-1 (include/gslic_hip.h, gslic_sh_grad_from_rgb): the SH backward
 // is linear in the clamp-masked colour gradient, dL_ddc = SH_C0 dRGB and dL_dsh[k] = c_k(view direction) dRGB, so only xyz / opacity /
-// scaling / rotation (11 of 59 floats) are all-reduced; the ranks all-gather their dL_ddc (3 floats) and camera centres and every
-// rank rebuilds the summed dL_ddc / dL_dsh of all views itself.  A rank sends 2 (N-1)/N 44 P + (N-1) 12 P bytes per step instead of
-// 2 (N-1)/N 236 P: 4.2x less at N = 2, 2.6x at N = 8 — on point-to-point xGMI links that is the exposed part of the step.
+// scaling / rotation (11 of 59 floats) are all-reduced; the ranks all-gather their dL_ddc (3 floats) and every rank rebuilds the summed
+// dL_ddc / dL_dsh of all views itself.  A rank sends 2 (N-1)/N 44 P + (N-1) 13 P bytes per step instead of 2 (N-1)/N 236 P: 4.1x less at
+// N = 2, 2.5x at N = 8 — on point-to-point xGMI links that is the exposed part of the step.
+// TWO collectives, both asynchronous, neither in front of the other: ONE all-gather of a per-rank payload {dL_ddc [P,3], camera centre [3],
+// visibility [P] bytes} — the rebuild kernel reads the gathered blocks in place through view_stride, the masks are OR-ed locally (no
+// separate MAX-reduce) — and ONE all-reduce of the four small groups as one slab.
 // This host only has the reference's gradient tensors, so dRGB is recovered from dL_ddc (exact to 1 ulp); all replicas rebuild the
 // identical rows, so they stay bit-identical to each other.
 //   params: {xyz, features_dc, features_rest, opacity, scaling, rotation};  camera_center: [3] device (Camera::camera_center_).
@@ -82,10 +85,6 @@ inline torch::Tensor exchange_gradients_rank1(c10d::Backend& pg, const std::vect
     torch::NoGradGuard no_grad;
     TORCH_CHECK(params.size() == 6, "exchange_gradients_rank1: six parameter groups expected");
     const int64_t P = visible.size(0), world = pg.getSize();
-    std::vector<at::Tensor> vis{visible.to(torch::kUInt8).contiguous()};
-    c10d::AllreduceOptions mx;
-    mx.reduceOp = c10d::ReduceOp::MAX;
-    pg.allreduce(vis, mx)->wait();
     std::vector<torch::Tensor> grads;
     for (const auto& p : params) grads.push_back(p.grad().defined() ? p.grad().contiguous() : torch::zeros_like(p));
     const int small_groups[4] = {0, 3, 4, 5};
@@ -93,17 +92,22 @@ inline torch::Tensor exchange_gradients_rank1(c10d::Backend& pg, const std::vect
     for (int g : small_groups) rows.push_back(grads[g].reshape({-1}));
     std::vector<at::Tensor> slab{torch::cat(rows)};
     auto w_small = pg.allreduce(slab);
-    auto fo = grads[1].options();
-    at::Tensor dc_all = torch::empty({world, P, 3}, fo), campos_all = torch::empty({world, 3}, fo);
-    at::Tensor dc_mine = grads[1].reshape({1, P, 3}).contiguous(), campos_mine = camera_center.to(fo).reshape({1, 3}).contiguous();
-    auto w_cam = pg._allgather_base(campos_all, campos_mine);
-    auto w_dc = pg._allgather_base(dc_all, dc_mine);
-    w_cam->wait(); w_dc->wait();
+    // the all-gather payload of this rank
+    const int64_t pay_bytes = (12 * P + 12 + P + 3) / 4 * 4;
+    auto bo = grads[1].options().dtype(torch::kUInt8);
+    at::Tensor pay = torch::zeros({pay_bytes}, bo), pay_all = torch::empty({world, pay_bytes}, bo);
+    pay.narrow(0, 0, 12 * P).view(torch::kFloat32).copy_(grads[1].reshape({-1}));
+    pay.narrow(0, 12 * P, 12).view(torch::kFloat32).copy_(camera_center.to(grads[1].options()).reshape({3}));
+    pay.narrow(0, 12 * P + 12, P).copy_(visible.to(torch::kUInt8));
+    at::Tensor pay_in = pay.view({1, pay_bytes});
+    pg._allgather_base(pay_all, pay_in)->wait();
+    torch::Tensor mask = std::get<0>(pay_all.narrow(1, 12 * P + 12, P).max(0)).to(torch::kBool);
     const int64_t M = params[2].numel() ? params[2].size(1) : 0;
     at::Tensor xyz = params[0].detach().contiguous();
-    int rc = gslic_sh_grad_from_rgb((int32_t)P, sh_degree, (int32_t)M, (int32_t)world, xyz.data_ptr<float>(), campos_all.data_ptr<float>(),
-                                    dc_all.data_ptr<float>(), /*input_is_ddc=*/1, grads[1].data_ptr<float>(), M ? grads[2].data_ptr<float>() : nullptr,
-                                    /*view_stride=*/0, /*stream=*/current_stream());
+    const uint8_t* base = pay_all.data_ptr<uint8_t>();
+    int rc = gslic_sh_grad_from_rgb((int32_t)P, sh_degree, (int32_t)M, (int32_t)world, xyz.data_ptr<float>(), reinterpret_cast<const float*>(base + 12 * P),
+                                    reinterpret_cast<const float*>(base), /*input_is_ddc=*/1, grads[1].data_ptr<float>(),
+                                    M ? grads[2].data_ptr<float>() : nullptr, /*view_stride=*/pay_bytes / 4, /*stream=*/current_stream());
     TORCH_CHECK(rc == GSLIC_OK, "gslic_sh_grad_from_rgb failed: ", gslic_last_error());
     w_small->wait();
     int64_t off = 0;
@@ -114,7 +118,7 @@ inline torch::Tensor exchange_gradients_rank1(c10d::Backend& pg, const std::vect
     }
     for (size_t i = 0; i < 6; i++)
         if (!params[i].grad().defined() || !params[i].grad().is_contiguous()) params[i].mutable_grad() = grads[i];
-    return vis[0].to(torch::kBool);
+    return mask;
 }
 
 }  // namespace gslic
