@@ -602,13 +602,15 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
 
 int launch_render_fwd(const RenderFwdArgs& a, hipStream_t s)
 {
-    // waves per tile: two halve the serial chain of a tile's wave, at the price of both fetching the tile's records — worth it while the
-    // tiles alone do not fill the machine (1080p: 8160 tiles, 0.33 -> 0.30 ms), not at 4K (32 400 tiles: 0.92 vs 1.00 ms).  GSLIC_FWD_SPLIT pins it.
+    // waves per tile: two halve the serial chain of a tile's wave, at the price of both fetching the tile's records — which the XCD-aware
+    // grid turns into an L2 hit.  Measured (profiles/r03h_fwd_split_ab.log): 1080p strict 0.364 (2 waves) vs 0.394 (4), fast 0.259 vs 0.291; 4K
+    // (32 400 tiles) strict 1.22 (2) vs 1.29 (1), fast 0.865 vs 0.875.  GSLIC_FWD_SPLIT pins it.
     static const int forced = [] { const char* e = getenv("GSLIC_FWD_SPLIT"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
     const unsigned T = (unsigned)(a.gx * a.gy);
-    const int split = forced ? forced : (T <= 16384u ? 2 : 1);
+    const int split = forced ? forced : 2;
     const unsigned groups = (T + 7u) / 8u;   // groups of 8 tiles x split waves (the kernel's blockIdx -> (tile rank, strips) mapping)
     if (g_strict_math && split == 1) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 1>), dim3(groups * 8u), dim3(64), 0, s, a);
+    else if (g_strict_math && split == 4) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 4>), dim3(groups * 32u), dim3(64), 0, s, a);
     else if (g_strict_math) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 2>), dim3(groups * 16u), dim3(64), 0, s, a);   // per-pixel arithmetic does not depend on the split
     else if (split == 1) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<false, 1>), dim3(groups * 8u), dim3(64), 0, s, a);
     else if (split == 4) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<false, 4>), dim3(groups * 32u), dim3(64), 0, s, a);
