@@ -180,8 +180,8 @@ struct BinningState {
 struct SampleState {
     uint32_t* bucket_to_tile; // [B]
     float4* ckpt;             // [B*256] {T, C.r, C.g, C.b} at the start of each bucket, per pixel
-    uint64_t* hit;            // [B*4*64] per bucket, 16x4 pixel strip q and list entry j: which of the strip's 64 pixels (bit = the forward's lane:
-                              // (row & 3) * 16 + column) blended entry j — written by the strict forward, read by the strict backward
+    uint64_t* hit;            // [B*256] per bucket and pixel (tile-major element order, like ckpt): bit j = the pixel blended entry j of the
+                              // bucket — written by the strict forward, read by the strict backward (its blend / skip decisions)
     static SampleState carve(const void* base, size_t B, size_t* bytes);
 };
 

@@ -4,9 +4,9 @@
 //   SPLIT WAVES PER 16x16 TILE (default 2), each blending 4 / SPLIT of the tile's four 8x8 pixel quadrants per lane (lane l owns
 //   pixel (l & 7, l >> 3) of every quadrant of its wave: quadrants cull better than 16x4 strips, -9 % pairs evaluated).  A wave fetches 64 list entries at a time (one 48-byte record per lane, three dwordx4 loads),
 //   pre-scales them, parks them in LDS and fetches entry j with three ds_read_b128 at a wave-uniform address (LDS broadcast, next
-//   entry prefetched): the kernel is VALU-issue bound and LDS reads cost no issue slot.  A 4-bit mask per entry says which strips
+//   entry prefetched): the kernel is VALU-issue bound and LDS reads cost no issue slot.  A 4-bit mask per entry says which quadrants
 //   it can reach at all; a checkpoint {T, C} per pixel is stored at every 64th entry (bucket = one wave of entries) as one coalesced
-//   1-KiB dwordx4 store per strip.  One wave per workgroup: no barrier anywhere.
+//   1-KiB dwordx4 store per quadrant.  One wave per workgroup: no barrier anywhere.
 //
 // render_bwd_kernel<BITS>  replaces PerGaussianRenderCUDA<3> (backward.cu:379-597)
 //   ONE WAVE PER BUCKET of 64 list entries: lane = Gaussian, the tile's pixels stream through the lanes as a 64-deep systolic
@@ -24,7 +24,7 @@ namespace gslic {
 // Upper bound of p2(x, y) = hA dx^2 + hC dy^2 + nB dx dy (dx = gx - x, dy = gy - y; a negative-definite form scaled by log2 e)
 // over the pixel rectangle [x0, x1] x [y0, y1], plus a rounding margin: the maximum of a concave quadratic over a rectangle that
 // does not contain its centre lies on an edge facing the centre, where it is a 1-D parabola.  Used to skip whole 16x4 pixel
-// strips that an entry cannot reach (alpha < 1/255 everywhere): conservative, so the image is unchanged bit for bit.
+// quadrants that an entry cannot reach (alpha < 1/255 everywhere): conservative, so the image is unchanged bit for bit.
 __device__ __forceinline__ float strip_max_p2(float hA, float hC, float nB, float gx, float gy, float x0, float x1, float y0, float y1)
 {
     const bool in_x = gx >= x0 && gx <= x1, in_y = gy >= y0 && gy <= y1;
@@ -54,7 +54,7 @@ __device__ __forceinline__ float strip_max_p2(float hA, float hC, float nB, floa
 // final_T and n_contrib then equal the reference kernels' bit for bit.  The default (fast) variant pre-scales the conic by log2(e),
 // works in tile-relative coordinates and uses v_exp_f32 directly; it differs by rounding only, which flips the alpha < 1/255 /
 // T < 1e-4 decisions of a few (pixel, Gaussian) pairs per million (counted in tests/test_fullsize_reference_gpu.py).
-// SPLIT = waves per tile (1, 2 or 4; blockIdx.y): each takes 4 / SPLIT of the tile's four 16x4 strips.  The kernel's duration is set by its
+// SPLIT = waves per tile (1, 2 or 4): each takes 4 / SPLIT of the tile's four 8x8 quadrants.  The kernel's duration is set by its
 // longest tiles (one wave alone on a SIMD issues a VALU instruction every 4.3 cycles, half the rate of a busy SIMD), so the default
 // splits every tile over two waves: +9 % instructions (the per-entry setup is repeated), half the latency of a long tile.
 template <bool STRICT, int SPLIT>
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
 {
     constexpr int QN = 4 / SPLIT;          // quadrants (= pixels per lane) of this wave
     __shared__ float4 s_rec[3 * GS_BUCKET];
-    // 1-D grid in groups of 8 * SPLIT workgroups: workgroup b of a group works on tile 8 * group + b % 8, strips (b / 8) * QN...:
+    // 1-D grid in groups of 8 * SPLIT workgroups: workgroup b of a group works on tile 8 * group + b % 8, quadrants (b / 8) * QN...:
     // consecutive workgroups go to consecutive XCDs (eight L2s), so the SPLIT waves of one tile land on the SAME XCD, a few dispatches
     // apart — the second wave's fetch of the tile's records hits the L2 the first one filled (render_fwd 0.30 -> 0.265 ms).
     const uint32_t grp = blockIdx.x / (8u * SPLIT), rem = blockIdx.x % (8u * SPLIT);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
         __builtin_amdgcn_wave_barrier();
         // one list entry against this lane's four pixels.  STRICT: the reference's arithmetic with its branches.  Default: straight-line
         // code — a pixel the entry does not blend into (finished, power > 0, alpha < 1/255) runs the same instructions with weight 0,
-        // which leaves its colour, transmittance and last contributor unchanged bit for bit; only the per-strip skip (wave-uniform) branches
+        // which leaves its colour, transmittance and last contributor unchanged bit for bit; only the per-quadrant skip and the early-out (wave-uniform) branch
         uint32_t vcontrib = (uint32_t)base, vone = 1u;
         asm volatile("" : "+v"(vcontrib), "+v"(vone));
         // STRICT: every pixel collects WHICH entries of this batch it blended (bit j = entry j; one dword at a time: hcur rolls over into
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
         auto blend_entry = [&](const float4 e0, const float4 e1, const float4 e2, const uint32_t contributor) {
             vcontrib += vone;  // == contributor, kept in a VGPR (an SGPR operand doubles the issue cost of the select that reads it)
             if constexpr (STRICT) vbit = 1u << ((contributor - 1u) & 31u);   // (wave-uniform; one v_mov per entry)
-            const uint32_t smask = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(e2.y));  // this wave's strips
+            const uint32_t smask = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(e2.y));  // this wave's quadrants
             if (smask == 0u) return;
             const float gdx = e0.x, gdy = e0.y, hA = e0.z, nB = e0.w, hC = e1.x, op = e1.y, colr = e1.z, colg = e1.w, colb = e2.x;
             if constexpr (STRICT) {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
             blend_entry(b0, b1, b2, (uint32_t)(base + j + 2));
         }
         if constexpr (STRICT) {
-            if (color && fits) {   // pixel-major like the checkpoints: one coalesced 512-byte store per strip
+            if (color && fits) {   // pixel-major like the checkpoints: one coalesced 512-byte store per quadrant
                 uint64_t* hp = a.hit + ((size_t)(bbm + (uint32_t)(base / GS_BUCKET)) * GS_TILE_PIX) + lane;
 #pragma unroll
                 for (int q = 0; q < QN; q++)
@@ -608,7 +608,7 @@ int launch_render_fwd(const RenderFwdArgs& a, hipStream_t s)
     static const int forced = [] { const char* e = getenv("GSLIC_FWD_SPLIT"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
     const unsigned T = (unsigned)(a.gx * a.gy);
     const int split = forced ? forced : 2;
-    const unsigned groups = (T + 7u) / 8u;   // groups of 8 tiles x split waves (the kernel's blockIdx -> (tile rank, strips) mapping)
+    const unsigned groups = (T + 7u) / 8u;   // groups of 8 tiles x split waves (the kernel's blockIdx -> (tile, quadrants) mapping)
     if (g_strict_math && split == 1) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 1>), dim3(groups * 8u), dim3(64), 0, s, a);
     else if (g_strict_math && split == 4) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 4>), dim3(groups * 32u), dim3(64), 0, s, a);
     else if (g_strict_math) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 2>), dim3(groups * 16u), dim3(64), 0, s, a);   // per-pixel arithmetic does not depend on the split
