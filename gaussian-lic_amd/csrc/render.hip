@@ -567,20 +567,19 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     float T1 = 0.f, A1 = 0.f, T2, A2;
     float4 Ra, Rb;
     uint2 Ha = make_uint2(0u, 0u), Hb = make_uint2(0u, 0u);
-    uint32_t sidx = 0;
     int off = -8 * lane, kzero_i = 0, khi = 8 * (int)ninj, keight = 8;   // byte offset of entry (0 - lane); the clamp bounds; all in VGPRs
     asm volatile("" : "+v"(off), "+v"(kzero_i), "+v"(khi), "+v"(keight));
+    // Two steps per trip, an even number of steps: one step more than needed is harmless — every lane then holds a pixel at or behind its
+    // last contributor in this bucket (or the all-zero drain entry), which blends nothing — and the trip needs no exit test in its middle.
 #define GS_BW_LOOP(USE_BITS)                                                                                         \
     GS_BW_PREFETCH(USE_BITS, T2, A2, Ra, Ha);                                                                        \
-    for (;;) {                                                                                                       \
+    for (uint32_t sidx = 0; sidx < nsteps; sidx += 2) {                                                              \
         GS_BW_SHIFT_INJ(T2, A2, T1, A1); /* set 2 = state */                                                         \
         GS_BW_PREFETCH(USE_BITS, T1, A1, Rb, Hb);                                                                    \
         GS_BW_BODY(USE_BITS, T2, A2, Ra, Ha);                                                                        \
-        if (++sidx >= nsteps) break;                                                                                 \
         GS_BW_SHIFT_INJ(T1, A1, T2, A2); /* set 1 = state */                                                         \
         GS_BW_PREFETCH(USE_BITS, T2, A2, Ra, Ha);                                                                    \
         GS_BW_BODY(USE_BITS, T1, A1, Rb, Hb);                                                                        \
-        if (++sidx >= nsteps) break;                                                                                 \
     }
     if (use_bits) { GS_BW_LOOP(true) } else { GS_BW_LOOP(false) }
 #undef GS_BW_LOOP
