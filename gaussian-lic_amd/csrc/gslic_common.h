@@ -290,34 +290,10 @@ __device__ __forceinline__ float expf_core(float x, float kL2E, float kCC)
 #define GS_EXP_L2E 0x1.715476p+0f   /* log2(e) rounded to float: 0x3fb8aa3b */
 #define GS_EXP_CC 0x1.4ae0bep-26f   /* log2(e) - (float)log2(e): 0x32a5705f */
 
-// Canonical logf for the culling threshold (forward.cu:302): fixed double polynomial, identical to orc_logf.
-__device__ __forceinline__ float canon_logf(float x)
-{
-    uint32_t u = __float_as_uint(x);
-    int e = (int)(u >> 23) - 127;
-    if ((u >> 23) == 0) {
-        x = x * 8388608.0f;
-        u = __float_as_uint(x);
-        e = (int)(u >> 23) - 127 - 23;
-    }
-    u = (u & 0x007fffffu) | 0x3f800000u;
-    double m = (double)__uint_as_float(u);
-    if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1; }
-    double f = m - 1.0;
-    double s = f / (2.0 + f);
-    double z = s * s;
-    double p = 1.0 / 13.0;
-    p = p * z + 1.0 / 11.0;
-    p = p * z + 1.0 / 9.0;
-    p = p * z + 1.0 / 7.0;
-    p = p * z + 1.0 / 5.0;
-    p = p * z + 1.0 / 3.0;
-    p = p * z + 1.0;
-    double r = (double)e * 0.6931471805599453 + 2.0 * s * p;
-    return (float)r;
-}
-
-__device__ __forceinline__ float cull_threshold(float opacity) { return canon_logf(opacity / (1.0f / 255.0f)); }
+// Culling threshold (forward.cu:302, rasterizer_impl.cu:89): logf(opacity / (1/255)) with the toolchain's own logf, i.e. the very
+// instruction sequence the reference's kernels get from hipcc (v_log_f32 + the two-FMA ln2 tail): a tile count can then never differ from
+// theirs.  (The CPU oracle has a correctly rounded logf, <= 1 ulp away: oracle/gs_oracle.c, orc_logf.)
+__device__ __forceinline__ float cull_threshold(float opacity) { return logf(opacity / (1.0f / 255.0f)); }
 
 __device__ __forceinline__ int trunc_clamped(float v, int hi)
 {

@@ -71,6 +71,7 @@ struct RenderBwdArgs {
     uint8_t* dead;             // [R] set to 1 for the instances of dead buckets (zeroed by the forward)
     const uint32_t* status;    // device status words: a non-zero [2] (capacity overflow in the forward) aborts the kernel
     int T;                     // tiles: bucket_offsets[T - 1] is the real bucket count (B may be a capacity)
+    int xcd_lg;                // log2 of the run of consecutive buckets one XCD takes (launch_render_bwd); < 0: bucket = blockIdx.x
 };
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
 

@@ -55,11 +55,15 @@ __device__ __forceinline__ size_t sort_count(size_t n, const uint32_t* n_dev)
     const size_t m = (size_t)*n_dev;
     return m < n ? m : n;
 }
+// Block 0 also clears the chained-scan state of its own pass (the scan is the next kernel in the stream): no memset launch per sort.
 __global__ __launch_bounds__(RS_THREADS) void sort_hist_kernel(const uint32_t* __restrict__ keys, size_t n_cap, const uint32_t* __restrict__ n_dev,
-                                                               int shift, uint32_t* __restrict__ hist, uint32_t nblk)
+                                                               int shift, uint32_t* __restrict__ hist, uint32_t nblk,
+                                                               unsigned long long* __restrict__ scan_state, uint32_t scan_state_words)
 {
     __shared__ uint32_t h[256];
     const size_t n = sort_count(n_cap, n_dev);
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < scan_state_words; i += RS_THREADS) scan_state[i] = 0ull;
     h[threadIdx.x] = 0;
     __syncthreads();
     const size_t t0 = (size_t)blockIdx.x * RS_TILE + (size_t)threadIdx.x * RS_ITEMS;
@@ -283,7 +287,7 @@ SortPlan sort_plan(size_t n, int end_bit)
     return p;
 }
 
-// scratch layout: classic  u8 scan_state[4][scan_state_bytes(hist_elems)] (zeroed per sort) | u32 hist[256*nblk]
+// scratch layout: classic  u8 scan_state[4][scan_state_bytes(hist_elems)] (cleared by each pass's histogram kernel) | u32 hist[256*nblk]
 //                 onesweep u64 status[4][nblk*256] | u32 ghist[4*256] | u32 gbase[4*256] | u32 tickets[64]
 // (sized for 4 passes whatever the plan says, so that a buffer's layout depends on n alone)
 static size_t classic_bytes(const SortPlan& plan) { return 4 * scan_state_bytes(plan.hist_elems) + plan.hist_elems * sizeof(uint32_t); }
@@ -310,7 +314,6 @@ static int sort_impl(const SortBuffers& b, const SortPlan& plan, const uint32_t*
     uint32_t* ghist = reinterpret_cast<uint32_t*>(status + (size_t)4 * plan.nblk * 256);
     uint32_t* gbase = ghist + 4 * 256;
     uint32_t* tickets = gbase + 4 * 256;
-    if (!onesweep) GS_HIP(hipMemsetAsync(scratch, 0, (size_t)plan.passes * ssb, s));  // one chained-scan state per pass
     if (onesweep) {
         GS_HIP(hipMemsetAsync(scratch, 0, onesweep_bytes(plan), s));
         GS_LAUNCH(id_hist, sort_ghist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, (const uint32_t*)b.keys[0], plan.n, n_dev, plan.passes, ghist);
@@ -327,8 +330,10 @@ static int sort_impl(const SortBuffers& b, const SortPlan& plan, const uint32_t*
             a.table = gbase + p * 256; a.status = status + (size_t)p * plan.nblk * 256; a.ticket = tickets + p;
             GS_LAUNCH(id_scatter, (sort_scatter_kernel<NV, true>), dim3(nblk), dim3(RS_THREADS), 0, s, a);
         } else {
-            GS_LAUNCH(id_hist, sort_hist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, a.kin, plan.n, n_dev, a.shift, hist, nblk);
-            GS_TRY(scan_u32_chained(hist, nullptr, hist, plan.hist_elems, true, static_cast<char*>(scratch) + (size_t)p * ssb, s));
+            unsigned long long* const state = reinterpret_cast<unsigned long long*>(static_cast<char*>(scratch) + (size_t)p * ssb);  // one chained-scan state per pass
+            GS_LAUNCH(id_hist, sort_hist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, a.kin, plan.n, n_dev, a.shift, hist, nblk, state,
+                      (uint32_t)(ssb / sizeof(unsigned long long)));
+            GS_TRY(scan_u32_chained(hist, nullptr, hist, plan.hist_elems, true, state, s));
             a.table = hist;
             GS_LAUNCH(id_scatter, (sort_scatter_kernel<NV, false>), dim3(nblk), dim3(RS_THREADS), 0, s, a);
         }

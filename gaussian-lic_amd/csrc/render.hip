@@ -430,7 +430,14 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     float2* const s_ta = smem + 2 * NENT;
     uint2* const s_hm = reinterpret_cast<uint2*>(smem + 3 * NENT);   // (BITS only)
     const int lane = threadIdx.x;
-    const uint32_t bucket = blockIdx.x;
+    // Workgroup i runs on XCD i % 8 (eight private L2s).  The buckets of a tile are consecutive and all read the tile's pix_final, dL_dpixel
+    // and the forward's per-tile data: runs of 2^xcd_lg consecutive buckets go to the same XCD, back to back, so that only the first
+    // bucket of a tile misses the L2 (a bijection on [0, gridDim.x), gridDim.x a multiple of 8 << xcd_lg).
+    uint32_t bucket = blockIdx.x;
+    if (a.xcd_lg >= 0) {
+        const uint32_t x = bucket & 7u, j = bucket >> 3;
+        bucket = ((((j >> a.xcd_lg) << 3) + x) << a.xcd_lg) + (j & ((1u << a.xcd_lg) - 1u));
+    }
     if (a.status[2] != 0u || bucket >= a.bucket_offsets[a.T - 1]) return;  // capacity overflow in the forward / B was a capacity
     const bool use_bits = BITS && a.status[GS_FLAG_HITBITS] != 0u;         // (wave-uniform) the forward recorded its blend decisions
     const uint32_t tile = a.bucket_to_tile[bucket];
@@ -620,8 +627,20 @@ int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s)
 {
     if (a.B <= 0) return GSLIC_OK;
     static const int lds_pad = [] { const char* e = getenv("GSLIC_BWD_LDS_PAD"); return e ? atoi(e) : 0; }();  // occupancy experiments only
-    if (g_strict_math) GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel<true>, dim3(a.B), dim3(64), (size_t)lds_pad, s, a);
-    else GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel<false>, dim3(a.B), dim3(64), (size_t)lds_pad, s, a);
+    // GSLIC_BWD_XCD_RUN = run length of consecutive buckets per XCD (a power of two; 0 = plain blockIdx order)
+    static const int xcd_lg = [] {
+        const char* e = getenv("GSLIC_BWD_XCD_RUN");
+        const int v = e ? atoi(e) : 16;
+        int lg = -1;
+        for (int k = 0; k < 12; k++) if (v == (1 << k)) lg = k;
+        return lg;
+    }();
+    RenderBwdArgs b = a;
+    b.xcd_lg = xcd_lg;
+    unsigned grid = (unsigned)a.B;
+    if (xcd_lg >= 0) { const unsigned unit = 8u << xcd_lg; grid = (grid + unit - 1u) / unit * unit; }
+    if (g_strict_math) GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel<true>, dim3(grid), dim3(64), (size_t)lds_pad, s, b);
+    else GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel<false>, dim3(grid), dim3(64), (size_t)lds_pad, s, b);
     return GSLIC_OK;
 }
 

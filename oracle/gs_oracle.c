@@ -24,9 +24,11 @@
  *
  * Canonical arithmetic: fp32, every multiply/add rounded separately in source order (build with
  * -ffp-contract=off), IEEE divide and sqrt, ndc2Pix in double (auxiliary.h:41-44 uses double literals), and the
- * tile-culling threshold logf() evaluated by orc_logf below (a fixed double-precision polynomial) so that the
- * integer outputs (radii, tiles_touched, sorted point_list, ranges) are reproducible bit-for-bit on any IEEE
- * machine — the HIP kernels implement the same sequence.  Third-party arithmetic of the reference that is not
+ * tile-culling threshold logf() evaluated by orc_logf below (a fixed double-precision polynomial: correctly
+ * rounded) so that the integer outputs (radii, tiles_touched, sorted point_list, ranges) are reproducible
+ * bit-for-bit on any IEEE machine.  The HIP kernels implement the same sequence, except that they take the
+ * threshold from the device logf as the reference's kernels do (<= 1 ulp from orc_logf: a tile count can differ
+ * from this oracle's for about one Gaussian in 1e7; against the reference's kernels it is exact).  Third-party arithmetic of the reference that is not
  * in /root/reference (glm mat3 products, cub scans/sorts, CUDA libm) is restated from its published
  * semantics: glm column-major products summed k = 0,1,2; stable LSD radix sort on bits [0, 32+msb(T)).
  *
@@ -79,7 +81,7 @@ static const real SH_C3[7] = {RC(-0.5900435899266435), RC(2.890611442640554), RC
 /* Canonical natural log used for the tile-culling threshold logf(opacity*255) (forward.cu:302,
  * rasterizer_impl.cu:89).  x = m*2^e with m in [sqrt(.5), sqrt(2)); log m = 2*atanh(s), s = (m-1)/(m+1),
  * series to s^13 in double, plain (uncontracted) double ops in the order written; result rounded to float.
- * |error| < 1e-11 relative: indistinguishable from CUDA logf (<= 1 ulp) yet identical on CPU and GPU. */
+ * |error| < 1e-11 relative: the correctly rounded float, <= 1 ulp from CUDA's / hipcc's device logf. */
 float orc_logf(float x)
 {
     union { float f; uint32_t u; } v;

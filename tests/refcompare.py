@@ -46,7 +46,7 @@ def compare(kind, P, W, H, deg, seed, modes=("fast", "strict"), backward=True):
             tt_h = npy(d["tiles_touched"]).astype(np.uint32)
             bad = np.nonzero(tt_h != ref["tiles_touched"])[0]
             st["radii_mismatch"] = int((npy(got["radii"]) != ref["radii"]).sum())
-            st["tiles_touched_mismatch"] = int(bad.size)     # the reference thresholds with the device logf, we with a fixed polynomial
+            st["tiles_touched_mismatch"] = int(bad.size)
             st["R"] = int(got["R"])
             pl_h, pl_r = npy(d["point_list"]).astype(np.uint32), ref["point_list"]
             if bad.size:
