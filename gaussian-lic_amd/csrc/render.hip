@@ -117,7 +117,8 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
     for (int m = 0; m < MY; m++) { fym[m] = (float)(STRICT ? pyi[QN == 4 ? 2 * m : 0] : pyi[QN == 4 ? 2 * m : 0] - ty0); asm volatile("" : "+v"(fym[m])); }
     // STRICT: the constants of expf_core; default: the exponent below which no pixel reaches alpha >= 1/255 (with a margin: the early-out only)
     float kL2E = GS_EXP_L2E, kCC = GS_EXP_CC, kmh = -0.5f, kzero = 0.0f, vonef = 1.0f, kp2min = -7.9943534f - 0.001f /* log2(1/255) */;
-    if constexpr (STRICT) asm volatile("" : "+v"(kL2E), "+v"(kCC), "+v"(kmh), "+v"(kzero), "+v"(vonef));
+    uint32_t ksign = 0x80000000u;
+    if constexpr (STRICT) asm volatile("" : "+v"(kL2E), "+v"(kCC), "+v"(kmh), "+v"(kzero), "+v"(vonef), "+v"(ksign));
     else asm volatile("" : "+v"(kp2min), "+v"(kzero));
 
     for (int base = 0; base < n; base += GS_BUCKET) {
@@ -213,12 +214,13 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
                     const bool cand = !(power > kzero) & !(alpha < c255);   // forward.cu:431,437
                     const bool stop = test_T < c1e4;                        // done; this entry is NOT applied (forward.cu:438-443)
                     if (cand) {   // exec-masked: skipped when no pixel of the quadrant blends this entry
+                        // (T and last are updated IN PLACE under the branch's exec mask: left to the compiler, the two-sided update costs five copies)
                         if (stop) {
-                            T[q] = -__builtin_fabsf(T[q]);
+                            asm("v_or_b32 %0, %0, %1" : "+v"(T[q]) : "v"(ksign));   // -|T|
                         } else {
                             Cr[q] = Cr[q] + (colr * alpha) * T[q]; Cg[q] = Cg[q] + (colg * alpha) * T[q]; Cb[q] = Cb[q] + (colb * alpha) * T[q];
-                            T[q] = test_T;
-                            last[q] = vcontrib;
+                            asm("v_mov_b32 %0, %1" : "+v"(T[q]) : "v"(test_T));
+                            asm("v_mov_b32 %0, %1" : "+v"(last[q]) : "v"(vcontrib));
                             hcur[q] |= vbit;   // this pixel blended this entry
                         }
                     }
@@ -349,7 +351,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // recorded, per bucket and pixel, the 64-bit mask of the bucket's list entries the pixel blended (SampleState::hit, pixel-major like the
 // checkpoints), and those bits ARE the reference's decisions (lane < n_contrib - bucket start, power <= 0, alpha >= 1/255:
 // backward.cu:538-546), since the strict forward is bit-identical to the reference's.  The mask travels with the pixel's other data (a fourth
-// float2-sized array at the same clamped offset) and lane L tests bit L of it: a select of the dword, one shift, one compare.  What a pair
+// float2-sized array at the same clamped offset) and lane L turns bit L of it into an AND mask: v_bfi (the dword of its half), v_bfe_i32, v_and.  What a pair
 // CONTRIBUTES is computed with the arithmetic described above in both modes (within a few ulp of the reference's; gradients are sums of
 // 1e2..1e4 such terms in an order that differs from the reference's atomics anyway).  A forward that recorded no bits (fast mode, or the mode
 // was switched in between) leaves status[GS_FLAG_HITBITS] = 0 and the kernel re-derives the decisions like the fast variant.
@@ -378,7 +380,7 @@ struct BwdLane {
         if (USE_BITS) NH = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(smem) + BW_OFF_HM + oc_);    \
         NR = make_float4(rg_.x, rg_.y, bt_.x, bt_.y);                                                                \
         NT = ta_.x; NA = ta_.y;                                                                                      \
-        off += keight;                                                                                               \
+        asm volatile("v_add_u32 %0, %0, %1" : "+v"(off) : "v"(keight)); /* (left to the compiler: three adds and a copy per two steps) */ \
         __builtin_amdgcn_sched_barrier(0); /* keep the LDS reads at the top of the step: a whole step passes before they are used */ \
     } while (0)
 #define GS_BW_BODY(USE_BITS, T_, A_, GR, GH)                                                                         \
@@ -391,11 +393,16 @@ struct BwdLane {
         p2 = __builtin_fmaf(L.hAC.y * d.y, d.y, p2);                                                                 \
         p2 = __builtin_fmaf(L.nB * d.x, d.y, p2); /* = log2(e) * power + log2(opacity) */                            \
         const float araw = __builtin_amdgcn_exp2f(p2); /* opacity * G */                                             \
-        bool hit;                                                                                                    \
-        if (USE_BITS) hit = (int)((hi_half ? GH.y : GH.x) << kshl) < 0; /* bit `lane` of the pixel's mask: the strict forward blended this pair */ \
-        /* lane < n_contrib - bucket start (backward.cu:538), power <= 0, alpha >= 1/255 (:543-546; min(0.99, a) < 1/255 iff a < 1/255) */ \
-        else hit = (kcmp < TAG) & !(p2 > L.lop) & !(araw < c255);                                                    \
-        const float ah = hit ? araw : 0.0f; /* one select masks both alpha and the gradient weight */                \
+        float ah; /* alpha before the 0.99 cap if the pair blends, else 0: masks both alpha and the gradient weight */ \
+        if (USE_BITS) { /* bit `lane` of the pixel's mask (the strict forward blended this pair) as an all-ones / all-zeros word: the dword   */ \
+            uint32_t sel_, m_; /* of this lane's half (v_bfi), the bit sign-extended (v_bfe_i32), one AND - no compare, no lane-mask operand */ \
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(sel_) : "v"(klo), "v"(GH.x), "v"(GH.y));                            \
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m_) : "v"(sel_), "v"(kbit));                                         \
+            ah = __uint_as_float(__float_as_uint(araw) & m_);                                                        \
+        } else { /* lane < n_contrib - bucket start (backward.cu:538), power <= 0, alpha >= 1/255 (:543-546; min(0.99, a) < 1/255 iff a < 1/255) */ \
+            const bool hit = (kcmp < TAG) & !(p2 > L.lop) & !(araw < c255);                                          \
+            ah = hit ? araw : 0.0f;                                                                                  \
+        }                                                                                                            \
         const float alpha = __builtin_amdgcn_fmed3f(ah, ninf, c099); /* min(0.99, .) without the canonicalising v_max fminf costs */ \
         const float om = 1.0f - alpha;                                                                               \
         const float rinv = __builtin_amdgcn_rcpf(om); /* 1 / (1 - alpha) scales a gradient term, it decides nothing (<= 1 ulp) */   \
@@ -563,9 +570,9 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     float c099 = 0.99f, c255 = 1.0f / 255.0f, ninf = -__builtin_inff();
     v2f kneg = {-0.0625f, -1.0f};
     uint32_t kcmp = ((uint32_t)lane << 16) | 0xffffu;
-    uint32_t kshl = 31u - ((uint32_t)lane & 31u);   // BITS: moves bit `lane & 31` of the mask's dword into the sign position
-    const bool hi_half = lane >= 32;                // ... of the dword this lane's bit lives in
-    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(ninf), "+v"(kneg), "+v"(kcmp), "+v"(kshl));
+    uint32_t kbit = (uint32_t)lane & 31u;           // BITS: this lane's bit inside ...
+    uint32_t klo = lane >= 32 ? 0u : 0xffffffffu;   // ... the low (all ones) or the high (all zeros) dword of the pixel's mask
+    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(ninf), "+v"(kneg), "+v"(kcmp), "+v"(kbit), "+v"(klo));
     v2f acc_S = {0.f, 0.f}, acc_cxy = {0.f, 0.f}, acc_rg = {0.f, 0.f};
     float acc_cw = 0, acc_op = 0, acc_b = 0;
     // {T, A}: the state travelling through the lanes (set 1) and the injection fetched one step ahead (set 2); a step shifts set 1
