@@ -513,7 +513,9 @@ def cpp_fused_host(args, model, cam, gt, n):
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gaussian-lic_amd", "fused_check")
     if not os.path.exists(exe):
         return None
-    d = tempfile.mkdtemp(prefix="gslic_cpp_host_")
+    keep = os.environ.get("GSLIC_CPP_HOST_DIR")   # keep the hand-over files there (to run fused_check by hand, e.g. under rocprofv3)
+    d = keep or tempfile.mkdtemp(prefix="gslic_cpp_host_")
+    os.makedirs(d, exist_ok=True)
     try:
         w = lambda name, t: np.ascontiguousarray(t, np.float32).tofile(os.path.join(d, name + ".f32"))
         for name, t in (("xyz", model.xyz), ("scaling", model.scaling), ("rotation", model.rotation), ("opacity", model.opacity),
@@ -531,7 +533,8 @@ def cpp_fused_host(args, model, cam, gt, n):
         return {"host": "C++ (LibTorch tensors + C-ABI, no autograd graph)", "value": round(float(tok[1]), 3), "unit": "views/s",
                 "ms_per_step": round(float(tok[3]), 3), "steps": n}
     finally:
-        shutil.rmtree(d, ignore_errors=True)
+        if not keep:
+            shutil.rmtree(d, ignore_errors=True)
 
 
 def growth_schedule(args, dev):
