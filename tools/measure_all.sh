@@ -36,7 +36,10 @@ PY
   GSLIC_EXCHANGE=dense GSLIC_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29557 RANK=0 WORLD_SIZE=1 $B $X 2>/dev/null | grep "^{" | tail -1
 } > $OUT/${TAG}_bench_lines.jsonl
 # per-kernel durations
-timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG -- python $R/bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-extras > /tmp/prof_$TAG.log 2>&1
+# (the default step counts, so that the trace's average of the dominant kernel and the HIP-event average bench.py prints for it come from the
+# SAME process: the line is kept next to the stats)
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG -- python $R/bench.py --no-cpu-baseline --no-extras > /tmp/prof_$TAG.log 2>&1
+grep "^{" /tmp/prof_$TAG.log | tail -1 > $OUT/${TAG}_bench_line_under_rocprof.json
 python $R/tools/rocpd_summary.py $(find /tmp/prof_$TAG -name "*.db" | head -1) $OUT/${TAG}_train_2M_1080p_kernel_stats > /dev/null
 # the same step through the reference's operator API + LibTorch autograd (what an unmodified reference host runs): where its extra time goes
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_dropin_$TAG -o $TAG -- python $R/bench.py --host dropin --steps 20 --warmup 4 --no-cpu-baseline --no-extras > /tmp/prof_dropin_$TAG.log 2>&1
