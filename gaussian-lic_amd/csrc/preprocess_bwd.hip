@@ -10,6 +10,7 @@
 // Sigma_3D is recomputed from scale/rotation instead of being stored by the forward (24 B/Gaussian saved).
 #include "gslic_common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace gslic {
 
@@ -58,8 +59,12 @@ struct ShOut {  // what phase B needs to write a Gaussian's dL_dsh row
     bool on;
 };
 
-template <bool LDS_SH, bool CAM>
-__device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so, float* sg, float* cg);
+struct PartialSums { float mx, my, cx, cy, cw, op, r, g, b; };   // the nine per-Gaussian sums of render_bwd's per-instance rows
+
+__device__ __forceinline__ bool bwd_gather(const PreprocessBwdArgs& a, const int idx, const bool staged, PartialSums& ps);
+template <bool CAM>
+__device__ __forceinline__ void bwd_rest(const PreprocessBwdArgs& a, const int idx, const PartialSums& ps, const float* sh_row, const float* sk_row,
+                                         ShOut& so, float* sg, float* cg);
 
 // Cooperative sink of the 14 small gradients per Gaussian of one block (see lds_g in the kernel): coalesced float4 stores into the
 // gradient tensors that were asked for (gout, group order of lds_g) and / or the in-place Adam update.  Group g of width w: the
@@ -122,52 +127,116 @@ __device__ __forceinline__ void small_groups_sink(const AdamFusedArgs& A, float*
     }
 }
 
-// LDS_SH (M == 15): the block's 256 x 45 SH floats (contiguous in memory) are staged through LDS with coalesced float4
-// accesses and read row-wise by the owning thread (row stride 45 floats: odd, bank-conflict free); the block's dL_dsh rows go
-// back the same way — instead of 45 strided 4-byte accesses per thread in each direction (measured 2.6x write amplification).
+// LDS_SH (M == 15, one wave per workgroup): the block's 64 x 45 SH floats are contiguous in memory and are read ONCE, as float4
+// columns, by a cooperative pass that does everything that needs them:
+//   * q_k = sum_ch sh[k][ch] dRGB[ch] per Gaussian and coefficient (all the direction gradient needs: dL/ddir = sum_k dc_k/ddir q_k) — the
+//     three channels of a coefficient are adjacent elements, a thread takes the triples that START in its float4 (the two elements behind
+//     it come with an 8-byte load of its neighbour's column: an L1 hit), so every q_k is one fixed-order sum written once;
+//   * the gradient element g = c_k(dir) dRGB[ch] (rank-1: never materialised as a row), stored to dL_dsh and / or consumed by Adam on the
+//     spot with the parameter value that is already in registers.
+// What the pass needs per Gaussian — c_0..c_14 and the clamp-masked dRGB — sits in a 64 x 19 float table.  LDS per wave 8.6 KB (table 4.75,
+// q 3.75) against the 11.3 KB of staging whole rows in and gradient rows out: 16 waves per CU instead of 13 (the kernel streams ~100 bytes
+// per flop: occupancy IS its memory-level parallelism, profiles/r03p_pbwd_occupancy.log), and features_rest is fetched once, not twice.
+static constexpr int SHT = 19;   // table row stride (odd: rows of one column sit in different banks)
+
+// (rem * 43) >> 7 == rem / 3 for 0 <= rem < 48
+__device__ __forceinline__ int div3_small(int rem) { return (rem * 43) >> 7; }
+
+template <int BS>
+__device__ __forceinline__ void sh_columns_pass(const PreprocessBwdArgs& a, const float* __restrict__ tab, float* __restrict__ sk,
+                                                const uint8_t* __restrict__ lds_vis, const int row0)
+{
+    constexpr int NE = BS * 45, NV = NE / 4, U = 4;
+    const AdamFusedArgs& A = a.adam;
+    const size_t base = (size_t)row0 * 45;
+    const float* __restrict__ P = a.shs + base;   // (== A.p[2] + base when the update is on: api.hip checks the aliasing)
+    const bool store_g = a.dL_dsh != nullptr;
+    for (int i0 = threadIdx.x; i0 < NV; i0 += BS * U) {
+        float4 x[U], m[U], v[U];
+        float2 nx[U];
+        int r0[U], rem0[U];
+        bool any[U], upd[U], vis[U][4];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + BS * u;
+            any[u] = upd[u] = false;
+            if (i < NV) {
+                const int e = 4 * i;
+                r0[u] = e / 45; rem0[u] = e - 45 * r0[u];
+                const int r1 = (r0[u] + 1 < BS) ? r0[u] + 1 : r0[u];
+                const bool v0 = lds_vis[r0[u]] != 0, v1 = lds_vis[r1] != 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) vis[u][c] = (rem0[u] + c < 45) ? v0 : v1;
+                any[u] = v0 | v1;   // some element of columns i, i + 1 belongs to a visible Gaussian
+                upd[u] = A.on & (vis[u][0] | vis[u][3]);
+                x[u] = make_float4(0.f, 0.f, 0.f, 0.f); nx[u] = make_float2(0.f, 0.f);
+                if (any[u]) {
+                    x[u] = reinterpret_cast<const float4*>(P)[i];
+                    if (e + 4 < NE) nx[u] = *reinterpret_cast<const float2*>(P + e + 4);
+                }
+                if (upd[u]) {
+                    m[u] = ld_stream(reinterpret_cast<const float4*>(A.m[2] + base) + i);
+                    v[u] = ld_stream(reinterpret_cast<const float4*>(A.v[2] + base) + i);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + BS * u;
+            if (i >= NV) continue;
+            const float xe[6] = {x[u].x, x[u].y, x[u].z, x[u].w, nx[u].x, nx[u].y};
+            float pr[6], g[4];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                int r = r0[u], rem = rem0[u] + c;
+                if (rem >= 45) { rem -= 45; r += 1; }
+                if (r >= BS) r = BS - 1;   // (elements behind the block: their products are never used)
+                const int k = div3_small(rem), ch = rem - 3 * k;
+                const float d = tab[r * SHT + 15 + ch];
+                pr[c] = xe[c] * d;
+                if (c < 4) g[c] = tab[r * SHT + k] * d;
+            }
+            // the triples that start in this float4: at c0 = (3 - ch(e)) % 3 and, when c0 == 0, at 3 as well
+            const int ch0 = rem0[u] - 3 * div3_small(rem0[u]);
+            const int c0 = ch0 == 0 ? 0 : 3 - ch0;
+            const float t0 = c0 == 0 ? pr[0] : (c0 == 1 ? pr[1] : pr[2]);
+            const float t1 = c0 == 0 ? pr[1] : (c0 == 1 ? pr[2] : pr[3]);
+            const float t2 = c0 == 0 ? pr[2] : (c0 == 1 ? pr[3] : pr[4]);
+            const int f = (4 * i + c0) / 3;   // = 15 r + k of the triple
+            sk[f] = (t0 + t1) + t2;
+            if (c0 == 0) sk[f + 1] = (pr[3] + pr[4]) + pr[5];
+            const float4 g4 = make_float4(g[0], g[1], g[2], g[3]);
+            if (store_g) reinterpret_cast<float4*>(a.dL_dsh + base)[i] = g4;
+            if (upd[u]) {
+                if (vis[u][0]) adam_scalar(x[u].x, g4.x, m[u].x, v[u].x, A.lr[2], A.b1, A.b2, A.eps);
+                if (vis[u][1]) adam_scalar(x[u].y, g4.y, m[u].y, v[u].y, A.lr[2], A.b1, A.b2, A.eps);
+                if (vis[u][2]) adam_scalar(x[u].z, g4.z, m[u].z, v[u].z, A.lr[2], A.b1, A.b2, A.eps);
+                if (vis[u][3]) adam_scalar(x[u].w, g4.w, m[u].w, v[u].w, A.lr[2], A.b1, A.b2, A.eps);
+                st_stream(reinterpret_cast<float4*>(A.p[2] + base) + i, x[u]);
+                st_stream(reinterpret_cast<float4*>(A.m[2] + base) + i, m[u]);
+                st_stream(reinterpret_cast<float4*>(A.v[2] + base) + i, v[u]);
+            }
+        }
+    }
+}
+
 template <bool LDS_SH, int BS, bool CAM>
 __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float lds_sh[LDS_SH ? BS * 45 : 4];
+    __shared__ __attribute__((aligned(16))) float lds_tab[LDS_SH ? BS * SHT : 4];   // {c_0..c_14, dRGB} per Gaussian; later the 14 small gradients
+    __shared__ float lds_sk[LDS_SH ? BS * 15 : 4];                                    // q_k per Gaussian
     __shared__ uint8_t lds_vis[BS];
     // the 14 small-group gradients of every Gaussian of the block, group-major (xyz | dc | opacity | scale | rotation), for the
     // cooperative float4 Adam below: per-thread 4-byte accesses at stride 12 / 16 B cost this kernel 0.29 ms of 0.86
-    float* const lds_g = lds_sh;  // overlays the head of lds_sh between "SH rows consumed" and "dL_dsh rows written" (LDS per wave 15.2 -> 11.6 KB)
+    float* const lds_g = lds_tab;  // overlays the table once the column pass is through (14 * BS <= SHT * BS)
     if (a.status[2] != 0u) return;  // capacity overflow in the forward: nothing of this step is valid — no gradients, no Adam
     const int idx = a.row_begin + blockIdx.x * BS + threadIdx.x;
     const int M = a.M;
-    lds_vis[threadIdx.x] = (idx < a.row_end && a.radii[idx] > 0) ? 1 : 0;
     const int row0 = a.row_begin + blockIdx.x * BS;
     const int rows = (a.row_end - row0) < BS ? (a.row_end - row0) : BS;
-    if constexpr (LDS_SH) {
-        const float* src = a.shs + (size_t)row0 * 45;
-        if (rows == BS) {
-            // all of a thread's loads are issued before the first LDS store: the rolled loop was load -> wait -> store twelve times,
-            // i.e. twelve dependent memory round trips at the head of every wave
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            constexpr int NT = (BS * 45 / 4 + BS - 1) / BS;
-            const v4f* s4 = reinterpret_cast<const v4f*>(src);
-            v4f* d4 = reinterpret_cast<v4f*>(lds_sh);
-            v4f pre[NT];
-#pragma unroll
-            for (int k = 0; k < NT; k++) {
-                const int i = threadIdx.x + k * BS;
-                pre[k] = (i < BS * 45 / 4) ? s4[i] : (v4f){0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int k = 0; k < NT; k++) {
-                const int i = threadIdx.x + k * BS;
-                if (i < BS * 45 / 4) d4[i] = pre[k];
-            }
-        } else {
-            for (int i = threadIdx.x; i < rows * 45; i += BS) lds_sh[i] = src[i];
-        }
-        __syncthreads();
-    }
     ShOut so;
     so.x = so.y = so.z = so.dR = so.dG = so.dB = 0.f;
     so.on = false;
-    const float* sh_row = LDS_SH ? (lds_sh + threadIdx.x * 45) : (a.shs ? a.shs + (size_t)3 * M * idx : nullptr);
     float sg[14];
 #pragma unroll
     for (int k = 0; k < 14; k++) sg[k] = 0.f;
@@ -179,7 +248,56 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
 #pragma unroll
         for (int k = 0; k < 27; k++) cg[k] = 0.f;
     }
-    if (idx < a.row_end) bwd_phase_a<LDS_SH, CAM>(a, idx, M, sh_row, so, LDS_SH ? sg : nullptr, cg);
+    PartialSums ps;
+    bool visible = false;
+    if (idx < a.row_end) visible = bwd_gather(a, idx, LDS_SH, ps);
+    lds_vis[threadIdx.x] = visible ? 1 : 0;
+    if constexpr (LDS_SH) {
+        // ---- this Gaussian's row of the table (zeros when invisible: its gradient elements and products are then exact zeros)
+        float trow[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) trow[k] = 0.f;
+        if (visible) {
+            const uint32_t clamp_bits = __float_as_uint(a.rec[GS_REC_F4 * (size_t)idx + 2].z);
+            float dox, doy, doz, x, y, z;
+            sh_dir(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2], a.campos, dox, doy, doz, x, y, z);
+            float c[15];
+            sh_coefs(a.D, x, y, z, c);
+#pragma unroll
+            for (int k = 0; k < 15; k++) trow[k] = c[k];
+            trow[15] = (clamp_bits & 1u) ? 0.f : ps.r; trow[16] = (clamp_bits & 2u) ? 0.f : ps.g; trow[17] = (clamp_bits & 4u) ? 0.f : ps.b;
+        }
+#pragma unroll
+        for (int k = 0; k < 18; k++) lds_tab[threadIdx.x * SHT + k] = trow[k];
+        __syncthreads();
+        // ---- the column pass over the block's SH parameters (full blocks); the last, partial block goes row by row
+        const bool sh_sink = a.dL_dsh || a.adam.on;
+        if (rows == BS) {
+            sh_columns_pass<BS>(a, lds_tab, lds_sk, lds_vis, row0);
+        } else {
+            const size_t base = (size_t)row0 * 45;
+            if ((int)threadIdx.x < rows) {
+                const float* __restrict__ sh = a.shs + base + 45 * threadIdx.x;
+                const float* __restrict__ tr = lds_tab + threadIdx.x * SHT;
+#pragma unroll
+                for (int k = 0; k < 15; k++) lds_sk[threadIdx.x * 15 + k] = (sh[3 * k] * tr[15] + sh[3 * k + 1] * tr[16]) + sh[3 * k + 2] * tr[17];
+            }
+            __syncthreads();   // every q_k has been formed from the parameters as they were
+            const AdamFusedArgs& A = a.adam;
+            if (sh_sink)
+                for (int i = threadIdx.x; i < rows * 45; i += BS) {
+                    const int r = i / 45, rem = i - 45 * r, k = rem / 3, ch = rem - 3 * k;
+                    const float g = lds_tab[r * SHT + k] * lds_tab[r * SHT + 15 + ch];
+                    if (a.dL_dsh) a.dL_dsh[base + i] = g;
+                    if (A.on && lds_vis[r]) adam_scalar(A.p[2][base + i], g, A.m[2][base + i], A.v[2][base + i], A.lr[2], A.b1, A.b2, A.eps);
+                }
+        }
+        __syncthreads();   // q_k complete; the table is free
+        if (visible) bwd_rest<CAM>(a, idx, ps, nullptr, lds_sk + threadIdx.x * 15, so, sg, cg);
+    } else {
+        const float* sh_row = a.shs ? a.shs + (size_t)3 * M * idx : nullptr;
+        if (visible) bwd_rest<CAM>(a, idx, ps, sh_row, nullptr, so, nullptr, cg);
+    }
     if constexpr (CAM) {
 #pragma unroll
         for (int k = 0; k < 27; k++) {
@@ -195,7 +313,8 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
         }
     }
     if constexpr (LDS_SH) {
-        __syncthreads();  // every SH row has been consumed: the buffer first takes the 14 small gradients per Gaussian, group-major
+        // ---- small groups: the block's rows of xyz / dc / opacity / scale / rotation are contiguous in memory, so the Adam update runs
+        // on float4 columns of those five regions (at most one float4 per thread and group, all fifteen loads issued before the math)
         const int t = threadIdx.x;
         lds_g[3 * t] = sg[0]; lds_g[3 * t + 1] = sg[1]; lds_g[3 * t + 2] = sg[2];
         lds_g[3 * BS + 3 * t] = sg[3]; lds_g[3 * BS + 3 * t + 1] = sg[4]; lds_g[3 * BS + 3 * t + 2] = sg[5];
@@ -203,80 +322,8 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
         lds_g[7 * BS + 3 * t] = sg[7]; lds_g[7 * BS + 3 * t + 1] = sg[8]; lds_g[7 * BS + 3 * t + 2] = sg[9];
         reinterpret_cast<float4*>(lds_g + 10 * BS)[t] = make_float4(sg[10], sg[11], sg[12], sg[13]);
         __syncthreads();
-    }
-
-    // ---- small groups: the block's rows of xyz / dc / opacity / scale / rotation are contiguous in memory, so the Adam update runs
-    // on float4 columns of those five regions (at most one float4 per thread and group, all fifteen loads issued before the math)
-    if constexpr (LDS_SH) {
         float* const gout[5] = {a.dL_dmean3D, a.dL_drgb ? a.dL_drgb : a.dL_ddc, a.dL_dopacity, a.dL_dscale, a.dL_drot};
         small_groups_sink<BS>(a.adam, gout, lds_g, lds_vis, row0, rows);
-        __syncthreads();  // ... and then the dL_dsh rows
-    }
-    // ---- phase B: this Gaussian's dL_dsh row (zeros when invisible, when shs == NULL, and above the active degree)
-    if constexpr (LDS_SH) {
-        if (!a.dL_dsh && !a.adam.on) return;   // (dL_drgb mode: the rows are rebuilt after the exchange)
-        if (idx < a.row_end) {
-            float* drow = lds_sh + threadIdx.x * 45;
-            if (so.on) {
-                float c[15];
-                sh_coefs(a.D, so.x, so.y, so.z, c);
-                for (int k = 0; k < 15; k++) { drow[3 * k] = c[k] * so.dR; drow[3 * k + 1] = c[k] * so.dG; drow[3 * k + 2] = c[k] * so.dB; }
-            } else {
-                for (int k = 0; k < 45; k++) drow[k] = 0.f;
-            }
-        }
-        __syncthreads();
-        // ---- phase C: the block's 256 x 45 gradient rows leave LDS coalesced: to dL_dsh and / or straight into Adam
-        const size_t base = (size_t)row0 * 45;
-        const AdamFusedArgs& A = a.adam;
-        if (rows == BS) {
-            const float4* s4 = reinterpret_cast<const float4*>(lds_sh);
-            constexpr int NV = BS * 45 / 4, U = 4;
-            // U independent float4 triples (param, exp_avg, exp_avg_sq) in flight per thread: the kernel runs at 3 waves/SIMD
-            // (LDS-limited), so memory-level parallelism has to come from inside the wave
-            for (int i0 = threadIdx.x; i0 < NV; i0 += BS * U) {
-                float4 g[U], p[U], m[U], v[U];
-                bool vis[U][4], any[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int i = i0 + BS * u;
-                    any[u] = false;
-                    if (i < NV) {
-                        g[u] = s4[i];
-                        if (a.dL_dsh) reinterpret_cast<float4*>(a.dL_dsh + base)[i] = g[u];
-                        if (A.on) {
-                            const int e = 4 * i;
-                            vis[u][0] = lds_vis[e / 45]; vis[u][1] = lds_vis[(e + 1) / 45];
-                            vis[u][2] = lds_vis[(e + 2) / 45]; vis[u][3] = lds_vis[(e + 3) / 45];
-                            any[u] = vis[u][0] | vis[u][1] | vis[u][2] | vis[u][3];
-                        }
-                    }
-                    if (any[u]) {
-                        p[u] = reinterpret_cast<float4*>(A.p[2] + base)[i];   // (read a moment ago as the SH row: an L2 hit)
-                        m[u] = ld_stream(reinterpret_cast<const float4*>(A.m[2] + base) + i);
-                        v[u] = ld_stream(reinterpret_cast<const float4*>(A.v[2] + base) + i);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    if (!any[u]) continue;
-                    const int i = i0 + BS * u;
-                    if (vis[u][0]) adam_scalar(p[u].x, g[u].x, m[u].x, v[u].x, A.lr[2], A.b1, A.b2, A.eps);
-                    if (vis[u][1]) adam_scalar(p[u].y, g[u].y, m[u].y, v[u].y, A.lr[2], A.b1, A.b2, A.eps);
-                    if (vis[u][2]) adam_scalar(p[u].z, g[u].z, m[u].z, v[u].z, A.lr[2], A.b1, A.b2, A.eps);
-                    if (vis[u][3]) adam_scalar(p[u].w, g[u].w, m[u].w, v[u].w, A.lr[2], A.b1, A.b2, A.eps);
-                    st_stream(reinterpret_cast<float4*>(A.p[2] + base) + i, p[u]);
-                    st_stream(reinterpret_cast<float4*>(A.m[2] + base) + i, m[u]);
-                    st_stream(reinterpret_cast<float4*>(A.v[2] + base) + i, v[u]);
-                }
-            }
-        } else {
-            for (int i = threadIdx.x; i < rows * 45; i += BS) {
-                const float g = lds_sh[i];
-                if (a.dL_dsh) a.dL_dsh[base + i] = g;
-                if (A.on && lds_vis[i / 45]) adam_scalar(A.p[2][base + i], g, A.m[2][base + i], A.v[2][base + i], A.lr[2], A.b1, A.b2, A.eps);
-            }
-        }
     } else if (idx < a.row_end && M > 0 && (a.dL_dsh || a.adam.on)) {
         // generic row width: per-thread strided rows (dL_dsh zeros when invisible, when shs == NULL, above the active degree)
         const AdamFusedArgs& A = a.adam;
@@ -293,9 +340,11 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
     }
 }
 
-template <bool LDS_SH, bool CAM>
-__device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const int idx, const int M, const float* sh_row, ShOut& so, float* sg, float* cg)
+// Zero rows of an invisible Gaussian / the segmented sum of a visible one's per-instance rows.  Returns the visibility.
+// staged: the five parameter-gradient rows leave through the block's staged float4 stores (their zeros too).
+__device__ __forceinline__ bool bwd_gather(const PreprocessBwdArgs& a, const int idx, const bool staged, PartialSums& ps)
 {
+    ps.mx = ps.my = ps.cx = ps.cy = ps.cw = ps.op = ps.r = ps.g = ps.b = 0.f;
     const bool visible = a.radii[idx] > 0;
 
     if (!visible) {
@@ -304,14 +353,14 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
         if (a.dL_dcolor) { a.dL_dcolor[3 * idx] = 0; a.dL_dcolor[3 * idx + 1] = 0; a.dL_dcolor[3 * idx + 2] = 0; }
         if (a.dL_dcov3D)
             for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * idx + k] = 0;
-        if (sg) return;  // the five parameter-gradient rows leave through the block's staged float4 stores (sg[] is pre-zeroed)
+        if (staged) return false;
         if (a.dL_dopacity) a.dL_dopacity[idx] = 0;
         if (a.dL_dmean3D) { a.dL_dmean3D[3 * idx] = 0; a.dL_dmean3D[3 * idx + 1] = 0; a.dL_dmean3D[3 * idx + 2] = 0; }
         if (a.dL_ddc) { a.dL_ddc[3 * idx] = 0; a.dL_ddc[3 * idx + 1] = 0; a.dL_ddc[3 * idx + 2] = 0; }
         if (a.dL_drgb) { a.dL_drgb[3 * idx] = 0; a.dL_drgb[3 * idx + 1] = 0; a.dL_drgb[3 * idx + 2] = 0; }
         if (a.dL_dscale) { a.dL_dscale[3 * idx] = 0; a.dL_dscale[3 * idx + 1] = 0; a.dL_dscale[3 * idx + 2] = 0; }
         if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0, 0, 0, 0);
-        return;
+        return false;
     }
 
     // ---- segmented sum of the per-instance partial gradients (ascending tile order) ----
@@ -355,7 +404,17 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
     if (a.dL_dmean2D) { a.dL_dmean2D[3 * idx] = s_mx; a.dL_dmean2D[3 * idx + 1] = s_my; a.dL_dmean2D[3 * idx + 2] = 0; }
     if (a.dL_dconic) reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(s_cx, s_cy, 0.f, s_cw);
     if (a.dL_dcolor) { a.dL_dcolor[3 * idx] = s_r; a.dL_dcolor[3 * idx + 1] = s_g; a.dL_dcolor[3 * idx + 2] = s_b; }
+    ps.mx = s_mx; ps.my = s_my; ps.cx = s_cx; ps.cy = s_cy; ps.cw = s_cw; ps.op = s_op; ps.r = s_r; ps.g = s_g; ps.b = s_b;
+    return true;
+}
 
+// Everything behind the sums for a VISIBLE Gaussian.  The SH block needs, per coefficient k, only q_k = sum_ch sh[k][ch] dRGB[ch]
+// (dL/ddir = sum_k dc_k/ddir q_k): sk_row hands them over when the block computed them cooperatively, else they are formed from sh_row.
+template <bool CAM>
+__device__ __forceinline__ void bwd_rest(const PreprocessBwdArgs& a, const int idx, const PartialSums& ps, const float* sh_row, const float* sk_row,
+                                         ShOut& so, float* sg, float* cg)
+{
+    const float s_mx = ps.mx, s_my = ps.my, s_cx = ps.cx, s_cy = ps.cy, s_cw = ps.cw, s_op = ps.op, s_r = ps.r, s_g = ps.g, s_b = ps.b;
     const float* __restrict__ V = a.view;
     const float* __restrict__ Pm = a.proj;
     const float mx3 = a.means[3 * idx], my3 = a.means[3 * idx + 1], mz3 = a.means[3 * idx + 2];
@@ -496,35 +555,33 @@ __device__ __forceinline__ void bwd_phase_a(const PreprocessBwdArgs& a, const in
         const float* __restrict__ sh = sh_row;
         const float dRGB[3] = {(clamp_bits & 1u) ? 0.f : s_r, (clamp_bits & 2u) ? 0.f : s_g, (clamp_bits & 4u) ? 0.f : s_b};
         so.x = x; so.y = y; so.z = z; so.dR = dRGB[0]; so.dG = dRGB[1]; so.dB = dRGB[2]; so.on = true;
-        float ddir[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            const float g = dRGB[ch];
-            ddc[ch] = a.dL_drgb ? g : SHC0 * g;   // (dL_drgb: the dc slot of the outputs carries the masked colour gradient itself)
-            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-#define S(k) sh[3 * (k) + ch]
-            if (a.D > 0) {
-                ddx = -SHC1 * S(2); ddy = -SHC1 * S(0); ddz = SHC1 * S(1);
-                if (a.D > 1) {
-                    ddx += b_SH_C2[0] * y * S(3) + b_SH_C2[2] * 2.f * -x * S(5) + b_SH_C2[3] * z * S(6) + b_SH_C2[4] * 2.f * x * S(7);
-                    ddy += b_SH_C2[0] * x * S(3) + b_SH_C2[1] * z * S(4) + b_SH_C2[2] * 2.f * -y * S(5) + b_SH_C2[4] * 2.f * -y * S(7);
-                    ddz += b_SH_C2[1] * y * S(4) + b_SH_C2[2] * 2.f * 2.f * z * S(5) + b_SH_C2[3] * x * S(6);
-                    if (a.D > 2) {
-                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                        ddx += (b_SH_C3[0] * S(8) * 3.f * 2.f * xy + b_SH_C3[1] * S(9) * yz + b_SH_C3[2] * S(10) * -2.f * xy +
-                                b_SH_C3[3] * S(11) * -3.f * 2.f * xz + b_SH_C3[4] * S(12) * (-3.f * xx + 4.f * zz - yy) +
-                                b_SH_C3[5] * S(13) * 2.f * xz + b_SH_C3[6] * S(14) * 3.f * (xx - yy));
-                        ddy += (b_SH_C3[0] * S(8) * 3.f * (xx - yy) + b_SH_C3[1] * S(9) * xz +
-                                b_SH_C3[2] * S(10) * (-3.f * yy + 4.f * zz - xx) + b_SH_C3[3] * S(11) * -3.f * 2.f * yz +
-                                b_SH_C3[4] * S(12) * -2.f * xy + b_SH_C3[5] * S(13) * -2.f * yz + b_SH_C3[6] * S(14) * -3.f * 2.f * xy);
-                        ddz += (b_SH_C3[1] * S(9) * xy + b_SH_C3[2] * S(10) * 4.f * 2.f * yz +
-                                b_SH_C3[3] * S(11) * 3.f * (2.f * zz - xx - yy) + b_SH_C3[4] * S(12) * 4.f * 2.f * xz +
-                                b_SH_C3[5] * S(13) * (xx - yy));
-                    }
+        for (int ch = 0; ch < 3; ch++) ddc[ch] = a.dL_drgb ? dRGB[ch] : SHC0 * dRGB[ch];   // (dL_drgb: the dc slot of the outputs carries the masked colour gradient itself)
+        float q[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++)
+            q[k] = sk_row ? sk_row[k] : (k < a.M ? ((sh[3 * k] * dRGB[0] + sh[3 * k + 1] * dRGB[1]) + sh[3 * k + 2] * dRGB[2]) : 0.f);
+        float ddir[3] = {0.f, 0.f, 0.f};
+        if (a.D > 0) {
+            float ddx = -SHC1 * q[2], ddy = -SHC1 * q[0], ddz = SHC1 * q[1];
+            if (a.D > 1) {
+                ddx += b_SH_C2[0] * y * q[3] + b_SH_C2[2] * 2.f * -x * q[5] + b_SH_C2[3] * z * q[6] + b_SH_C2[4] * 2.f * x * q[7];
+                ddy += b_SH_C2[0] * x * q[3] + b_SH_C2[1] * z * q[4] + b_SH_C2[2] * 2.f * -y * q[5] + b_SH_C2[4] * 2.f * -y * q[7];
+                ddz += b_SH_C2[1] * y * q[4] + b_SH_C2[2] * 2.f * 2.f * z * q[5] + b_SH_C2[3] * x * q[6];
+                if (a.D > 2) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    ddx += (b_SH_C3[0] * q[8] * 3.f * 2.f * xy + b_SH_C3[1] * q[9] * yz + b_SH_C3[2] * q[10] * -2.f * xy +
+                            b_SH_C3[3] * q[11] * -3.f * 2.f * xz + b_SH_C3[4] * q[12] * (-3.f * xx + 4.f * zz - yy) +
+                            b_SH_C3[5] * q[13] * 2.f * xz + b_SH_C3[6] * q[14] * 3.f * (xx - yy));
+                    ddy += (b_SH_C3[0] * q[8] * 3.f * (xx - yy) + b_SH_C3[1] * q[9] * xz +
+                            b_SH_C3[2] * q[10] * (-3.f * yy + 4.f * zz - xx) + b_SH_C3[3] * q[11] * -3.f * 2.f * yz +
+                            b_SH_C3[4] * q[12] * -2.f * xy + b_SH_C3[5] * q[13] * -2.f * yz + b_SH_C3[6] * q[14] * -3.f * 2.f * xy);
+                    ddz += (b_SH_C3[1] * q[9] * xy + b_SH_C3[2] * q[10] * 4.f * 2.f * yz +
+                            b_SH_C3[3] * q[11] * 3.f * (2.f * zz - xx - yy) + b_SH_C3[4] * q[12] * 4.f * 2.f * xz +
+                            b_SH_C3[5] * q[13] * (xx - yy));
                 }
             }
-#undef S
-            ddir[0] += ddx * g; ddir[1] += ddy * g; ddir[2] += ddz * g;
+            ddir[0] = ddx; ddir[1] = ddy; ddir[2] = ddz;
         }
         // dnormvdv (auxiliary.h:119-129)
         const float sum2 = dox * dox + doy * doy + doz * doz;
@@ -662,8 +719,9 @@ int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
     if (a.M == 15 && a.shs && (a.dL_dsh || a.adam.on || a.dL_drgb)) {
         // one wave per workgroup: 64 Gaussians' SH rows (11.25 KiB) + small-group gradients in LDS, the phase barriers are wave-level,
         // and ten workgroups per CU sit in different phases (measured 0.72 ms against 0.75 at 128 and 0.88 at 256 threads)
-        if (cam) GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64, true>), dim3(div_up(nrows, 64)), dim3(64), 0, s, a);
-        else GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64, false>), dim3(div_up(nrows, 64)), dim3(64), 0, s, a);
+        static const int lds_pad = [] { const char* e = getenv("GSLIC_PBWD_LDS_PAD"); return e ? atoi(e) : 0; }();  // occupancy experiments only
+        if (cam) GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64, true>), dim3(div_up(nrows, 64)), dim3(64), (size_t)lds_pad, s, a);
+        else GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64, false>), dim3(div_up(nrows, 64)), dim3(64), (size_t)lds_pad, s, a);
     } else {
         if (cam) GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<false, 256, true>), dim3(div_up(nrows, 256)), dim3(256), 0, s, a);
         else GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<false, 256, false>), dim3(div_up(nrows, 256)), dim3(256), 0, s, a);
