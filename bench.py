@@ -568,19 +568,30 @@ def growth_schedule(args, dev):
         trainer.training_step_fused(model, cam, gt, bg)
     torch.cuda.synchronize()
     P1, inserted, ext_ms = model.P, 0, 0.0
+    from gaussian_lic_amd import _lib
+    _lib.profile_reset()
+    _lib.profile_enable(True, only=["render_bwd", "preprocess_bwd", "render_fwd"])   # (three event pairs per step: where a slow run loses its time)
+    seg_ms = []
     t0 = time.perf_counter()
     for it in range(100):
         if it % 20 == 0:
             e0 = time.perf_counter()
             inserted += model.extend(cam, *frames[1 + it // 20], Rcw, tcw, intr)   # (synchronises: the survivor count sizes the append)
-            ext_ms += 1e3 * (time.perf_counter() - e0)
+            e1 = time.perf_counter()
+            ext_ms += 1e3 * (e1 - e0)
+            seg_ms.append(1e3 * (e0 - t0))   # (the device is idle at e0: extend() of the previous segment synchronised, or nothing ran yet)
         trainer.training_step_fused(model, cam, gt, bg)
     torch.cuda.synchronize()
     sec = time.perf_counter() - t0
+    seg_ms.append(1e3 * sec)
+    kms = _lib.profile_collect()
+    _lib.profile_enable(False)
     return {"workload": f"SURVEY 8d config 3 schedule: {P1} -> {model.P} Gaussians by 5 extend() appends (every 20 iterations), 100 iterations, reference learning rates",
             "value": round(100.0 / sec, 3), "unit": "views/s", "ms_per_iteration": round(10.0 * sec, 3), "iterations": 100, "appends": 5,
             "gaussians_start": P1, "gaussians_end": model.P, "inserted": inserted, "extend_ms_per_call": round(ext_ms / 5.0, 3),
-            "gaussians_before_warmup_frame": P0}
+            "gaussians_before_warmup_frame": P0,
+            "kernel_ms_per_launch": {k: round(v[0] / max(v[1], 1), 4) for k, v in kms.items()},
+            "ms_per_20_iterations": [round(b - a, 2) for a, b in zip(seg_ms[:-1], seg_ms[1:])]}
 
 
 def _cpu_step(orc, sc, cam, gt, state, lrs):
