@@ -40,6 +40,19 @@ static const char* const k_names[K_COUNT] = {
     "preprocess", "scan_reduce", "scan_spine", "scan_apply", "keybuild", "sort_hist", "sort_scatter", "finalize_lists",
     "bucket_count", "render_fwd", "render_bwd", "preprocess_bwd", "adam", "ssim_fwd", "ssim_bwd", "knn_minmax", "knn_morton",
     "knn_boxes", "knn_search", "debug_export", "extend", "dsort_hist", "dsort_scatter"};
+uint32_t g_lds_pad[K_COUNT] = {0};
+static const bool g_lds_pad_parsed = [] {   // GSLIC_LDS_PAD="name=bytes,name=bytes"
+    const char* e = getenv("GSLIC_LDS_PAD");
+    while (e && *e) {
+        const char* eq = strchr(e, '=');
+        if (!eq) break;
+        for (int k = 0; k < K_COUNT; k++)
+            if (strlen(k_names[k]) == (size_t)(eq - e) && strncmp(k_names[k], e, (size_t)(eq - e)) == 0) g_lds_pad[k] = (uint32_t)atoi(eq + 1);
+        const char* c = strchr(eq, ',');
+        e = c ? c + 1 : nullptr;
+    }
+    return true;
+}();
 struct ProfRec { int id; hipEvent_t a, b; };
 static std::vector<ProfRec> g_pending;
 static std::vector<hipEvent_t> g_pool;

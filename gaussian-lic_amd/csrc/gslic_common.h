@@ -66,10 +66,13 @@ extern bool g_prof_on;
 #define GS_FLAG_HITBITS 4   // index into GeomState::flags: set by a forward that recorded SampleState::hit
 extern int g_strict_math;  // gslic_set_math_mode(): 1 (default) = blend kernels in the reference's arithmetic (render.hip), 0 = fast (GSLIC_FAST_MATH=1)
 
+// g_lds_pad[id]: extra dynamic LDS per workgroup of kernel class id — occupancy experiments only (GSLIC_LDS_PAD="render_bwd=4000,preprocess=2000",
+// names as in the profiler's table; all zero by default): how much a kernel loses per wave of occupancy says what an LDS diet would buy.
+extern uint32_t g_lds_pad[];
 #define GS_LAUNCH(id, kernel, grid, block, shmem, stream, ...)                                             \
     do {                                                                                                   \
         if (::gslic::g_prof_on) ::gslic::prof_begin(id, stream);                                           \
-        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                               \
+        hipLaunchKernelGGL(kernel, grid, block, (shmem) + ::gslic::g_lds_pad[id], stream, __VA_ARGS__);    \
         if (::gslic::g_prof_on) ::gslic::prof_end(id, stream);                                             \
         GS_HIP(hipGetLastError());                                                                         \
     } while (0)

@@ -28,38 +28,49 @@ __constant__ float c_SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.45
 __device__ __forceinline__ float fmin_c(float a, float b) { return (b < a) ? b : a; }
 __device__ __forceinline__ float fmax_c(float a, float b) { return (b > a) ? b : a; }
 
-// LDS_SH (M == 15, colour mode): the block's 256 x 45 SH floats are contiguous in memory; they are staged through LDS with
-// coalesced float4 loads issued first (their latency hides under the projection / tile counting) and read row-wise by the
-// owning thread (row stride 45 floats: odd, bank-conflict free) instead of 45 strided 4-byte loads per visible Gaussian.
+// SH -> RGB of one Gaussian (forward.cu:29-77), the reference's operation order; sh = the Gaussian's features_rest row.
+__device__ __forceinline__ void sh_to_rgb(const PreprocessArgs& a, const int idx, const float px, const float py, const float pz,
+                                          const float* __restrict__ sh, float (&rgb)[3], uint32_t& clamp_bits)
+{
+    float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = dx / len, y = dy / len, z = dz / len;
+    const float* __restrict__ d0 = a.dc + 3 * (size_t)idx;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        float res = c_SH_C0 * d0[ch];
+#define S(k) sh[3 * (k) + ch]
+        if (a.D > 0) {
+            res = res - c_SH_C1 * y * S(0) + c_SH_C1 * z * S(1) - c_SH_C1 * x * S(2);
+            if (a.D > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                res = res + c_SH_C2[0] * xy * S(3) + c_SH_C2[1] * yz * S(4) + c_SH_C2[2] * (2.0f * zz - xx - yy) * S(5) +
+                      c_SH_C2[3] * xz * S(6) + c_SH_C2[4] * (xx - yy) * S(7);
+                if (a.D > 2) {
+                    res = res + c_SH_C3[0] * y * (3.0f * xx - yy) * S(8) + c_SH_C3[1] * xy * z * S(9) +
+                          c_SH_C3[2] * y * (4.0f * zz - xx - yy) * S(10) +
+                          c_SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * S(11) +
+                          c_SH_C3[4] * x * (4.0f * zz - xx - yy) * S(12) + c_SH_C3[5] * z * (xx - yy) * S(13) +
+                          c_SH_C3[6] * x * (xx - 3.0f * yy) * S(14);
+                }
+            }
+        }
+#undef S
+        res += 0.5f;
+        if (res < 0.0f) clamp_bits |= (1u << ch);
+        rgb[ch] = fmax_c(res, 0.0f);
+    }
+}
+
+// LDS_SH (M == 15, colour mode, one wave per workgroup): the block's SH rows reach their threads through LDS (see "SH -> RGB" below).
 template <bool LDS_SH, int BS>
 __global__ __launch_bounds__(BS) void preprocess_kernel(PreprocessArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float lds_sh[LDS_SH ? BS * 45 : 4];
+    __shared__ __attribute__((aligned(16))) float lds_sh[LDS_SH ? (BS / 2) * 45 : 4];
+    __shared__ uint8_t lds_v[LDS_SH ? BS : 4];
     const int idx = blockIdx.x * BS + threadIdx.x;
     const int lane = threadIdx.x & 63;
     for (int t = idx; t < a.gx * a.gy; t += gridDim.x * BS) a.ranges[t] = make_uint2(0u, 0u);
-    constexpr int SH_REGS = LDS_SH ? (BS * 45 / 4 + BS - 1) / BS : 1;  // float4 per thread of the block's SH region
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    v4f sh_pre[SH_REGS];
-#pragma unroll
-    for (int k = 0; k < SH_REGS; k++) sh_pre[k] = (v4f){0.f, 0.f, 0.f, 0.f};
-    if constexpr (LDS_SH) {
-        const int row0 = blockIdx.x * BS;
-        const int rows = (a.P - row0) < BS ? (a.P - row0) : BS;
-        const float* src = a.shs + (size_t)row0 * 45;
-        if (rows == BS) {
-            // the loads are issued here and parked in registers; they land in LDS only after the geometry below, which
-            // therefore runs under their latency (the kernel is latency-bound: 3 waves per SIMD, one dependent chain each)
-            const v4f* s4 = reinterpret_cast<const v4f*>(src);
-#pragma unroll
-            for (int k = 0; k < SH_REGS; k++) {
-                const int i = threadIdx.x + k * BS;
-                if (i < BS * 45 / 4) sh_pre[k] = __builtin_nontemporal_load(s4 + i);   // 360 MB read once per forward: past the L2's retention
-            }
-        } else {
-            for (int i = threadIdx.x; i < rows * 45; i += BS) lds_sh[i] = src[i];
-        }
-    }
     bool active = idx < a.P;
     const float* __restrict__ V = a.view;
     const float* __restrict__ Pm = a.proj;
@@ -194,52 +205,55 @@ __global__ __launch_bounds__(BS) void preprocess_kernel(PreprocessArgs a)
         a.tiles_touched[idx] = visible ? cnt : 0u;
         a.depth_keys[idx] = visible ? __float_as_uint(depth) : 0xffffffffu;  // low half of the reference's sort key (forward.cu:254)
     }
-    if constexpr (LDS_SH) {
-        if ((a.P - (int)(blockIdx.x * BS)) >= BS) {
-            v4f* d4 = reinterpret_cast<v4f*>(lds_sh);
-#pragma unroll
-            for (int k = 0; k < SH_REGS; k++) {
-                const int i = threadIdx.x + k * BS;
-                if (i < BS * 45 / 4) d4[i] = sh_pre[k];
-            }
-        }
-        __syncthreads();  // SH rows have landed in LDS (block-uniform: no thread has returned yet)
-    }
-    if (!visible) return;
-
     // ---- SH -> RGB (forward.cu:29-77) ----
     float rgb[3] = {0.f, 0.f, 0.f};
     uint32_t clamp_bits = 0;
-    if (!a.no_color) {
-        float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
-        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-        const float x = dx / len, y = dy / len, z = dz / len;
-        const float* __restrict__ d0 = a.dc + 3 * (size_t)idx;
-        const float* __restrict__ sh = LDS_SH ? (lds_sh + threadIdx.x * 45) : (a.shs ? a.shs + (size_t)3 * a.M * idx : nullptr);
+    if constexpr (LDS_SH) {
+        // The block's 64 x 45 SH floats are contiguous in memory: they pass through LDS in TWO rounds of 32 rows (5.6 KB instead of 11.3:
+        // the kernel is latency-bound and loses 18 % when LDS padding takes it from 13 to 10 waves per CU, profiles/r03t_occupancy_sweep.log),
+        // as coalesced float4 columns — only those that touch a visible Gaussian's row — and are read row-wise by the owning thread (row
+        // stride 45 floats: odd, bank-conflict free) instead of 45 strided 4-byte loads per visible Gaussian.
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        constexpr int HR = BS / 2, NV = HR * 45 / 4, NT = (NV + BS - 1) / BS;
+        const int row0 = blockIdx.x * BS;
+        const int rows = (a.P - row0) < BS ? (a.P - row0) : BS;
+        lds_v[threadIdx.x] = visible ? 1 : 0;
+        __syncthreads();
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            const float* src = a.shs + (size_t)(row0 + h * HR) * 45;
+            const int hrows = (rows - h * HR) < HR ? (rows - h * HR) : HR;
+            if (hrows == HR) {
+                const v4f* s4 = reinterpret_cast<const v4f*>(src);
+                v4f* d4 = reinterpret_cast<v4f*>(lds_sh);
+                v4f pre[NT];
+                bool ld[NT];
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            float res = c_SH_C0 * d0[ch];
-#define S(k) sh[3 * (k) + ch]
-            if (a.D > 0) {
-                res = res - c_SH_C1 * y * S(0) + c_SH_C1 * z * S(1) - c_SH_C1 * x * S(2);
-                if (a.D > 1) {
-                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    res = res + c_SH_C2[0] * xy * S(3) + c_SH_C2[1] * yz * S(4) + c_SH_C2[2] * (2.0f * zz - xx - yy) * S(5) +
-                          c_SH_C2[3] * xz * S(6) + c_SH_C2[4] * (xx - yy) * S(7);
-                    if (a.D > 2) {
-                        res = res + c_SH_C3[0] * y * (3.0f * xx - yy) * S(8) + c_SH_C3[1] * xy * z * S(9) +
-                              c_SH_C3[2] * y * (4.0f * zz - xx - yy) * S(10) +
-                              c_SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * S(11) +
-                              c_SH_C3[4] * x * (4.0f * zz - xx - yy) * S(12) + c_SH_C3[5] * z * (xx - yy) * S(13) +
-                              c_SH_C3[6] * x * (xx - 3.0f * yy) * S(14);
+                for (int k = 0; k < NT; k++) {
+                    const int i = threadIdx.x + k * BS;
+                    ld[k] = false;
+                    if (i < NV) {
+                        const int e = 4 * i;
+                        ld[k] = (lds_v[h * HR + e / 45] | lds_v[h * HR + (e + 3) / 45]) != 0;
+                        if (ld[k]) pre[k] = __builtin_nontemporal_load(s4 + i);   // 360 MB read once per forward: past the L2's retention
                     }
                 }
+#pragma unroll
+                for (int k = 0; k < NT; k++) {
+                    const int i = threadIdx.x + k * BS;
+                    if (ld[k]) d4[i] = pre[k];
+                }
+            } else {
+                for (int i = threadIdx.x; i < hrows * 45; i += BS) lds_sh[i] = src[i];
             }
-#undef S
-            res += 0.5f;
-            if (res < 0.0f) clamp_bits |= (1u << ch);
-            rgb[ch] = fmax_c(res, 0.0f);
+            __syncthreads();
+            if (visible && (int)(threadIdx.x / HR) == h) sh_to_rgb(a, idx, px, py, pz, lds_sh + (threadIdx.x % HR) * 45, rgb, clamp_bits);
+            __syncthreads();
         }
+        if (!visible) return;
+    } else {
+        if (!visible) return;
+        if (!a.no_color) sh_to_rgb(a, idx, px, py, pz, a.shs ? a.shs + (size_t)3 * a.M * idx : nullptr, rgb, clamp_bits);
     }
     float4* rec = a.rec + GS_REC_F4 * (size_t)idx;
     rec[0] = make_float4(mx, my, cA, cB);

@@ -719,9 +719,8 @@ int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
     if (a.M == 15 && a.shs && (a.dL_dsh || a.adam.on || a.dL_drgb)) {
         // one wave per workgroup: 64 Gaussians' SH rows (11.25 KiB) + small-group gradients in LDS, the phase barriers are wave-level,
         // and ten workgroups per CU sit in different phases (measured 0.72 ms against 0.75 at 128 and 0.88 at 256 threads)
-        static const int lds_pad = [] { const char* e = getenv("GSLIC_PBWD_LDS_PAD"); return e ? atoi(e) : 0; }();  // occupancy experiments only
-        if (cam) GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64, true>), dim3(div_up(nrows, 64)), dim3(64), (size_t)lds_pad, s, a);
-        else GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64, false>), dim3(div_up(nrows, 64)), dim3(64), (size_t)lds_pad, s, a);
+        if (cam) GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64, true>), dim3(div_up(nrows, 64)), dim3(64), 0, s, a);
+        else GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<true, 64, false>), dim3(div_up(nrows, 64)), dim3(64), 0, s, a);
     } else {
         if (cam) GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<false, 256, true>), dim3(div_up(nrows, 256)), dim3(256), 0, s, a);
         else GS_LAUNCH(K_PREPROCESS_BWD, (preprocess_bwd_kernel<false, 256, false>), dim3(div_up(nrows, 256)), dim3(256), 0, s, a);

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_scatter_kernel(const SortPass
     __shared__ uint32_t red[8];
     __shared__ uint32_t s_tile;
     __shared__ uint32_t skeys[RS_TILE];
-    __shared__ uint32_t svals[NV][RS_TILE];
+    __shared__ uint32_t svals[RS_TILE];   // ONE payload at a time (see below)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (ONESWEEP && tid == 0) s_tile = atomicAdd(a.ticket, 1u);
@@ -249,28 +249,32 @@ __global__ __launch_bounds__(RS_THREADS) void sort_scatter_kernel(const SortPass
     gofs[tid] = gl;
     __syncthreads();
 
-#pragma unroll
-    for (int i = 0; i < RS_ITEMS; i++) {
-        const size_t idx = base + (size_t)i * 64 + lane;
-        if (idx < n) {
-            const uint32_t d = (key[i] >> shift) & 0xffu;
-            const uint32_t pos = dstart[d] + cnt[wave][d] + rank[i];
-            skeys[pos] = key[i];
-#pragma unroll
-            for (int v = 0; v < NV; v++) svals[v][pos] = val[v][i];
-        }
-    }
-    __syncthreads();
-
+    // Keys and payloads leave through LDS in block-sorted order, as contiguous runs per digit.  The payloads take turns in ONE staging
+    // buffer: with two of them resident the kernel held 54 KB of LDS — two workgroups per CU — and it loses a third of its speed when
+    // padding takes it from two to one (profiles/r03t_occupancy_sweep.log); 38 KB allow four.
     const size_t remain = n > blk_base ? n - blk_base : 0;
     const uint32_t nvalid = remain < (size_t)RS_TILE ? (uint32_t)remain : (uint32_t)RS_TILE;
-    for (uint32_t j = tid; j < nvalid; j += RS_THREADS) {
-        const uint32_t k = skeys[j];
-        const uint32_t d = (k >> shift) & 0xffu;
-        const size_t g = (size_t)gofs[d] + (j - dstart[d]);
-        a.kout[g] = k;
 #pragma unroll
-        for (int v = 0; v < NV; v++) a.vout[v][g] = svals[v][j];
+    for (int v = 0; v < NV; v++) {
+        if (v > 0) __syncthreads();   // the previous payload has left the buffer
+#pragma unroll
+        for (int i = 0; i < RS_ITEMS; i++) {
+            const size_t idx = base + (size_t)i * 64 + lane;
+            if (idx < n) {
+                const uint32_t d = (key[i] >> shift) & 0xffu;
+                const uint32_t pos = dstart[d] + cnt[wave][d] + rank[i];
+                if (v == 0) skeys[pos] = key[i];
+                svals[pos] = val[v][i];
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = tid; j < nvalid; j += RS_THREADS) {
+            const uint32_t k = skeys[j];
+            const uint32_t d = (k >> shift) & 0xffu;
+            const size_t g = (size_t)gofs[d] + (j - dstart[d]);
+            if (v == 0) a.kout[g] = k;
+            a.vout[v][g] = svals[j];
+        }
     }
 }
 

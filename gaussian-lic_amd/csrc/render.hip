@@ -633,7 +633,6 @@ int launch_render_fwd(const RenderFwdArgs& a, hipStream_t s)
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s)
 {
     if (a.B <= 0) return GSLIC_OK;
-    static const int lds_pad = [] { const char* e = getenv("GSLIC_BWD_LDS_PAD"); return e ? atoi(e) : 0; }();  // occupancy experiments only
     // GSLIC_BWD_XCD_RUN = run length of consecutive buckets per XCD (a power of two; 0 = plain blockIdx order)
     static const int xcd_lg = [] {
         const char* e = getenv("GSLIC_BWD_XCD_RUN");
@@ -646,8 +645,8 @@ int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s)
     b.xcd_lg = xcd_lg;
     unsigned grid = (unsigned)a.B;
     if (xcd_lg >= 0) { const unsigned unit = 8u << xcd_lg; grid = (grid + unit - 1u) / unit * unit; }
-    if (g_strict_math) GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel<true>, dim3(grid), dim3(64), (size_t)lds_pad, s, b);
-    else GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel<false>, dim3(grid), dim3(64), (size_t)lds_pad, s, b);
+    if (g_strict_math) GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel<true>, dim3(grid), dim3(64), 0, s, b);
+    else GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel<false>, dim3(grid), dim3(64), 0, s, b);
     return GSLIC_OK;
 }
 
