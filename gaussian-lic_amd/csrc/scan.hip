@@ -180,26 +180,39 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32
 }
 
 // tiles' bucket counts and their inclusive scan in one single-block launch (rasterizer_impl.cu:433-441): T is the tile count of an
-// image, a few thousand
-__global__ __launch_bounds__(SCAN_THREADS) void bucket_scan_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ bucket_offsets,
-                                                                   uint32_t* __restrict__ max_contrib)
+// image, a few thousand.  1024 threads x 8 tiles: one trip for a 1080p image (8160 tiles) — the kernel is a chain of dependent memory
+// round trips, so trips are what it costs (256 x 16 took two: 14 us).
+static constexpr int BSC_THREADS = 1024, BSC_ITEMS = 8, BSC_TILE = BSC_THREADS * BSC_ITEMS;
+__global__ __launch_bounds__(BSC_THREADS) void bucket_scan_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ bucket_offsets,
+                                                                  uint32_t* __restrict__ max_contrib)
 {
-    __shared__ uint32_t lds[8];
+    __shared__ uint32_t wsum[BSC_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t carry = 0;
-    for (int base = 0; base < T; base += SCAN_TILE) {
-        const int t0 = base + (int)threadIdx.x * SCAN_ITEMS;
-        uint32_t v[SCAN_ITEMS];
+    for (int base = 0; base < T; base += BSC_TILE) {
+        const int t0 = base + (int)threadIdx.x * BSC_ITEMS;
+        uint32_t v[BSC_ITEMS];
         uint32_t s = 0;
 #pragma unroll
-        for (int i = 0; i < SCAN_ITEMS; i++) {
+        for (int i = 0; i < BSC_ITEMS; i++) {
             uint32_t c = 0;
             if (t0 + i < T) { const uint2 r = ranges[t0 + i]; c = (r.y - r.x + (GS_BUCKET - 1)) / GS_BUCKET; }
             v[i] = c; s += c;
         }
-        uint32_t total;
-        uint32_t run = carry + block256_exclusive_prefix(s, total, lds);
+        const uint32_t inc = wave_inclusive_scan(s);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t wave_base = 0, total = 0;
 #pragma unroll
-        for (int i = 0; i < SCAN_ITEMS; i++) {
+        for (int w = 0; w < BSC_THREADS / 64; w++) {
+            const uint32_t x = wsum[w];
+            if (w < wave) wave_base += x;
+            total += x;
+        }
+        __syncthreads();
+        uint32_t run = carry + wave_base + inc - s;
+#pragma unroll
+        for (int i = 0; i < BSC_ITEMS; i++) {
             run += v[i];
             if (t0 + i < T) { bucket_offsets[t0 + i] = run; max_contrib[t0 + i] = 0u; }  // (render_fwd's waves of a tile combine their maxima with atomicMax)
         }
@@ -211,7 +224,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void bucket_scan_kernel(int T, const 
 // itself costs this single-block kernel 7 us on every forward: a net loss on four of five workloads.  Not in the tree.)
 int launch_bucket_scan(int T, const uint2* ranges, uint32_t* bucket_offsets, uint32_t* max_contrib, hipStream_t s)
 {
-    GS_LAUNCH(K_BUCKET_COUNT, bucket_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, T, ranges, bucket_offsets, max_contrib);
+    GS_LAUNCH(K_BUCKET_COUNT, bucket_scan_kernel, dim3(1), dim3(BSC_THREADS), 0, s, T, ranges, bucket_offsets, max_contrib);
     return GSLIC_OK;
 }
 
