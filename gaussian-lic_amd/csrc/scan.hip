@@ -5,7 +5,7 @@
 //                    seven scans): a block posts its tile total as one 8-byte {flag | sum} word (relaxed agent-scope atomic
 //                    store, as in radix_sort.hip's onesweep protocol), then its 256 threads poll the words of ALL preceding
 //                    tiles in parallel and reduce them to the carry-in.  Tiles are ticketed, so every tile a block waits for
-//                    has started.  Reads grow as nb^2 / 2 words, so above 1024 tiles it falls back to the three launches.
+//                    has started.  Reads grow as nb^2 / 2 words, so above 2048 tiles it falls back to the three launches.
 #include "gslic_common.h"
 #include <stdlib.h>
 
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
 }
 
 static constexpr unsigned long long SC_FLAG = 1ull << 63;
-static constexpr size_t SC_MAX_TILES = 1024;
+static constexpr size_t SC_MAX_TILES = 2048;   // 8.4M elements: the scans over P of a 5M-Gaussian map (1221 tiles) stay one launch — and one gather
 
 // state: u32 ticket (in word 0) | u64 words[nb], all zero on entry
 __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32_t* in, const uint32_t* __restrict__ gather, uint32_t* out,
