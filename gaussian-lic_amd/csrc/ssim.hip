@@ -6,7 +6,7 @@
 // The 42x42 input halo tiles are staged once in LDS; the horizontal pass produces ALL statistics of a row in
 // one sweep (forward: E[a], E[a^2], E[b], E[b^2], E[ab]; backward: the three dL-weighted maps) into LDS, then
 // the vertical pass finishes them — 3 barriers per plane instead of the reference's ~25 per channel, and no
-// scratch flush.  LDS: forward 14.1 KB + 26.9 KB, backward 21.2 KB + 16.1 KB.  Forward: the two images interleaved in LDS, statistics on
+// scratch flush.  LDS: forward 14.1 KB + 21.5 KB, backward 21.2 KB (the horizontal sums overwrite the rows they came from).  Forward: the two images interleaved in LDS, statistics on
 // float2 pairs (v_pk_fma_f32); backward: three separate maps, scalar FMAs (see the note above ssim_bwd_kernel).
 #include "gslic_common.h"
 
@@ -33,13 +33,18 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // the statistics are accumulated on float2 pairs with v_pk_fma_f32 / v_pk_mul_f32 (5 VALU per tap instead of 8, 3 instead of 5 in the
 // vertical pass, fewer and wider LDS reads); every component still sees the reference's operation sequence (taps 0..10 from 0.0f).
 struct FwdLds {
-    v2f ab[SH_][SH_];   // {img1, img2} halo tile
+    v2f ab[SH_][SH_];   // {img1, img2} halo tile; after the horizontal pass the first 32 floats of row ly hold that row's E[ab] (h1)
     v4f h4[SH_][ST];    // horizontal pass: {E[a], E[b], E[a^2], E[b^2]}
-    float h1[SH_][ST];  // horizontal pass: E[ab]
+    // E[ab] of the horizontal pass overwrites the head of the halo row it was computed from (128 of its 336 bytes): the wave that owns a
+    // row has read all of it by then (two rows per wave, lockstep), and nothing reads the halo tile afterwards.  35.6 KB instead of 41.0:
+    // four workgroups per CU instead of three (the kernel loses 14 % from three to two: profiles/r03t_occupancy_sweep.log).
+    __device__ __forceinline__ float* h1(int ly) { return reinterpret_cast<float*>(&ab[ly][0]); }
+    __device__ __forceinline__ const float* h1(int ly) const { return reinterpret_cast<const float*>(&ab[ly][0]); }
 };
 struct FwdStats { float mu1, mu2, e11, e22, e12; };
 
-__device__ __forceinline__ void ssim_fwd_stage(FwdLds& L, const float* __restrict__ a, const float* __restrict__ b, int H, int W, int x0, int y0)
+// l1: += |a - b| over this thread's elements of the 32 x 32 centre (0 outside the image: both read as zero there)
+__device__ __forceinline__ void ssim_fwd_stage(FwdLds& L, const float* __restrict__ a, const float* __restrict__ b, int H, int W, int x0, int y0, float& l1)
 {
     const int tid = threadIdx.x;
     // all of a thread's halo loads are issued before the first LDS store: a rolled loop pays one memory round trip per trip
@@ -50,6 +55,7 @@ __device__ __forceinline__ void ssim_fwd_stage(FwdLds& L, const float* __restric
         const int ly = t / SH_, lx = t - ly * SH_;
         va[k] = (t < SH_ * SH_) ? pix_or_zero(a, H, W, y0 + ly - 5, x0 + lx - 5) : 0.f;
         vb[k] = (t < SH_ * SH_) ? pix_or_zero(b, H, W, y0 + ly - 5, x0 + lx - 5) : 0.f;
+        if (t < SH_ * SH_ && ly >= 5 && ly < 5 + ST && lx >= 5 && lx < 5 + ST) l1 += fabsf(va[k] - vb[k]);
     }
 #pragma unroll
     for (int k = 0; k < HALO_TRIPS; k++) {
@@ -70,7 +76,7 @@ __device__ __forceinline__ void ssim_fwd_stage(FwdLds& L, const float* __restric
             r4 = __builtin_fmaf(c_G[i], p.x * p.y, r4);
         }
         L.h4[ly][lx] = (v4f){r02.x, r02.y, r13.x, r13.y};
-        L.h1[ly][lx] = r4;
+        L.h1(ly)[lx] = r4;
     }
     __syncthreads();
 }
@@ -86,7 +92,7 @@ __device__ __forceinline__ void ssim_fwd_column4(const FwdLds& L, int ly0, int l
 #pragma unroll
     for (int r = 0; r < 14; r++) {
         const v4f q = L.h4[ly0 + r][lx];
-        const float q1 = L.h1[ly0 + r][lx];
+        const float q1 = L.h1(ly0 + r)[lx];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int j = r - k;
@@ -136,7 +142,8 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, float C1, f
     const size_t plane = (size_t)blockIdx.z * H * W;
     const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
     const int tid = threadIdx.x;
-    ssim_fwd_stage(L, img1 + plane, img2 + plane, H, W, x0, y0);
+    float l1_unused = 0.f;
+    ssim_fwd_stage(L, img1 + plane, img2 + plane, H, W, x0, y0, l1_unused);
     const int lx = tid & 31;
     FwdStats st4[4];
     ssim_fwd_column4(L, 4 * (tid >> 5), lx, st4);
@@ -165,10 +172,11 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float
                                                        const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12,
                                                        float* __restrict__ dL_dimg1)
 {
+    // the horizontal pass overwrites the first 32 floats of each row with that row's sums (the wave that owns a row has read all of it
+    // by then: two rows per wave, lockstep): 21.2 KB instead of 37.3 — six workgroups per CU instead of four
     __shared__ float s1[SH_][SH_];
     __shared__ float s2[SH_][SH_];
     __shared__ float s3[SH_][SH_];
-    __shared__ float hs[3][SH_][ST];
     const size_t plane = (size_t)blockIdx.z * H * W;
     const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
     const int tid = threadIdx.x;
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float
             const float g = c_G[i];
             r0 += g * s1[ly][lx + i]; r1 += g * s2[ly][lx + i]; r2 += g * s3[ly][lx + i];
         }
-        hs[0][ly][lx] = r0; hs[1][ly][lx] = r1; hs[2][ly][lx] = r2;
+        s1[ly][lx] = r0; s2[ly][lx] = r1; s3[ly][lx] = r2;
     }
     __syncthreads();
     const int lx = tid & 31;
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float
     float w0[4] = {0.f, 0.f, 0.f, 0.f}, w1[4] = {0.f, 0.f, 0.f, 0.f}, w2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 14; r++) {
-        const float a0 = hs[0][ly0 + r][lx], a1 = hs[1][ly0 + r][lx], a2 = hs[2][ly0 + r][lx];
+        const float a0 = s1[ly0 + r][lx], a1 = s2[ly0 + r][lx], a2 = s3[ly0 + r][lx];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int j = r - k;
@@ -261,9 +269,9 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(int H, int W, float C1, f
     const size_t plane = (size_t)blockIdx.z * H * W;
     const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
     const int tid = threadIdx.x;
-    ssim_fwd_stage(L, img1 + plane, img2 + plane, H, W, x0, y0);
-    const int lx = tid & 31;
     float sum_l1 = 0.f, sum_ssim = 0.f;
+    ssim_fwd_stage(L, img1 + plane, img2 + plane, H, W, x0, y0, sum_l1);
+    const int lx = tid & 31;
     FwdStats st4[4];
     ssim_fwd_column4(L, 4 * (tid >> 5), lx, st4);
 #pragma unroll
@@ -275,8 +283,6 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(int H, int W, float C1, f
             const SsimTerms t = ssim_terms(st, C1, C2);
             const size_t o = plane + (size_t)py * W + px;
             sum_ssim += t.map;
-            const v2f c = L.ab[ly + 5][lx + 5];
-            sum_l1 += fabsf(c.x - c.y);
             dm_dmu1[o] = t.d_mu1;
             dm_dsigma1_sq[o] = t.d_sigma1_sq;
             dm_dsigma12[o] = t.d_sigma12;
@@ -308,10 +314,11 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(int H, int W, float w_l1,
                                                        const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12,
                                                        float* __restrict__ dL_dimg1)
 {
+    // the horizontal pass overwrites the first 32 floats of each row with that row's sums (the wave that owns a row has read all of it
+    // by then: two rows per wave, lockstep): 21.2 KB instead of 37.3 — six workgroups per CU instead of four
     __shared__ float s1[SH_][SH_];
     __shared__ float s2[SH_][SH_];
     __shared__ float s3[SH_][SH_];
-    __shared__ float hs[3][SH_][ST];
     const size_t plane = (size_t)blockIdx.z * H * W;
     const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
     const int tid = threadIdx.x;
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(int H, int W, float w_l1,
             const float g = c_G[i];
             r0 += g * s1[ly][lx + i]; r1 += g * s2[ly][lx + i]; r2 += g * s3[ly][lx + i];
         }
-        hs[0][ly][lx] = r0; hs[1][ly][lx] = r1; hs[2][ly][lx] = r2;
+        s1[ly][lx] = r0; s2[ly][lx] = r1; s3[ly][lx] = r2;
     }
     __syncthreads();
     const int lx = tid & 31;
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(int H, int W, float w_l1,
     float w0[4] = {0.f, 0.f, 0.f, 0.f}, w1[4] = {0.f, 0.f, 0.f, 0.f}, w2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 14; r++) {
-        const float a0 = hs[0][ly0 + r][lx], a1 = hs[1][ly0 + r][lx], a2 = hs[2][ly0 + r][lx];
+        const float a0 = s1[ly0 + r][lx], a1 = s2[ly0 + r][lx], a2 = s3[ly0 + r][lx];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int j = r - k;
