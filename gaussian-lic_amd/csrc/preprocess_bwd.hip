@@ -738,15 +738,18 @@ int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
 // dL_ddc / dL_dsh per Gaussian: every rank all-gathers the views' 3-float dRGB and rebuilds the summed rows here — per view the very
 // products the backward forms (sh_dir / sh_coefs shared, multiply then add, no contraction), summed in view order.
 // One wave per 64 Gaussians; the rows leave through LDS as contiguous runs (M == 15) like the backward's own dL_dsh rows.
+static constexpr int SGR = 32;
 template <bool ADAM>
 __global__ __launch_bounds__(64) void sh_grad_from_rgb_kernel(ShGradFromRgbArgs a)
 {
 #pragma clang fp contract(off)
-    __shared__ float lds_rows[64 * 48];
+    // SGR = 32 Gaussians per one-wave workgroup: lanes 0..31 rebuild a row each, then all 64 lanes stream the block's moments.  With 64 rows
+    // the staging buffer was 12 KB and the kernel ran at 12 waves per CU; it lives on its occupancy like preprocess_bwd (6 KB: 20 waves).
+    __shared__ __attribute__((aligned(16))) float lds_rows[SGR * 48];
     const int t = threadIdx.x;
-    const int row0 = blockIdx.x * 64;
-    const int idx = row0 + t;
-    const int rows = (a.P - row0) < 64 ? (a.P - row0) : 64;
+    const int row0 = blockIdx.x * SGR;
+    const int idx = t < SGR ? row0 + t : a.P;   // (lanes 32..63 own no Gaussian)
+    const int rows = (a.P - row0) < SGR ? (a.P - row0) : SGR;
     float acc[45], adc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 45; k++) acc[k] = 0.f;
@@ -779,34 +782,36 @@ __global__ __launch_bounds__(64) void sh_grad_from_rgb_kernel(ShGradFromRgbArgs 
             }
         }
     }
-    // dc rows [64 x 3] then rest rows [64 x 45] through LDS: contiguous float runs instead of 48 strided 4-byte stores per thread
+    // dc rows [32 x 3] then rest rows [32 x 45] through LDS: contiguous float runs instead of 48 strided 4-byte stores per thread
+    if (t < SGR) {
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) lds_rows[3 * t + ch] = adc[ch];
+        for (int ch = 0; ch < 3; ch++) lds_rows[3 * t + ch] = adc[ch];
 #pragma unroll
-    for (int k = 0; k < 45; k++) lds_rows[192 + 45 * t + k] = acc[k];
+        for (int k = 0; k < 45; k++) lds_rows[3 * SGR + 45 * t + k] = acc[k];
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (a.dL_ddc)
         for (int i = t; i < rows * 3; i += 64) a.dL_ddc[(size_t)row0 * 3 + i] = lds_rows[i];
     if (a.dL_dsh) {
         if (a.M == 15) {
-            for (int i = t; i < rows * 45; i += 64) a.dL_dsh[(size_t)row0 * 45 + i] = lds_rows[192 + i];
-        } else if (a.M > 0 && idx < a.P) {   // generic row width: coefficients above 15 (and above the active degree) are zero
-            for (int k = 0; k < 3 * a.M; k++) a.dL_dsh[(size_t)3 * a.M * idx + k] = k < 45 ? lds_rows[192 + 45 * t + k] : 0.f;
+            for (int i = t; i < rows * 45; i += 64) a.dL_dsh[(size_t)row0 * 45 + i] = lds_rows[3 * SGR + i];
+        } else if (a.M > 0 && idx < a.P) {   // generic row width (lanes 0..31): coefficients above 15 (and above the active degree) are zero
+            for (int k = 0; k < 3 * a.M; k++) a.dL_dsh[(size_t)3 * a.M * idx + k] = k < 45 ? lds_rows[3 * SGR + 45 * t + k] : 0.f;
         }
     }
     if constexpr (ADAM) {
         // the masked Adam of optim_utils.h:102-137 on features_dc and features_rest straight from the rebuilt rows (adam_scalar: the one
         // definition every call site shares), on float4 columns of the block's contiguous regions like the fused backward's phase C
         __shared__ uint8_t lds_vis[64];
-        lds_vis[t] = (idx < a.P && a.visible[idx]) ? 1 : 0;
+        lds_vis[t] = (idx < a.P && a.visible[idx]) ? 1 : 0;   // (entries 32..63: never read)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const AdamFusedArgs& A = a.adam;
         auto update = [&](int grp, int width, const float* rows_lds, size_t base) {
-            // region of this block: rows * width floats at param + base, 16-byte aligned (row0 is a multiple of 64)
-            if (rows == 64) {
-                const int nv = 64 * width / 4;
+            // region of this block: rows * width floats at param + base, 16-byte aligned (row0 is a multiple of 32)
+            if (rows == SGR) {
+                const int nv = SGR * width / 4;
                 const float4* s4 = reinterpret_cast<const float4*>(rows_lds);
                 constexpr int U = 4;
                 for (int i0 = t; i0 < nv; i0 += 64 * U) {
@@ -849,11 +854,11 @@ __global__ __launch_bounds__(64) void sh_grad_from_rgb_kernel(ShGradFromRgbArgs 
         };
         update(1, 3, lds_rows, (size_t)row0 * 3);
         if (a.M == 15) {
-            update(2, 45, lds_rows + 192, (size_t)row0 * 45);
+            update(2, 45, lds_rows + 3 * SGR, (size_t)row0 * 45);
         } else if (a.M > 0 && idx < a.P && lds_vis[t]) {
             for (int k = 0; k < 3 * a.M; k++) {
                 const size_t o = (size_t)3 * a.M * idx + k;
-                adam_scalar(A.p[2][o], k < 45 ? lds_rows[192 + 45 * t + k] : 0.f, A.m[2][o], A.v[2][o], A.lr[2], A.b1, A.b2, A.eps);
+                adam_scalar(A.p[2][o], k < 45 ? lds_rows[3 * SGR + 45 * t + k] : 0.f, A.m[2][o], A.v[2][o], A.lr[2], A.b1, A.b2, A.eps);
             }
         }
     }
@@ -862,8 +867,8 @@ __global__ __launch_bounds__(64) void sh_grad_from_rgb_kernel(ShGradFromRgbArgs 
 int launch_sh_grad_from_rgb(const ShGradFromRgbArgs& a, hipStream_t s)
 {
     if (a.P <= 0) return GSLIC_OK;
-    if (a.adam.on) GS_LAUNCH(K_ADAM, sh_grad_from_rgb_kernel<true>, dim3(div_up(a.P, 64)), dim3(64), 0, s, a);
-    else GS_LAUNCH(K_PREPROCESS_BWD, sh_grad_from_rgb_kernel<false>, dim3(div_up(a.P, 64)), dim3(64), 0, s, a);
+    if (a.adam.on) GS_LAUNCH(K_ADAM, sh_grad_from_rgb_kernel<true>, dim3(div_up(a.P, SGR)), dim3(64), 0, s, a);
+    else GS_LAUNCH(K_PREPROCESS_BWD, sh_grad_from_rgb_kernel<false>, dim3(div_up(a.P, SGR)), dim3(64), 0, s, a);
     return GSLIC_OK;
 }
 
