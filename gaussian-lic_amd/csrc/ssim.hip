@@ -7,7 +7,8 @@
 // one sweep (forward: E[a], E[a^2], E[b], E[b^2], E[ab]; backward: the three dL-weighted maps) into LDS, then
 // the vertical pass finishes them — 3 barriers per plane instead of the reference's ~25 per channel, and no
 // scratch flush.  LDS: forward 14.1 KB + 21.5 KB, backward 21.2 KB (the horizontal sums overwrite the rows they came from).  Forward: the two images interleaved in LDS, statistics on
-// float2 pairs (v_pk_fma_f32); backward: three separate maps, scalar FMAs (see the note above ssim_bwd_kernel).
+// float2 pairs (packed multiply + packed add); backward: three separate maps, scalar arithmetic (see the note above ssim_bwd_kernel).
+// Compiled with -ffp-contract=off (build.py): no product is fused into a sum, so the maps do not depend on instruction selection.
 #include "gslic_common.h"
 
 namespace gslic {
@@ -27,11 +28,10 @@ __device__ __forceinline__ float pix_or_zero(const float* __restrict__ img, int 
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
-#define SS_FMA2(a, b, c) __builtin_elementwise_fma((a), (b), (c))
 
 // ---- shared cores.  The two images (the three derivative maps) sit INTERLEAVED in LDS — one ds_read_b64 fetches the pixel pair — and
-// the statistics are accumulated on float2 pairs with v_pk_fma_f32 / v_pk_mul_f32 (5 VALU per tap instead of 8, 3 instead of 5 in the
-// vertical pass, fewer and wider LDS reads); every component still sees the reference's operation sequence (taps 0..10 from 0.0f).
+// the statistics are accumulated on float2 pairs with v_pk_mul_f32 + v_pk_add_f32 (fewer and wider LDS reads); every component sees the
+// reference's operation sequence (taps 0..10 from 0.0f, product and sum rounded separately: the file is compiled with -ffp-contract=off).
 struct FwdLds {
     v2f ab[SH_][SH_];   // {img1, img2} halo tile; after the horizontal pass the first 32 floats of row ly hold that row's E[ab] (h1)
     v4f h4[SH_][ST];    // horizontal pass: {E[a], E[b], E[a^2], E[b^2]}
@@ -71,9 +71,9 @@ __device__ __forceinline__ void ssim_fwd_stage(FwdLds& L, const float* __restric
         for (int i = 0; i < 11; i++) {
             const v2f p = L.ab[ly][lx + i];
             const v2f g2 = {c_G[i], c_G[i]};
-            r02 = SS_FMA2(g2, p, r02);
-            r13 = SS_FMA2(g2, p * p, r13);
-            r4 = __builtin_fmaf(c_G[i], p.x * p.y, r4);
+            r02 = r02 + g2 * p;                 // val += G_i * pixel            (ssim.cu:116-126; this file is compiled with -ffp-contract=off:
+            r13 = r13 + g2 * (p * p);           // val += G_i * do_sq(pixel)      every product and every sum is rounded on its own, like the
+            r4 = r4 + c_G[i] * (p.x * p.y);     // val += G_i * (pix1 * pix2)     reference's kernels under the same flag — bit-identical maps)
         }
         L.h4[ly][lx] = (v4f){r02.x, r02.y, r13.x, r13.y};
         L.h1(ly)[lx] = r4;
@@ -98,9 +98,9 @@ __device__ __forceinline__ void ssim_fwd_column4(const FwdLds& L, int ly0, int l
             const int j = r - k;
             if (j >= 0 && j <= 10) {
                 const v2f g2 = {c_G[j], c_G[j]};
-                v02[k] = SS_FMA2(g2, ((v2f){q.x, q.y}), v02[k]);
-                v13[k] = SS_FMA2(g2, ((v2f){q.z, q.w}), v13[k]);
-                v4[k] = __builtin_fmaf(c_G[j], q1, v4[k]);
+                v02[k] = v02[k] + g2 * ((v2f){q.x, q.y});
+                v13[k] = v13[k] + g2 * ((v2f){q.z, q.w});
+                v4[k] = v4[k] + c_G[j] * q1;
             }
         }
     }
@@ -110,8 +110,8 @@ __device__ __forceinline__ void ssim_fwd_column4(const FwdLds& L, int ly0, int l
 
 // SSIM of one pixel from its five window statistics, and the three derivative maps the backward consumes (ssim.cu:261-282).
 // SSIM = (lum_n * con_n) / (lum_d * con_d): luminance and contrast-structure terms, numerators and denominators; every quotient keeps the
-// reference's association (the CPU oracle reproduces the reference's maps bit for bit; this file is compiled with fma contraction and
-// agrees with the reference's kernels to 1.5e-5).  One definition for the drop-in kernel and the fused loss kernel.
+// reference's association and, with contraction off, its roundings: the maps equal the reference kernels' (and the CPU oracle's) bit for bit
+// (tests/test_vs_reference_kernels_gpu.py).  One definition for the drop-in kernel and the fused loss kernel.
 struct SsimTerms { float map, d_mu1, d_sigma1_sq, d_sigma12; };
 __device__ __forceinline__ SsimTerms ssim_terms(const FwdStats& st, float C1, float C2)
 {
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, float C1, f
     }
 }
 
-// The backward keeps three separate LDS arrays and scalar FMAs: the interleaved / packed variant of the forward was measured slower here
+// The backward keeps three separate LDS arrays and scalar arithmetic: the interleaved / packed variant of the forward was measured slower here
 // (0.063 -> 0.071 ms: three maps do not pair up, the float2 rows of 42 conflict on the LDS banks).
 __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                                                        const float* __restrict__ dL_dmap, const float* __restrict__ dm_dmu1,
@@ -307,8 +307,9 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(size_t nblk, const flo
     if (threadIdx.x == 0) { terms[0] = t0 * inv_n; terms[1] = t1 * inv_n; }
 }
 
-// dL/dimg for dL/dloss = 1: the SSIM branch is ssim_bwd_kernel with the uniform upstream gradient -lambda/N pulled out of the
-// convolutions (zero padding commutes with a constant factor), plus the L1 branch (1-lambda)/N * sign(img - gt).
+// dL/dimg for dL/dloss = 1: the SSIM branch is ssim_bwd_kernel with the uniform upstream gradient dL_dmap = -lambda/N (multiplied into the
+// derivative maps before the convolutions, exactly where fusedssim_backwardCUDA multiplies by dL_dmap: ssim.cu:318-350), plus the L1 branch
+// (1-lambda)/N * sign(img - gt): bit-identical to fusedssim_backward(full(-lambda/N)) + (1-lambda)/N * sign(img - gt).
 __global__ __launch_bounds__(256) void loss_bwd_kernel(int H, int W, float w_l1, float w_ssim, const float* __restrict__ img1,
                                                        const float* __restrict__ img2, const float* __restrict__ dm_dmu1,
                                                        const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12,
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(int H, int W, float w_l1,
 #pragma unroll
         for (int k = 0; k < HALO_TRIPS; k++) {
             const int t = tid + 256 * k;
-            if (t < SH_ * SH_) { (&s1[0][0])[t] = v1[k]; (&s2[0][0])[t] = v2[k]; (&s3[0][0])[t] = v3[k]; }
+            if (t < SH_ * SH_) { (&s1[0][0])[t] = v1[k] * w_ssim; (&s2[0][0])[t] = v2[k] * w_ssim; (&s3[0][0])[t] = v3[k] * w_ssim; }
         }
     }
     __syncthreads();
@@ -378,7 +379,11 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(int H, int W, float w_l1,
             const float pix1 = img1[o], pix2 = img2[o];
             const float d = pix1 - pix2;
             const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);  // torch.sign (abs backward)
-            dL_dimg1[o] = w_ssim * (v0 + pix1 * 2.0f * v1 + pix2 * v2) + w_l1 * sgn;
+            float acc = 0.0f;
+            acc += v0;
+            acc += pix1 * 2.0f * v1;
+            acc += pix2 * v2;
+            dL_dimg1[o] = w_l1 * sgn + acc;
         }
     }
 }

@@ -80,13 +80,11 @@ def test_twenty_training_steps_track_the_oracle(kind, P, W, H, lr_scale):
 
     # ---- the gate
     assert o_loss[-1] < o_loss[0]                                           # the optimisation does move
-    # step by step: the first steps agree to fp32 rounding; later Adam's normalised update (|step| = lr whatever the gradient's size) turns
-    # last-bit differences of near-zero gradients into lr-sized differences of single parameters, and the two runs drift apart slowly
-    # (at the reference's full rates the separation reaches 1e-4 between the fourth and the sixth step: two builds of the loss kernels whose
-    # gradients differ in the last bit only (3e-7 of the largest element, profiles/r03w_loss_lds_alias_ab.log) land below 1e-4 and at 1.3e-4 at
-    # the sixth step; both are within 1.5e-5 over the first four)
-    n_first = 6 if lr_scale < 1.0 else 4
-    np.testing.assert_allclose(h_loss[:n_first], o_loss[:n_first], rtol=1e-4)
+    # step by step: the first six steps agree to 1e-4 at both sets of rates; later Adam's normalised update (|step| = lr whatever the gradient's
+    # size) turns last-bit differences of near-zero gradients into lr-sized differences of single parameters and the two runs drift apart slowly.
+    # The loss kernels carry the reference's bits (csrc/ssim.hip is compiled with -ffp-contract=off; test_vs_reference_kernels_gpu.py holds them
+    # to the reference kernels bit for bit), so what separates the runs is the oracle's host-libm exp in the blend, not instruction scheduling.
+    np.testing.assert_allclose(h_loss[:6], o_loss[:6], rtol=1e-4)
     np.testing.assert_allclose(h_loss, o_loss, rtol=5e-3)
     p_h, p_o = _psnr(h_img, gtn), _psnr(o_img, gtn)
     assert abs(p_h - p_o) < 0.05, (p_h, p_o)                                 # final PSNR-to-GT within 0.05 dB

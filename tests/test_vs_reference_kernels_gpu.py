@@ -76,10 +76,11 @@ def _check_against_reference(rk, kind, P, W, H, deg, seed, fast):
     assert np.abs(g["dL_drot"] - ref["dL_drot"]).max() / scale < TOL
 
 
-@pytest.mark.parametrize("B,CH,H,W", [(1, 3, 50, 70), (2, 3, 270, 480)])
+@pytest.mark.parametrize("B,CH,H,W", [(1, 3, 50, 70), (2, 3, 270, 480), (1, 3, 33, 17), (1, 1, 64, 96)])
 def test_hip_ssim_matches_reference_kernels(B, CH, H, W):
-    """fused-SSIM forward / backward of the HIP path against the reference's own kernels on the same MI355X, and against the
-    committed golden vectors (tests/golden/ssim_*.npz) where the shape has one."""
+    """fused-SSIM forward / backward of the HIP path against the reference's own kernels (ssim.cu:186-365) on the same MI355X: BIT FOR BIT.
+    csrc/ssim.hip is compiled with -ffp-contract=off like the checker, every tap is a separately rounded product and sum in the reference's
+    order, so the four maps and the gradient carry the reference's bits whatever the compiler schedules."""
     import torch
     from gaussian_lic_amd import loss
     rk = _ref()
@@ -92,22 +93,52 @@ def test_hip_ssim_matches_reference_kernels(B, CH, H, W):
     ta, tb, tdl = (torch.from_numpy(x).to("cuda:0") for x in (a, b, dL))
     m, d1, d2, d3 = loss.fusedssim(0.01 ** 2, 0.03 ** 2, ta, tb, True)
     for got, ref in ((m, rm), (d1, r1), (d2, r2), (d3, r3)):
-        assert rel_err(got.cpu().numpy(), ref) < 1e-4   # (measured 1.5e-5: ssim.hip is compiled with fma contraction, the checker without)
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
     g = loss.fusedssim_backward(0.01 ** 2, 0.03 ** 2, ta, tb, tdl, d1, d2, d3)
-    assert rel_err(g.cpu().numpy(), rg) < 1e-4
+    np.testing.assert_array_equal(g.cpu().numpy(), rg)
+    # inference mode (train = false: empty derivative tensors, ssim.cu:381-388): the same map
+    m2 = loss.fusedssim(0.01 ** 2, 0.03 ** 2, ta, tb, False)[0]
+    np.testing.assert_array_equal(m2.cpu().numpy(), rm)
 
 
-def test_hip_ssim_matches_golden():
+@pytest.mark.parametrize("name", ["ssim_1x3x70x50", "ssim_2x3x96x64"])
+def test_hip_ssim_matches_golden(name):
+    """... and against the committed vectors the reference's kernels produced (tests/golden/ssim_*.npz): bit for bit."""
     import os
     import torch
     from gaussian_lic_amd import loss
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ssim_1x3x70x50.npz"))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
     ta, tb, tdl = (torch.from_numpy(z[k]).to("cuda:0") for k in ("img1", "img2", "dL_dmap"))
     m, d1, d2, d3 = loss.fusedssim(0.01 ** 2, 0.03 ** 2, ta, tb, True)
     for got, key in ((m, "ssim_map"), (d1, "dm_dmu1"), (d2, "dm_dsigma1_sq"), (d3, "dm_dsigma12")):
-        assert rel_err(got.cpu().numpy(), z[key]) < 1e-4
+        np.testing.assert_array_equal(got.cpu().numpy(), z[key])
     g = loss.fusedssim_backward(0.01 ** 2, 0.03 ** 2, ta, tb, tdl, d1, d2, d3)
-    assert rel_err(g.cpu().numpy(), z["dL_dimg1"]) < 1e-4
+    np.testing.assert_array_equal(g.cpu().numpy(), z["dL_dimg1"])
+
+
+@pytest.mark.parametrize("H,W", [(50, 70), (270, 480), (1080, 1920)])
+def test_fused_loss_gradient_is_the_reference_chain_bit_for_bit(H, W):
+    """gslic_l1_ssim_loss_forward/_backward (L1 folded into the SSIM passes) against the chain the reference's host runs
+    (gaussian.cpp:685-691 -> loss_utils.h:30-33,130-193): dL/dimage = (1 - lambda)/N sign(image - gt) + fusedssim_backward(dL_dmap = -lambda/N)
+    with the reference's kernels: the same bits (the fused kernel multiplies the derivative maps by dL_dmap where the reference does)."""
+    import torch
+    from gaussian_lic_amd import loss
+    rk = _ref()
+    rng = np.random.default_rng(11)
+    a = rng.random((1, 3, H, W)).astype(np.float32)
+    b = np.clip(a + 0.1 * rng.standard_normal((1, 3, H, W)), 0.0, 1.0).astype(np.float32)
+    a[0, :, :4, :6] = b[0, :, :4, :6]                      # a patch where image == target: sign(0) = 0
+    n = float(a.size)
+    lam = 0.2
+    rm, r1, r2, r3 = rk.ssim_forward(a, b)
+    f32 = np.float32   # the two upstream scalars in fp32 arithmetic, as LibTorch's mean / mul backward form them: (1 - lambda) / N and -lambda / N
+    w_l1, w_ssim = (f32(1.0) - f32(lam)) / f32(n), -f32(lam) / f32(n)
+    ref = w_l1 * np.sign(a - b).astype(np.float32) + rk.ssim_backward(a, b, np.full_like(a, w_ssim), r1, r2, r3)
+    fl = loss.FusedLoss(lam)
+    dL, terms = fl.forward_backward(torch.from_numpy(a[0]).to("cuda:0"), torch.from_numpy(b[0]).to("cuda:0"))
+    np.testing.assert_array_equal(dL.cpu().numpy(), ref[0])
+    t = terms.cpu().numpy()
+    assert abs(float(t[0]) - float(np.abs(a - b).mean())) < 1e-6 and abs(float(t[1]) - float(rm.mean(dtype=np.float64))) < 1e-6
 
 
 @pytest.mark.parametrize("P,seed", [(100096, 31), (1500, 32), (5, 34)])
