@@ -24,6 +24,7 @@ SOURCES = {
     "radix_sort.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],
     "render.hip": ["-fno-slp-vectorize"],
+    "render_bwd_scan.hip": ["-fno-slp-vectorize"],
     "preprocess_bwd.hip": [],
     "adam.hip": [],
     "ssim.hip": ["-ffp-contract=off"],    # the maps are held bit-exact to the reference kernels under the same flag (tests/golden/ssim_*.npz)

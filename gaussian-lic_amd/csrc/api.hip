@@ -561,6 +561,11 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
         if (adam->param[0] != means3D || adam->param[4] != scales || adam->param[5] != rotations || (prm->M > 0 && adam->param[2] != shs))
             return set_error(GSLIC_ERR_INVALID_ARG, "fused Adam: param[] must alias the tensors passed as means3D / shs / scales / rotations");
     }
+    {   // (checked before anything is enqueued: a bad row range must not leave a blend backward behind)
+        const int re = row_end < 0 ? P : row_end;
+        if (row_begin < 0 || re > P || row_begin > re || (row_begin & 63))
+            return set_error(GSLIC_ERR_INVALID_ARG, "row range [%d, %d) of %d Gaussians (row_begin must be a multiple of 64)", row_begin, re, P);
+    }
     hipStream_t s = (hipStream_t)stream;
     int gx, gy;
     const int T = tile_grid(prm->width, prm->height, gx, gy);
@@ -580,8 +585,6 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
     PreprocessBwdArgs pb;
     pb.P = P; pb.D = prm->D; pb.M = prm->M; pb.W = prm->width; pb.H = prm->height; pb.raw = prm->raw_params;
     pb.row_begin = row_begin; pb.row_end = row_end < 0 ? P : row_end;
-    if (pb.row_begin < 0 || pb.row_end > P || pb.row_begin > pb.row_end || (pb.row_begin & 63))
-        return set_error(GSLIC_ERR_INVALID_ARG, "row range [%d, %d) of %d Gaussians (row_begin must be a multiple of 64)", pb.row_begin, pb.row_end, P);
     pb.focal_y = prm->height / (2.0f * prm->tan_fovy);
     pb.focal_x = prm->width / (2.0f * prm->tan_fovx);
     pb.limx_neg = prm->limx_neg; pb.limx_pos = prm->limx_pos; pb.limy_neg = prm->limy_neg; pb.limy_pos = prm->limy_pos;

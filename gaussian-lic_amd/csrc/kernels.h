@@ -72,8 +72,10 @@ struct RenderBwdArgs {
     const uint32_t* status;    // device status words: a non-zero [2] (capacity overflow in the forward) aborts the kernel
     int T;                     // tiles: bucket_offsets[T - 1] is the real bucket count (B may be a capacity)
     int xcd_lg;                // log2 of the run of consecutive buckets one XCD takes (launch_render_bwd); < 0: bucket = blockIdx.x
+    int skip_if_bits;          // pipeline kernel only: leave when the forward recorded decision masks (the row-scan kernel has done the work)
 };
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
+int launch_render_bwd_scan(const RenderBwdArgs& b, unsigned grid, hipStream_t s);   // render_bwd_scan.hip: strict arithmetic, needs SampleState::hit
 
 struct AdamFusedArgs {
     float *p[6], *m[6], *v[6];  // xyz, features_dc, features_rest, opacity, scaling, rotation

@@ -18,6 +18,7 @@
 #include "gslic_common.h"
 #include "kernels.h"
 #include <stdlib.h>
+#include <mutex>
 
 namespace gslic {
 
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     }
     if (a.status[2] != 0u || bucket >= a.bucket_offsets[a.T - 1]) return;  // capacity overflow in the forward / B was a capacity
     const bool use_bits = BITS && a.status[GS_FLAG_HITBITS] != 0u;         // (wave-uniform) the forward recorded its blend decisions
+    if (a.skip_if_bits && use_bits) return;                                // ... and render_bwd_scan_kernel, launched in front of this one, used them
     const uint32_t tile = a.bucket_to_tile[bucket];
     const uint2 range = a.ranges[tile];
     const uint32_t n = range.y - range.x;
@@ -613,8 +615,30 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
     }
 }
 
+// Host-side note of which arithmetic the last forward into a sample buffer ran in (key: the address of its decision masks).  The device flag
+// status[GS_FLAG_HITBITS] stays the kernels' source of truth; the note only lets the strict backward skip the launch of its fallback kernel
+// when it is known that the masks exist (unknown buffer: both kernels are launched and one of them leaves at once).
+static std::mutex g_fwd_note_mu;
+static struct { const void* hit; bool strict; } g_fwd_note[64];
+static unsigned g_fwd_note_next = 0;
+static void note_forward(const void* hit, bool strict)
+{
+    std::lock_guard<std::mutex> lk(g_fwd_note_mu);
+    for (auto& e : g_fwd_note)
+        if (e.hit == hit) { e.strict = strict; return; }
+    g_fwd_note[g_fwd_note_next++ & 63u] = {hit, strict};
+}
+static bool forward_known_strict(const void* hit)
+{
+    std::lock_guard<std::mutex> lk(g_fwd_note_mu);
+    for (auto& e : g_fwd_note)
+        if (e.hit == hit) return e.strict;
+    return false;
+}
+
 int launch_render_fwd(const RenderFwdArgs& a, hipStream_t s)
 {
+    if (!a.no_color && a.hit) note_forward(a.hit, g_strict_math != 0);
     // waves per tile: two halve the serial chain of a tile's wave, at the price of both fetching the tile's records — which the XCD-aware
     // grid turns into an L2 hit.  Measured (profiles/r03h_fwd_split_ab.log): 1080p strict 0.364 (2 waves) vs 0.394 (4), fast 0.259 vs 0.291; 4K
     // (32 400 tiles) strict 1.22 (2) vs 1.29 (1), fast 0.865 vs 0.875.  GSLIC_FWD_SPLIT pins it.
@@ -641,10 +665,20 @@ int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s)
         for (int k = 0; k < 12; k++) if (v == (1 << k)) lg = k;
         return lg;
     }();
+    // GSLIC_BWD_SCAN = 0: the pipeline kernel in the strict mode too (A/B runs)
+    static const bool use_scan = [] { const char* e = getenv("GSLIC_BWD_SCAN"); return !(e && atoi(e) == 0); }();
     RenderBwdArgs b = a;
     b.xcd_lg = xcd_lg;
+    b.skip_if_bits = 0;
     unsigned grid = (unsigned)a.B;
     if (xcd_lg >= 0) { const unsigned unit = 8u << xcd_lg; grid = (grid + unit - 1u) / unit * unit; }
+    if (g_strict_math && use_scan) {
+        // the row-scan kernel works from the decision masks of a strict forward; when the forward recorded none (the mode was switched in
+        // between) every one of its workgroups leaves at once and the pipeline kernel behind it re-derives the decisions instead
+        launch_render_bwd_scan(b, grid, s);
+        if (forward_known_strict(a.hit)) return GSLIC_OK;
+        b.skip_if_bits = 1;
+    }
     if (g_strict_math) GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel<true>, dim3(grid), dim3(64), 0, s, b);
     else GS_LAUNCH(K_RENDER_BWD, render_bwd_kernel<false>, dim3(grid), dim3(64), 0, s, b);
     return GSLIC_OK;

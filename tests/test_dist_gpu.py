@@ -252,7 +252,7 @@ from gaussian_lic_amd.synthetic import random_scene, gt_image
 rank, world, task, out = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), os.environ["GSLIC_TEST_TASK"], os.environ["GSLIC_TEST_OUT"]
 nviews = int(os.environ.get("GSLIC_TEST_VIEWS", world))
 dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
-W, H, P = 320, 192, 30000
+W, H, P = (int(os.environ.get(k, d)) for k, d in (("GSLIC_TEST_W", 320), ("GSLIC_TEST_H", 192), ("GSLIC_TEST_P", 30000)))
 bg = torch.zeros(3, device=dev)
 model = trainer.GaussianModel(random_scene(P, W, H, 3, 5), dev); model.training_setup()
 def digest(m):
@@ -279,7 +279,7 @@ else:
         _, v = trainer.training_step_fused(model, cam, gt, bg)
         torch.cuda.synchronize()
         if rank == 0:
-            np.savez(out, flat=model._grad_slab.flat.double().cpu().numpy(), vis=v.cpu().numpy())
+            np.savez(out, flat=model._grad_slab.flat.cpu().numpy(), vis=v.cpu().numpy())
     else:                    # three complete steps
         for _ in range(3):
             trainer.training_step_fused(model, cam, gt, bg)
@@ -322,6 +322,36 @@ def test_n_ranks_exchanged_gradients_equal_the_sum_over_views(world, tmp_path):
             a, b = got["flat"][offs[g]:offs[g + 1]], ref["flat"][offs[g]:offs[g + 1]]
             scale = max(float(np.abs(b).max()), 1e-30)
             assert float(np.abs(a - b).max()) / scale < 1e-5, (mode, g, float(np.abs(a - b).max()) / scale)
+
+
+@pytest.mark.gpu
+def test_config4_full_size_eight_views_gradient_sum(tmp_path):
+    """BASELINE config 4 at its own size: 2 000 000 Gaussians, 1920x1080, eight views k = 0..7 (yaw (k - 3.5) 4 deg, x = (k - 3.5) 0.25 m),
+    one per rank — eight processes sharing the box's one GPU, gloo on device tensors.  The exchanged gradient slab equals sum_k grad(view k) of
+    the single-GPU path (1e-5 of each group's max-abs) and the mask equals OR_k visible_k exactly, for the rank-1 exchange (default: dRGB
+    all-gathered, SH rows rebuilt) and for the dense slab all-reduce."""
+    import numpy as np
+    size = {"GSLIC_TEST_W": "1920", "GSLIC_TEST_H": "1080", "GSLIC_TEST_P": "2000000"}
+    ref_file = str(tmp_path / "ref.npz")
+    _spawn_ranks(1, "reference", "dense", 29801, ref_file, dict(size, GSLIC_TEST_VIEWS="8"))
+    ref = np.load(ref_file)
+    rflat, rvis = ref["flat"], ref["vis"]
+    offs = np.concatenate([[0], np.cumsum(ref["sizes"])])
+    assert int(rvis.sum()) > 1_000_000 and rflat.size == 59 * 2_000_000
+    for mode, port in (("rank1", 29811), ("dense", 29821)):
+        got_file = str(tmp_path / f"got_{mode}.npz")
+        _spawn_ranks(8, "grads", mode, port, got_file, dict(size, GSLIC_RANK1_SPLIT_ADAM="1"))
+        got = np.load(got_file)
+        np.testing.assert_array_equal(got["vis"], rvis, err_msg=f"{mode}: mask != OR of the eight views' masks")
+        gflat = got["flat"]
+        for g in range(6):
+            a, b = gflat[offs[g]:offs[g + 1]], rflat[offs[g]:offs[g + 1]]
+            scale = max(float(np.abs(b).max()), 1e-30)
+            err = float(np.abs(a - b).max()) / scale
+            print(f"config 4 full size, {mode}, group {g}: max |exchanged - sum of views| / max-abs = {err:.2e}")
+            assert err < 1e-5, (mode, g, err)
+        del got, gflat
+        os.remove(got_file)
 
 
 @pytest.mark.gpu

@@ -46,7 +46,7 @@ Lb = np.nonzero(live)[0]
 print(f"scene sigma x{density:g} logit opacity {oshift:+g}: P={P} R={f['R']} B={B} live buckets {Lb.size}")
 ncb = tiles[b2t[Lb]]                                   # [Bl, 256]
 rel_cur = np.clip(ncb - bstart[Lb, None], 0, 64)
-m = hit[Lb]
+m = np.where(rel_cur > 0, hit[Lb], np.uint64(0))   # (a forward wave stops writing masks once its pixels are finished: beyond n_contrib they are stale)
 # highest set bit + 1 (0 for an empty mask), popcount
 hi = (m >> np.uint64(32)).astype(np.uint32); lo = (m & np.uint64(0xffffffff)).astype(np.uint32)
 def top32(x):
@@ -120,3 +120,16 @@ for name, sub in blocks.items():
         st = (-(-nSb // G)) * (-(-npx // rows))
         print(f"row-scan, blocks = {name}, {G} entries x {rows} pixels per step: {tot(st):.2f}M steps = {st.sum() / Lb.size:.0f} per live bucket "
               f"({100 * st.sum() / s_cur.sum():.1f}% of the pipeline's steps); entries per block {nSb.mean():.1f}, group passes per bucket {(-(-nSb // G)).sum() / Lb.size:.1f}")
+# ---- per-bucket choice between the two kernels (cycle model: pipeline 110 cycles per step; row scan 150 per step + ~250 per quadrant pass + 300 fixed)
+nS16 = -(-nS // 16); nq4 = -(-nq // 4)
+rs_cycles = (nS16 * nq4).sum(1) * 150 + nS16.sum(1) * 120 + (nq > 0).sum(1) * 130 + 300
+pl_cycles = s_cur * 110 + 400
+best = np.minimum(rs_cycles, pl_cycles)
+print(f"cycle model per live bucket: pipeline {pl_cycles.mean():.0f}, row scan {rs_cycles.mean():.0f}, per-bucket minimum {best.mean():.0f} "
+      f"({100 * best.sum() / pl_cycles.sum():.1f}% of the pipeline; row scan wins in {100 * (rs_cycles < pl_cycles).mean():.1f}% of the buckets)")
+kb = (bstart[Lb] // 64)
+for k in range(0, 8):
+    sel = kb == k
+    if sel.any():
+        print(f"  bucket {k} of its tile: {int(sel.sum())} live buckets, pipeline {pl_cycles[sel].mean():.0f}, row scan {rs_cycles[sel].mean():.0f}, row scan wins in {100 * (rs_cycles[sel] < pl_cycles[sel]).mean():.0f}%, "
+              f"injected {inj_cur[sel].mean():.0f}, entries per quadrant {nS[sel].mean():.1f}")

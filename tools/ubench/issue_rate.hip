@@ -22,6 +22,13 @@ __global__ __launch_bounds__(256) void k(float* out, float a, float b)
         else if (MODE == 11) asm volatile(REP8("v_fma_f32 v8, v8, v16, v17\n v_fma_f32 v9, v9, v16, v17\n v_fma_f32 v10, v10, v16, v17\n v_fma_f32 v11, v11, v16, v17\n") ::: "v8", "v9", "v10", "v11");  // every instruction reads the SAME two multiplicand registers (what round 1's valu_rate did)
         else if (MODE == 12) asm volatile(REP8("v_fma_f32 v8, v8, v16, v17\n v_fma_f32 v9, v9, v18, v19\n v_fma_f32 v10, v10, v16, v17\n v_fma_f32 v11, v11, v18, v19\n") ::: "v8", "v9", "v10", "v11");  // alternating operand pairs
         else if (MODE == 10) asm volatile(REP8("v_mov_b32_dpp v8, v17 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v9, v18 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v10, v19 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v11, v16 wave_shr:1 row_mask:0xf bank_mask:0xf\n") ::: "v8", "v9", "v10", "v11");
+        else if (MODE == 13) asm volatile(REP8("v_mul_f32_dpp v8, v17, v8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mul_f32_dpp v9, v18, v9 row_shr:2 row_mask:0xf bank_mask:0xf\n v_mul_f32_dpp v10, v19, v10 row_shr:4 row_mask:0xf bank_mask:0xf\n v_mul_f32_dpp v11, v16, v11 row_shr:8 row_mask:0xf bank_mask:0xf\n") ::: "v8", "v9", "v10", "v11");
+        else if (MODE == 14) asm volatile(REP8("v_mov_b32_dpp v8, v17 row_newbcast:15 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v9, v18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v10, v19 row_newbcast:15 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v11, v16 row_newbcast:15 row_mask:0xf bank_mask:0xf\n") ::: "v8", "v9", "v10", "v11");
+        else if (MODE == 15) asm volatile(REP8("v_fma_mix_f32 v8, v17, v18, v8 op_sel_hi:[1,0,0]\n v_fma_mix_f32 v9, v18, v19, v9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 v10, v19, v16, v10 op_sel_hi:[1,0,0]\n v_fma_mix_f32 v11, v16, v17, v11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n") ::: "v8", "v9", "v10", "v11");
+        else if (MODE == 16) asm volatile(REP8("v_permlane32_swap_b32 v8, v9\n v_permlane16_swap_b32 v10, v11\n v_permlane32_swap_b32 v9, v10\n v_permlane16_swap_b32 v11, v8\n") ::: "v8", "v9", "v10", "v11");
+        else if (MODE == 17) asm volatile(REP8("v_rcp_f32 v8, v8\n v_rcp_f32 v9, v9\n v_rcp_f32 v10, v10\n v_rcp_f32 v11, v11\n") ::: "v8", "v9", "v10", "v11");
+        else if (MODE == 18) asm volatile(REP8("s_nop 1\n v_mul_f32_dpp v8, v8, v8 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_mul_f32_dpp v8, v8, v8 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_mul_f32_dpp v8, v8, v8 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_mul_f32_dpp v8, v8, v8 row_shr:8 row_mask:0xf bank_mask:0xf\n") ::: "v8");   // a 16-lane scan: each step depends on the last
+        else if (MODE == 19) asm volatile(REP8("v_bfe_i32 v8, v17, v18, 1\n v_bfi_b32 v9, v18, v19, v16\n v_and_b32 v10, v19, v16\n v_med3_f32 v11, v16, v17, v18\n") ::: "v8", "v9", "v10", "v11");
     }
     float r;
     asm volatile("v_add_f32 %0, v8, v9" : "=v"(r));
@@ -56,6 +63,13 @@ int main()
         run<10>("v_mov_b32_dpp wave_shr:1", d, w);
         run<11>("v_fma_f32, same two source registers in every instruction", d, w);
         run<12>("v_fma_f32, two alternating source pairs", d, w);
+        run<13>("v_mul_f32_dpp row_shr:1/2/4/8", d, w);
+        run<14>("v_mov_b32_dpp row_newbcast:15", d, w);
+        run<15>("v_fma_mix_f32 (f16 lo / hi source)", d, w);
+        run<16>("v_permlane32_swap / v_permlane16_swap", d, w);
+        run<17>("v_rcp_f32", d, w);
+        run<18>("dependent v_mul_f32_dpp row_shr chain + s_nop 1", d, w);
+        run<19>("v_bfe_i32 / v_bfi_b32 / v_and_b32 / v_med3_f32", d, w);
     }
     return 0;
 }
