@@ -61,8 +61,36 @@ def algorithmic_bytes(kernel, s):
         "adam": 28 * (11 + 3 * K - 3) * V + (11 + 3 * K - 3) * P,
         "ssim_fwd": 24 * N + 48 * N,
         "ssim_bwd": 72 * N + 12 * N,
+        # ---- the N > 1 compute leg (rank-1 exchange); nv = views whose colour gradients a rank rebuilds from, Vu = rows some view sees
+        # per Gaussian: nv x 12 B dRGB + 12 B mean + 1 B mask in; per row some view sees: features_dc + features_rest (48 scalars) param / m / v read and written
+        "sh_grad_from_rgb": P * (12 * s.get("nv", 1) + 13) + s.get("Vu", V) * 24 * 3 * K,
+        # Adam on the four small groups (xyz, opacity, scaling, rotation: 11 scalars) of the rows some view sees, mask byte per scalar-thread
+        "adam_small": 28 * 11 * s.get("Vu", V) + 11 * P,
     }
     return float(table.get(kernel, 0))
+
+
+def a_view_bytes(s):
+    """SURVEY.md section 8d's algorithmic bytes of ONE view (forward + backward + Adam + loss), evaluated at this run's unit counts.  The SURVEY's
+    bucket is the reference's 32-entry one (B32 = sum over tiles of ceil(n_t / 32)); each logical array is counted once per stage that must touch
+    it, the sort as one read + one write.  roofline.step divides it by ms_per_step: the whole step's fraction of the 8 TB/s HBM peak."""
+    P, V, R, N, T, K, B32 = s["P"], s["V"], s["R"], s["N"], s["T"], s["K"], s.get("B32", 2 * s["B"])
+    a_fwd = 52 * P + V * (12 * K + 67) + 8 * P + 36 * V + 12 * R + 24 * R + 8 * R + 24 * T + 40 * R + 4096 * B32 + 20 * N
+    a_bwd = 4096 * B32 + 40 * R + 28 * N + 72 * R + 4 * P + V * (12 * K + 103) + V * (12 * K + 40)
+    a_adam = 28 * (11 + 3 * K) * V + (11 + 3 * K) * P
+    a_loss = 72 * N + 84 * N + 60 * N
+    return {"A_fwd": float(a_fwd), "A_bwd": float(a_bwd), "A_adam": float(a_adam), "A_loss": float(a_loss), "A_view": float(a_fwd + a_bwd + a_adam + a_loss)}
+
+
+# Modelled VALU issue cost of the blend kernels' instruction mix: (instructions of each class in the kernel's inner loop, from the ISA) x (cycles a
+# wave64 instruction of that class occupies a SIMD's issue port, tools/ubench/issue_rate on gfx950: 2.3 plain VGPR operands, 4.1-4.2 DPP / packed /
+# SGPR operand / v_bfe / v_bfi, 8.0 v_exp / v_rcp), averaged.  roofline.frac of a VALU-bound kernel = instructions issued x this / SIMD cycles.
+VALU_CYCLES_PER_INST = {
+    "render_bwd": 3.25,       # row-scan kernel (render_bwd_scan.hip): 43.5 per step = 10 DPP + 4 packed + 2 transcendental + 2 bfe / bfi + 25.5 plain
+    "render_bwd_pipeline": 3.05,   # pipeline kernel (render.hip): 36 per step = 2 DPP + 7 packed + 2 transcendental + 2 bfe / bfi + 23 plain
+    "render_fwd": 2.7,        # strict body: 36 per (entry, quadrant) = 1 transcendental + 3 SGPR-operand + 32 plain (+ SALU, not counted)
+}
+SHADER_CLOCK_GHZ = 2.0        # what the part sustains under this workload (DESIGN.md section 6; 2.4 nominal)
 
 
 def main():
@@ -95,6 +123,9 @@ def main():
                                                                    "i.e. the blend kernels walk further down their lists")
     ap.add_argument("--math", default="default", choices=["default", "strict", "fast"],
                     help="arithmetic of the blend kernels for the timed region: default = the library's (strict unless GSLIC_FAST_MATH=1)")
+    ap.add_argument("--views", type=int, default=16, help="views of the `views_cycle` leg: K synthetic cameras (yaw / translation rig of SURVEY 8d continued) with K "
+                                                             "different targets, visited in a shuffled order, every step's target uploaded from pinned host memory on a "
+                                                             "side stream while the previous step runs — the reference's optimize() pattern (gaussian.cpp:645-678); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements of the default run (other host path, graphed step, growth schedule)")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every kernel inside the timed region (adds overhead)")
@@ -244,6 +275,17 @@ def main():
                                        "Gaussians in a one-rank group, where the collectives are copies",
                         "exposed_fraction_upper_bound": round(tail / max(comp + tail, 1e-9), 4), "bytes_sent_per_rank_per_step": None if sent is None else int(sent),
                         "world": n}
+    timed_all = None
+    if dist_on and not args.profile_all:
+        # the N > 1 compute leg gets a per-kernel roofline of its own (sh_grad_from_rgb, the split Adam, preprocess_bwd without Adam): a short
+        # fully instrumented pass AFTER the timed region
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        for _ in range(min(10, args.steps)):
+            step()
+        sync_all()
+        timed_all = _lib.profile_collect()
+        _lib.profile_enable(False)
     if graphed["gs"] is not None:
         assert graphed["gs"].check() == 0, "a timed step did not fit its capacity buffers"
         graphed["gs"] = None
@@ -251,6 +293,42 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(dt.item())
+
+    # ---- unit counts of this workload (one extra forward, untimed), taken RIGHT AFTER the timed steps: the secondary legs below train the map
+    # further, and the counts (live instances above all) drift with it — the roofline and the replayed counters must describe the timed region
+    with torch.no_grad():
+        from gaussian_lic_amd.rasterizer import render
+        image, _, _, visible, radii = render(cam, model, bg)
+    torch.cuda.synchronize()
+    # R and B of the last forward are returned by the C-ABI; re-run through the functional API to read them
+    from gaussian_lic_amd import rasterizer as rz
+    rs = rz.GaussianRasterizationSettings(H, W, float(cam.tanfovx), float(cam.tanfovy), float(cam.limx_neg), float(cam.limx_pos),
+                                          float(cam.limy_neg), float(cam.limy_pos), bg, 1.0, cam.d_world_view_transform,
+                                          cam.d_full_proj_transform, 3, cam.d_camera_center)
+    with torch.no_grad():
+        e = torch.empty(0, device=dev)
+        Rn, Bn = rz.rasterize_gaussians(bg, model.get_xyz(), e, model.get_opacity(), model.get_scaling(), model.get_rotation(), 1.0, e,
+                                        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, rs.limx_neg, rs.limx_pos,
+                                        rs.limy_neg, rs.limy_pos, model.get_features_dc(), model.get_features_rest(), 3, rs.campos,
+                                        False, False, False)[:2]
+    P = model.P
+    stats = dict(P=P, V=int(visible.sum().item()), R=int(Rn), B=int(Bn), N=W * H, T=((W + 15) // 16) * ((H + 15) // 16), K=16, strict=strict_mode,
+                 nv=world, Vu=int(vis.sum().item()) if (vis is not None and torch.is_tensor(vis)) else int(visible.sum().item()))   # (N > 1: `vis` of the last step is the OR over the views)
+    try:   # instances / buckets in front of their tile's last contributor: what the blend kernels really process
+        with torch.no_grad():
+            fwd = rz.rasterize_gaussians(bg, model.get_xyz(), e, model.get_opacity(), model.get_scaling(), model.get_rotation(), 1.0, e,
+                                         rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, rs.limx_neg, rs.limx_pos,
+                                         rs.limy_neg, rs.limy_pos, model.get_features_dc(), model.get_features_rest(), 3, rs.campos, False, False, False)
+            dbg = rz.debug_export(rs, P, 15, fwd[0], fwd[1], fwd[5], fwd[6], fwd[7], fwd[8], what=("ranges", "max_contrib"))
+        n_t = (dbg["ranges"][:, 1] - dbg["ranges"][:, 0]).long()
+        live_b = (dbg["max_contrib"].long() + 63) // 64
+        stats["B32"] = int(((n_t + 31) // 32).sum().item())   # the reference's 32-entry buckets (SURVEY 8d's B)
+        stats["B_live"] = int(live_b.sum().item())
+        stats["R_live"] = int(torch.minimum(n_t, 64 * live_b).sum().item())
+        del fwd, dbg
+    except Exception:
+        pass
+
 
     # ---- the same K steps through the other host path (reported next to `value`, not part of it)
     def timed_loop(fn, n):
@@ -274,7 +352,12 @@ def main():
         value_long = {"value": round(n_long * world / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_long, 3), "steps": n_long,
                       "seconds": round(sec, 3)}
 
-    other, graphed_res, growth, cpp_host, math_legs = None, None, None, None, None
+    other, graphed_res, growth, cpp_host, math_legs, cycle = None, None, None, None, None, None
+    if args.mode == "train" and args.host == "fused" and args.views > 1 and world == 1 and not trainer._dist_on() and not args.graph and (not args.no_extras or "--views" in sys.argv):
+        try:
+            cycle = views_cycle(args, model, bg, dev, args.views, min(args.steps, 200))
+        except Exception as ex:   # a secondary leg must never take the line down
+            cycle = {"error": str(ex)[:300]}
     n_extra = min(args.steps, 200)
     if args.mode == "train" and not args.no_extras and not args.graph and world == 1 and not trainer._dist_on():
         # the two arithmetic modes of the blend kernels, same workload: throughput, and what the fast mode moves element for element
@@ -310,38 +393,6 @@ def main():
             torch.cuda.empty_cache()
             growth = growth_schedule(args, dev)
 
-    # ---- unit counts of this workload (one extra forward, untimed)
-    with torch.no_grad():
-        from gaussian_lic_amd.rasterizer import render
-        image, _, _, visible, radii = render(cam, model, bg)
-    torch.cuda.synchronize()
-    # R and B of the last forward are returned by the C-ABI; re-run through the functional API to read them
-    from gaussian_lic_amd import rasterizer as rz
-    rs = rz.GaussianRasterizationSettings(H, W, float(cam.tanfovx), float(cam.tanfovy), float(cam.limx_neg), float(cam.limx_pos),
-                                          float(cam.limy_neg), float(cam.limy_pos), bg, 1.0, cam.d_world_view_transform,
-                                          cam.d_full_proj_transform, 3, cam.d_camera_center)
-    with torch.no_grad():
-        e = torch.empty(0, device=dev)
-        Rn, Bn = rz.rasterize_gaussians(bg, model.get_xyz(), e, model.get_opacity(), model.get_scaling(), model.get_rotation(), 1.0, e,
-                                        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, rs.limx_neg, rs.limx_pos,
-                                        rs.limy_neg, rs.limy_pos, model.get_features_dc(), model.get_features_rest(), 3, rs.campos,
-                                        False, False, False)[:2]
-    P = model.P
-    stats = dict(P=P, V=int(visible.sum().item()), R=int(Rn), B=int(Bn), N=W * H, T=((W + 15) // 16) * ((H + 15) // 16), K=16, strict=strict_mode)
-    try:   # instances / buckets in front of their tile's last contributor: what the blend kernels really process
-        with torch.no_grad():
-            fwd = rz.rasterize_gaussians(bg, model.get_xyz(), e, model.get_opacity(), model.get_scaling(), model.get_rotation(), 1.0, e,
-                                         rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, rs.limx_neg, rs.limx_pos,
-                                         rs.limy_neg, rs.limy_pos, model.get_features_dc(), model.get_features_rest(), 3, rs.campos, False, False, False)
-            dbg = rz.debug_export(rs, P, 15, fwd[0], fwd[1], fwd[5], fwd[6], fwd[7], fwd[8], what=("ranges", "max_contrib"))
-        n_t = (dbg["ranges"][:, 1] - dbg["ranges"][:, 0]).long()
-        live_b = (dbg["max_contrib"].long() + 63) // 64
-        stats["B_live"] = int(live_b.sum().item())
-        stats["R_live"] = int(torch.minimum(n_t, 64 * live_b).sum().item())
-        del fwd, dbg
-    except Exception:
-        pass
-
     if rank != 0:
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
@@ -352,6 +403,8 @@ def main():
     avg_ms = dom_ms / max(dom_n, 1)
     fused_adam = args.mode in ("train", "slam") and args.host == "fused" and world == 1
     abytes = algorithmic_bytes("preprocess_bwd+adam" if (dominant == "preprocess_bwd" and fused_adam) else dominant, stats)
+    if dominant == "adam" and dist_on and trainer.exchange_mode() == "rank1":
+        abytes = algorithmic_bytes("adam_small", stats)   # rank-1 exchange: features_dc / features_rest are updated inside sh_grad_from_rgb
     if dominant == "adam" and dom_n > args.steps:
         abytes /= round(dom_n / args.steps)   # N > 1: the optimiser runs once per exchanged segment; the formula is per STEP, the time per launch
     achieved = abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -359,41 +412,61 @@ def main():
     # REPLAYED from the committed profile of the same workload and labelled with the file they come from; null when the workload differs.
     traffic, traffic_src, sq, sq_src = None, None, None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    pmc_workload_ok = False
+    pmc_units_ok = False
     if os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
-            pmc_workload_ok = pmc.get("workload") == f"{args.scene}-{P}-{W}x{H}"
-            for key in (f"{dominant}_kernel", dominant):
-                if pmc_workload_ok and key in pmc.get("kernels", {}):
+            # the counters are replayed only when they were collected on THIS workload: same scene, and the unit counts the kernels' work
+            # depends on (visible Gaussians, instances, live instances / buckets) within 2 % of this run's — otherwise traffic is null
+            pu = pmc.get("units") or {}
+            pmc_units_ok = (pmc.get("workload") == f"{args.scene}-{P}-{W}x{H}" and strict_mode == bool(pmc.get("strict", True)) and
+                            all(k in pu and stats.get(k) and abs(pu[k] - stats[k]) <= 0.02 * stats[k] for k in ("V", "R", "R_live", "B_live")))
+            scan_key = f"{dominant}_scan_kernel" if (strict_mode and os.environ.get("GSLIC_BWD_SCAN", "1") != "0") else None
+            for key in (scan_key, f"{dominant}_kernel", dominant):
+                if key and pmc_units_ok and key in pmc.get("kernels", {}) and traffic is None:
                     traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
-                    traffic_src = f"profiles/pmc_traffic.json@{pmc.get('tag', 'untagged')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated on a 1 GiB copy)"
+                    traffic_src = (f"profiles/pmc_traffic.json@{pmc.get('tag', 'untagged')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated on a "
+                                   f"1 GiB copy; collected at V={pu.get('V')} R={pu.get('R')} R_live={pu.get('R_live')} B_live={pu.get('B_live')})")
         except Exception:
             traffic = None
+    units_now = {k: stats.get(k) for k in ("P", "V", "R", "R_live", "B_live")}
     roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src, algorithmic_bytes_per_launch=abytes,
-                    avg_launch_ms=round(avg_ms, 4), launches_timed=int(dom_n), timing="HIP events around every launch of the kernel inside the timed region")
+                    avg_launch_ms=round(avg_ms, 4), launches_timed=int(dom_n), timing="HIP events around every launch of the kernel inside the timed region",
+                    units=units_now)
     if dominant in ("render_fwd", "render_bwd"):
-        # the blend kernels are VALU-bound, not HBM-bound.  Every bucket offers 256 x 64 (pixel, Gaussian) slots; the
-        # kernels skip finished pixels / unreachable strips, so this is an upper bound of the pairs evaluated (no FLOP claim is derived)
-        slots = 256.0 * 64.0 * stats["B"]
-        roofline["valu"] = dict(pair_slots_per_launch=slots, gslots_per_s=round(slots / (avg_ms * 1e-3) / 1e9, 2) if avg_ms > 0 else 0,
-                                note="VALU-issue bound, not HBM-bound: see DESIGN.md section 6 (issue cost per instruction class, tools/ubench/issue_rate)")
+        # The blend kernels are VALU-issue bound, not HBM-bound: `bound` says so, `frac` is the modelled issue cycles of
+        # the instructions the kernel executed over the SIMD cycles it had, and the HBM view stays beside it (hbm_frac, achieved, traffic).
+        roofline["bound"] = "valu"
+        roofline["hbm_frac"] = roofline["frac"]
+        roofline["frac"] = None
+        scan_on = strict_mode and os.environ.get("GSLIC_BWD_SCAN", "1") != "0"
+        cpi = VALU_CYCLES_PER_INST["render_bwd" if (dominant == "render_bwd" and scan_on) else ("render_bwd_pipeline" if dominant == "render_bwd" else "render_fwd")]
+        roofline["valu"] = dict(modelled_issue_cycles_per_inst=cpi, shader_clock_ghz=SHADER_CLOCK_GHZ, simds=1024,
+                                note="frac = VALU instructions per launch (rocprofv3 SQ_INSTS_VALU of the same workload) x modelled issue cycles per "
+                                     "instruction (instruction mix of the inner loop x tools/ubench/issue_rate) / (launch duration x 1024 SIMDs x clock)")
         try:
             import ast
             import glob
             sq_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.txt")))   # the newest tag sorts last
             for line in (open(sq_files[-1]) if sq_files else []):
-                name, _, rest = line.partition(" ")
-                if name.split("<")[0] in (f"{dominant}_kernel", dominant) and pmc_workload_ok:
-                    c = ast.literal_eval(rest.strip())
+                name, _, rest = line.partition(" {")
+                if name.split("<")[0].strip() in (f"{dominant}_kernel", f"{dominant}_scan_kernel" if scan_on else "-") and pmc_units_ok:
+                    c = ast.literal_eval("{" + rest.strip())
                     insts = c["SQ_INSTS_VALU"] * 32.0   # the extract averages per shader engine; 32 engines
+                    cycles = 1024.0 * avg_ms * 1e-3 * SHADER_CLOCK_GHZ * 1e9
                     roofline["valu"].update(valu_insts_per_launch=insts, counters_source="profiles/" + os.path.basename(sq_files[-1]),
-                                            simd_cycles_per_valu_inst=round(1024.0 * avg_ms * 1e-3 * 2.4e9 / insts, 2) if insts else None,
-                                            simd_cycles_note="launch duration x 1024 SIMDs x 2.4 GHz (nominal) / VALU instructions; a wave64 VALU instruction "
-                                                             "issues every 2.1-2.4 cycles (VGPR operands), 4.2 (SGPR / literal operand, DPP, packed), 8 (exp, rcp)")
+                                            simd_cycles_per_valu_inst=round(cycles / insts, 2) if insts else None)
+                    roofline["frac"] = round(insts * cpi / cycles, 4) if cycles else None
         except Exception:
             pass
+    # the whole step against the HBM peak on SURVEY 8d's A_view (the survey's figure of merit): algorithmic bytes of one view / ms_per_step
+    av = a_view_bytes(stats)
+    step_ms = 1e3 * elapsed / args.steps
+    roofline["step"] = dict(algorithmic_bytes=av["A_view"], parts={k: v for k, v in av.items() if k != "A_view"},
+                            achieved_TBps=round(av["A_view"] * world / (step_ms * 1e-3) / 1e12, 3) if step_ms > 0 else None,
+                            frac=round(av["A_view"] * world / (step_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4) if step_ms > 0 else None,
+                            note="SURVEY.md 8d A_view at this run's P, V, R, B32, N, T (per view; N > 1: per GPU) / ms_per_step / 8 TB/s")
 
     # ---- CPU baseline: the oracle (C port of the reference kernels, OpenMP) on a 1/16-scale sample of the same workload
     cpu = None
@@ -438,6 +511,7 @@ def main():
         "cpu_baseline": cpu,
         "value_long": value_long,
         "exchange": exchange,
+        "views_cycle": cycle,
         "math_modes": math_legs,
         "other_host_path": other,
         "graphed": graphed_res,
@@ -449,20 +523,98 @@ def main():
         # sum exceed ms_per_step; used to pick the dominant kernel, not to price the step)
         "kernel_ms_per_step_instrumented": {k: round(v[0] / max(nprof, 1), 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
         "kernel_ms_per_launch_timed": None if not args.profile_all else {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(timed.items(), key=lambda kv: -kv[1][0])},
-        "kernel_roofline": None if not args.profile_all else kernel_table(timed, stats, fused_adam),
+        "kernel_roofline": (kernel_table(timed, stats, fused_adam, rank1=dist_on and trainer.exchange_mode() == "rank1") if args.profile_all else
+                            (kernel_table(timed_all, stats, False, rank1=trainer.exchange_mode() == "rank1") if timed_all else None)),
     }
     print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
-def kernel_table(timed, stats, fused_adam):
+def views_cycle(args, model, bg, dev, K, n):
+    """The reference's iteration pattern on one GPU (gaussian.cpp:640-719): up to 100 DIFFERENT views per keyframe visited in random order, the
+    ground-truth image of every iteration uploaded to the device (`.to(device)`, :678).  K synthetic cameras (the yaw / translation rig of SURVEY 8d,
+    continued past k = 7) with K different targets in pinned host memory; a seeded shuffle per epoch; the target of step i + 1 is copied into the
+    other of two device buffers on a side stream while step i runs.  Visible set, sort order and the blend kernels' branch pattern now change
+    from step to step.  Reports the throughput with the uploads overlapped, with the uploads serialised in front of every step, the measured
+    upload time, and the spread of the per-view unit counts."""
+    from gaussian_lic_amd import trainer
+    from gaussian_lic_amd.camera import synthetic_camera
+    from gaussian_lic_amd.synthetic import gt_image
+    W, H = args.width, args.height
+    cams = [synthetic_camera(W, H, k).to_device(dev) for k in range(K)]
+    host = torch.empty(K, 3, H, W).pin_memory()
+    for k in range(K):
+        host[k].copy_(gt_image(H, W, seed=2 + k))
+    rng = np.random.default_rng(7)
+    order = np.concatenate([rng.permutation(K) for _ in range((n + 8) // K + 2)])
+    bufs = [torch.empty(3, H, W, device=dev) for _ in range(2)]
+    side = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    up_done = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+    up_t = []
+
+    def upload(i, b, timed):
+        with torch.cuda.stream(side):
+            side.wait_event(consumed[b])                       # the step that read this buffer last has finished
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            bufs[b].copy_(host[int(order[i])], non_blocking=True)
+            e1.record(side)
+            up_done[b].record(side)
+            if timed:
+                up_t.append((e0, e1))
+
+    def run(steps, overlapped, timed):
+        for b in range(2):
+            consumed[b].record(main)
+        upload(0, 0, False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            b = i & 1
+            if overlapped:
+                upload(i + 1, b ^ 1, timed)                     # in flight while step i runs
+            main.wait_event(up_done[b])
+            trainer.training_step_fused(model, cams[int(order[i])], bufs[b], bg)
+            consumed[b].record(main)
+            if not overlapped:
+                upload(i + 1, b ^ 1, timed)
+                side.synchronize()                              # serialised: the host waits for the copy before it launches the next step
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(2 * K if 2 * K < 40 else 40, True, False)               # warm-up: every view once (allocator sizes, scratch buffers)
+    sec_o = run(n, True, True)
+    sec_s = run(n, False, False)
+    torch.cuda.synchronize()
+    up_ms = [a.elapsed_time(b) for a, b in up_t]
+    nbytes = 3 * H * W * 4
+    # unit counts per view: how much the workload moves from step to step
+    from gaussian_lic_amd.rasterizer import render
+    vs = []
+    with torch.no_grad():
+        for k in range(min(K, 8)):
+            vs.append(int(render(cams[k], model, bg)[3].sum().item()))
+    return {"views": K, "steps": n, "order": "seeded shuffle per epoch", "value": round(n / sec_o, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec_o / n, 3),
+            "target_upload": {"bytes_per_step": nbytes, "ms_per_upload": round(float(np.mean(up_ms)), 3) if up_ms else None,
+                              "GBps": round(nbytes / (float(np.mean(up_ms)) * 1e-3) / 1e9, 2) if up_ms else None,
+                              "how": "pinned host memory -> one of two device buffers, hipMemcpyAsync on a side stream, overlapped with the previous step"},
+            "uploads_serialised": {"value": round(n / sec_s, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec_s / n, 3),
+                                   "note": "the copy is waited for on the host before the next step is launched (what a plain .to(device) per iteration does)"},
+            "visible_per_view_first8": vs}
+
+
+def kernel_table(timed, stats, fused_adam, rank1=False):
     """Per-kernel roofline of a --profile-all run: average launch time (HIP events inside the timed region), algorithmic bytes per launch
     (DESIGN.md section 4 formulas x this run's unit counts), achieved GB/s and the fraction of the 8 TB/s HBM peak."""
     out = {}
     for k, (ms, n) in sorted(timed.items(), key=lambda kv: -kv[1][0]):
         avg = ms / max(n, 1)
-        ab = algorithmic_bytes("preprocess_bwd+adam" if (k == "preprocess_bwd" and fused_adam) else k, stats)
+        ab = algorithmic_bytes("preprocess_bwd+adam" if (k == "preprocess_bwd" and fused_adam) else ("adam_small" if (k == "adam" and rank1) else k), stats)
+        if k == "adam" and n > 0 and rank1:
+            ab /= max(1, round(n / max(1, timed.get("render_bwd", (0, n))[1])))   # launches per step
         gbs = ab / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
         out[k] = {"avg_launch_ms": round(avg, 4), "launches": int(n), "algorithmic_bytes": ab, "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
     return out
@@ -546,9 +698,11 @@ def growth_schedule(args, dev):
     from gaussian_lic_amd.camera import synthetic_camera
     from gaussian_lic_amd.synthetic import gt_image, lidar_scene, random_scene
     W, H, P = args.width, args.height, args.gaussians
-    big = random_scene(int(P * 1.1), W, H, sh_degree=3, seed=0)
+    P_start, n_frame = (3 * P) // 4, P // 20                 # 1.5M -> 2.0M by five appends of 1e5 at the default size
+    big = random_scene(int(P * 1.25), W, H, sh_degree=3, seed=0)
     u_pix = big["xyz"][:, 0] * (0.675 * W) / big["xyz"][:, 2].abs().clamp_min(0.2) + 0.4857 * W
-    keep = torch.nonzero(u_pix < 0.7 * W).squeeze(1)[:int(0.75 * P)]
+    keep = torch.nonzero(u_pix < 0.7 * W).squeeze(1)[:P_start]
+    assert keep.numel() == P_start, "not enough Gaussians left of the uncovered strip"
     raw = {k: (v[keep].contiguous() if torch.is_tensor(v) else v) for k, v in big.items()}
     model = trainer.GaussianModel(raw, dev, capacity=int(1.05 * P))
     model.training_setup()
@@ -558,15 +712,30 @@ def growth_schedule(args, dev):
     Rcw = torch.from_numpy(cam.world_view_transform[:3, :3].T.copy())
     tcw = torch.from_numpy(cam.world_view_transform[3, :3].copy())
     intr = (float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy))
+    # LiDAR frames whose points ALL survive extend()'s filter, so that every append inserts exactly n_frame Gaussians: one return per pixel, on
+    # distinct pixels of the strip the map does not cover (u > 0.75 W: transmittance 1 there; later frames land on pixels earlier ones left free)
+    x_lo = int(0.75 * W) + 1
+    strip = (W - x_lo) * H
+    assert 5 * n_frame <= strip, "the uncovered strip has too few pixels for five frames of distinct pixels"
+    g = torch.Generator().manual_seed(200)
+    pix = torch.randperm(strip, generator=g)[:5 * n_frame]
     frames = []
-    for k in range(6):   # one warm-up frame + five timed ones; ~ P/20 of a frame's points fall on the uncovered part
-        f = lidar_scene(int(P / 6), W, H, sh_degree=3, seed=200 + k)
-        frames.append((f["xyz"].to(dev), (f["features_dc"].reshape(-1, 3) * 0.28209479177387814 + 0.5).to(dev), f["xyz"][:, 2].contiguous().to(dev)))
+    for k in (0, 0, 1, 2, 3, 4):   # the warm-up frame (its rows are dropped again, so it may share the first frame's pixels) + five timed ones
+        pk = pix[k * n_frame:(k + 1) * n_frame]
+        px_ = (x_lo + pk % (W - x_lo)).float() + 0.25
+        py_ = (pk // (W - x_lo)).float() + 0.25
+        z = torch.rand(n_frame, generator=g) * 38.0 + 2.0
+        xyz = torch.stack([(px_ - intr[2]) * z / intr[0], (py_ - intr[3]) * z / intr[1], z], 1).contiguous()
+        col = torch.rand(n_frame, 3, generator=g)
+        frames.append((xyz.to(dev), col.to(dev), z.contiguous().to(dev)))
     P0 = model.P
-    model.extend(cam, *frames[0], Rcw, tcw, intr)     # warm-up: one-off allocations of extend()
+    warm = model.extend(cam, *frames[0], Rcw, tcw, intr)     # warm-up: one-off allocations of extend(); its rows are dropped again
+    model.P = P0
+    model._rebind()
     for _ in range(3):
         trainer.training_step_fused(model, cam, gt, bg)
     torch.cuda.synchronize()
+    clocks0 = _gpu_clocks()
     P1, inserted, ext_ms = model.P, 0, 0.0
     from gaussian_lic_amd import _lib
     _lib.profile_reset()
@@ -587,11 +756,27 @@ def growth_schedule(args, dev):
     kms = _lib.profile_collect()
     _lib.profile_enable(False)
     return {"workload": f"SURVEY 8d config 3 schedule: {P1} -> {model.P} Gaussians by 5 extend() appends (every 20 iterations), 100 iterations, reference learning rates",
+            "warmup_frame_inserted_then_dropped": int(warm), "clocks_before": clocks0, "clocks_after": _gpu_clocks(),
             "value": round(100.0 / sec, 3), "unit": "views/s", "ms_per_iteration": round(10.0 * sec, 3), "iterations": 100, "appends": 5,
             "gaussians_start": P1, "gaussians_end": model.P, "inserted": inserted, "extend_ms_per_call": round(ext_ms / 5.0, 3),
             "gaussians_before_warmup_frame": P0,
             "kernel_ms_per_launch": {k: round(v[0] / max(v[1], 1), 4) for k, v in kms.items()},
             "ms_per_20_iterations": [round(b - a, 2) for a, b in zip(seg_ms[:-1], seg_ms[1:])]}
+
+
+def _gpu_clocks():
+    """Current shader / memory clock of GPU 0 as the driver reports them (sysfs; None when not readable): recorded around the growth leg,
+    whose rate was bimodal in round 3 with no counter to say why."""
+    out = {}
+    try:
+        import glob
+        for name in ("pp_dpm_sclk", "pp_dpm_mclk"):
+            for f in sorted(glob.glob(f"/sys/class/drm/card*/device/{name}"))[:1]:
+                cur = [l.split(":")[1].strip().rstrip("*").strip() for l in open(f).read().splitlines() if l.strip().endswith("*")]
+                out[name] = cur[0] if cur else None
+    except Exception:
+        return None
+    return out or None
 
 
 def _cpu_step(orc, sc, cam, gt, state, lrs):

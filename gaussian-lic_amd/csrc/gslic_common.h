@@ -58,6 +58,7 @@ enum KernelId {
     K_EXTEND,
     K_DSORT_HIST,
     K_DSORT_SCATTER,
+    K_SH_REBUILD,
     K_COUNT
 };
 void prof_begin(int id, hipStream_t s);

@@ -867,8 +867,8 @@ __global__ __launch_bounds__(64) void sh_grad_from_rgb_kernel(ShGradFromRgbArgs 
 int launch_sh_grad_from_rgb(const ShGradFromRgbArgs& a, hipStream_t s)
 {
     if (a.P <= 0) return GSLIC_OK;
-    if (a.adam.on) GS_LAUNCH(K_ADAM, sh_grad_from_rgb_kernel<true>, dim3(div_up(a.P, SGR)), dim3(64), 0, s, a);
-    else GS_LAUNCH(K_PREPROCESS_BWD, sh_grad_from_rgb_kernel<false>, dim3(div_up(a.P, SGR)), dim3(64), 0, s, a);
+    if (a.adam.on) GS_LAUNCH(K_SH_REBUILD, sh_grad_from_rgb_kernel<true>, dim3(div_up(a.P, SGR)), dim3(64), 0, s, a);
+    else GS_LAUNCH(K_SH_REBUILD, sh_grad_from_rgb_kernel<false>, dim3(div_up(a.P, SGR)), dim3(64), 0, s, a);
     return GSLIC_OK;
 }
 

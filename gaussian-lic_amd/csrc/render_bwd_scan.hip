@@ -98,6 +98,23 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 }
 #endif
 
+// OR over lanes 0..31 and over lanes 32..63 (wave-uniform results)
+__device__ __forceinline__ void half_or(uint32_t v, uint32_t& lo_half, uint32_t& hi_half)
+{
+#ifdef GS_SCAN_SAFE
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) v |= (uint32_t)__shfl_xor((int)v, d, 64);
+    lo_half = readlane_u(v, 0); hi_half = readlane_u(v, 32);
+#else
+    v |= dpp_u<0x111>(0u, v);
+    v |= dpp_u<0x112>(0u, v);
+    v |= dpp_u<0x114>(0u, v);
+    v |= dpp_u<0x118>(0u, v);            // lane 15 of each row: the row's OR
+    v |= dpp_u<0x142, 0xa>(0u, v);       // row_bcast15 into rows 1 and 3: lanes 31 and 63 hold their halves' ORs
+    lo_half = readlane_u(v, 31); hi_half = readlane_u(v, 63);
+#endif
+}
+
 struct ScanEntry {     // one list entry of the bucket, as the pipeline's BwdLane holds it
     float d0x, d0y;    // centre relative to the tile origin
     float hA, hC, nB;  // log2(e)-scaled conic: -1/2 A, -1/2 C, -B
@@ -105,22 +122,26 @@ struct ScanEntry {     // one list entry of the bucket, as the pipeline's BwdLan
     float cr, cg, cb;  // colour
 };
 
-constexpr int SC_NENT = 64 + 1;            // pixel records of a quadrant + the all-zero record
+constexpr int SC_HALF = 32 + 1;            // pixel records of a half quadrant (8x4 pixels) + its all-zero record
+constexpr int SC_NENT = 2 * SC_HALF;       // both halves of the quadrant being worked on
 constexpr int SC_ENT_F4 = 3;               // float4 per staged entry
 
 struct ScanLds {
     float4 ent[64 * SC_ENT_F4];       // the bucket's 64 entries (stride 12 floats)
     float acc[64 * 9];                // their nine sums, accumulated over the four quadrants
-    uint32_t list[64];                // compacted entry indices of the current quadrant
+    uint32_t list[2 * 64];            // compacted entry indices of the two half quadrants being worked on
     float2 ta[SC_NENT], rg[SC_NENT], bx[SC_NENT], py[SC_NENT];   // pixel records in compacted order: {T, A} {g.r, g.g} {g.b, px} {py, -}
     uint2 hm[SC_NENT];                // ... and the pixel's decision mask
 };
 
-// One quadrant's pixels (npx records in LDS) against its ne compacted entries in NG = ceil(ne / 16) groups: lane = (entry slot, pixel row).
-// A specialisation per group count: the chunk loop carries no per-group branch, and every group's entry and its nine sums stay in registers.
+// One block's pixels (npx records in LDS from index rb) against its ne compacted entries (S.list from lb) in NG = ceil(ne / 16) groups:
+// lane = (entry slot, pixel row).  A specialisation per group count: the chunk loop carries no per-group branch, and every group's entry and
+// its nine sums stay in registers.  The block is a HALF quadrant (8x4 pixels): its entry set is smaller than the quadrant's (23 against 28 of
+// 64 on the 2M / 1080p scene) and fills its groups of sixteen better — 16 % fewer steps than whole quadrants (tools/bwd_hitmask_model.py).
 template <int NG>
-__device__ __forceinline__ void quadrant_pass(ScanLds& S, const int lane, const int npx, const int ne, float c099)
+__device__ __forceinline__ void block_pass(ScanLds& S, const int lane, const int rb, const int lb, const int npx_, const int ne, float c099)
 {
+    const int npx = rb + npx_;
     const int slot_i = lane & 15, row = lane >> 4;
     ScanEntry E[NG];
     uint32_t ent[NG], kbit[NG], klo[NG];
@@ -134,14 +155,14 @@ __device__ __forceinline__ void quadrant_pass(ScanLds& S, const int lane, const 
         ent[g] = 0u; kbit[g] = 0u; klo[g] = 0u;
         const int k = 16 * g + slot_i;
         if (k < ne) {
-            const uint32_t e = S.list[k];
+            const uint32_t e = S.list[lb + k];
             const float4 e0 = S.ent[SC_ENT_F4 * e], e1 = S.ent[SC_ENT_F4 * e + 1], e2 = S.ent[SC_ENT_F4 * e + 2];
             E[g] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x};
             ent[g] = e; kbit[g] = e & 31u; klo[g] = e < 32u ? 0xffffffffu : 0u;
         }
     }
-    const int nchunk = (npx + 3) >> 2;
-    int off = row;   // record index of this row's pixel; clamped to the all-zero record npx
+    const int nchunk = (npx_ + 3) >> 2;
+    int off = rb + row;   // record index of this row's pixel; clamped to the block's all-zero record
     for (int c = 0; c < nchunk; c++, off += 4) {
         const int idx = off < npx ? off : npx;
         const float2 ta = S.ta[idx], rg = S.rg[idx], bx = S.bx[idx], pyv = S.py[idx];
@@ -151,9 +172,10 @@ __device__ __forceinline__ void quadrant_pass(ScanLds& S, const int lane, const 
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             const float dx = E[g].d0x - pxf, dy = E[g].d0y - pyf;
-            float p2 = __builtin_fmaf(E[g].hA * dx, dx, E[g].lop);
+            // log2(e) * power + log2(opacity) = dx (hA dx + nB dy) + hC dy^2 + lop: five instructions (the decisions come from the masks, so
+            // the order of the rounding is free here; the pipeline's six repeat the fast forward's sequence bit for bit)
+            float p2 = __builtin_fmaf(__builtin_fmaf(E[g].hA, dx, E[g].nB * dy), dx, E[g].lop);
             p2 = __builtin_fmaf(E[g].hC * dy, dy, p2);
-            p2 = __builtin_fmaf(E[g].nB * dx, dy, p2);             // log2(e) * power + log2(opacity)
             const float araw = __builtin_amdgcn_exp2f(p2);         // opacity * G
             // bit `entry` of the pixel's mask (the strict forward blended this pair) as an all-ones / all-zeros word
             uint32_t sel_, m_;
@@ -200,7 +222,7 @@ __device__ __forceinline__ void quadrant_pass(ScanLds& S, const int lane, const 
     }
 }
 
-__global__ __launch_bounds__(64) void render_bwd_scan_kernel(RenderBwdArgs a)
+__global__ __launch_bounds__(64, 4) void render_bwd_scan_kernel(RenderBwdArgs a)
 {
     __shared__ ScanLds S;
     const int lane = threadIdx.x;
@@ -228,6 +250,7 @@ __global__ __launch_bounds__(64) void render_bwd_scan_kernel(RenderBwdArgs a)
 
     // ---- lane = entry: stage the bucket's entries
     const float LOG2E = 1.4426950408889634f;
+    {
     ScanEntry L = {0.f, 0.f, 0.f, 0.f, 0.f, -__builtin_inff(), 0.f, 0.f, 0.f};
     float rop = 0.f;
     if (valid) {
@@ -242,66 +265,111 @@ __global__ __launch_bounds__(64) void render_bwd_scan_kernel(RenderBwdArgs a)
     }
     S.ent[SC_ENT_F4 * lane] = make_float4(L.d0x, L.d0y, L.hA, L.hC);
     S.ent[SC_ENT_F4 * lane + 1] = make_float4(L.nB, L.lop, L.cr, L.cg);
-    S.ent[SC_ENT_F4 * lane + 2] = make_float4(L.cb, 0.f, 0.f, 0.f);
+    S.ent[SC_ENT_F4 * lane + 2] = make_float4(L.cb, rop, __uint_as_float(slot), 0.f);   // (.y, .z: what the lane needs again at the very end)
 #pragma unroll
     for (int k = 0; k < 9; k++) S.acc[9 * lane + k] = 0.f;
+    }
 
     float c099 = 0.99f;
     asm volatile("" : "+v"(c099));
 
+    // One quadrant's per-pixel inputs.  All four loads of a lane are issued together (the checkpoint of a pixel that turns out inactive is
+    // stale memory and is never used), and quadrant q + 1's are in flight while quadrant q is worked on: a bucket otherwise spends eight
+    // dependent round trips to memory here with four waves per SIMD to hide them.
+    struct PixIn { uint64_t hm; float4 pf, ck; float g0, g1, g2; };
+    auto load_pix = [&](int q) {
+        PixIn r;
+        const int pidx = q * 64 + lane;
+        r.hm = a.hit[(size_t)bucket * GS_TILE_PIX + pidx];
+        r.pf = a.pix_final[(size_t)tile * GS_TILE_PIX + pidx];
+        r.ck = a.ckpt[(size_t)bucket * GS_TILE_PIX + pidx];
+        const int px = tx0 + tile_pix_x(pidx), py = ty0 + tile_pix_y(pidx);
+        r.g0 = r.g1 = r.g2 = 0.f;
+        if (px < a.W && py < a.H) {
+            const size_t pid = (size_t)py * a.W + px;
+            r.g0 = a.dL_dpix[pid]; r.g1 = a.dL_dpix[plane + pid]; r.g2 = a.dL_dpix[2 * plane + pid];
+        }
+        return r;
+    };
+#ifndef GS_SCAN_PREFETCH
+#define GS_SCAN_PREFETCH 0   // 1: quadrant q + 1's inputs are fetched while quadrant q is worked on — measured slower (profiles/r04g_bwd_scan_ab.log:
+#endif                       // the thirteen parked registers spill at four waves per SIMD)
+#if GS_SCAN_PREFETCH
+    PixIn nxt = load_pix(0);
+#endif
     for (int q = 0; q < 4; q++) {
         // ---- lane = pixel of quadrant q
+#if GS_SCAN_PREFETCH
+        const PixIn cur = nxt;
+        if (q < 3) nxt = load_pix(q + 1);   // (wave-uniform)
+#else
+        const PixIn cur = load_pix(q);
+#endif
         const int pidx = q * 64 + lane;
-        const uint64_t hm64 = a.hit[(size_t)bucket * GS_TILE_PIX + pidx];
+        const uint64_t hm64 = cur.hm;
         const int lx = tile_pix_x(pidx), ly = tile_pix_y(pidx);
         const int px = tx0 + lx, py = ty0 + ly;
         // (a forward wave stops writing masks and checkpoints once all ITS pixels are finished: beyond a pixel's last contributor both are stale)
-        const float4 pf = a.pix_final[(size_t)tile * GS_TILE_PIX + pidx];
+        const float4 pf = cur.pf;
         const bool active = px < a.W && py < a.H && __float_as_uint(pf.w) > bstart && hm64 != 0ull;
         const uint64_t bal = __ballot(active);
         if (bal == 0ull) continue;   // (wave-uniform)
         const uint32_t mlo = active ? (uint32_t)hm64 : 0u, mhi = active ? (uint32_t)(hm64 >> 32) : 0u;
-        const uint32_t S_lo = wave_or(mlo), S_hi = wave_or(mhi);
-        const int npx = __popcll(bal);
-        const int ne = __popc(S_lo) + __popc(S_hi);
+        // lanes 0..31 are the quadrant's upper 8x4 pixels, lanes 32..63 its lower: one entry set per half
+        uint32_t S_lo[2], S_hi[2];
+        half_or(mlo, S_lo[0], S_lo[1]);
+        half_or(mhi, S_hi[0], S_hi[1]);
+        const uint32_t balh[2] = {(uint32_t)bal, (uint32_t)(bal >> 32)};
+        const int half = lane >> 5;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the previous quadrant's LDS traffic is done before its records are overwritten
         __builtin_amdgcn_wave_barrier();
         if (active) {
-            const float4 ck = a.ckpt[(size_t)bucket * GS_TILE_PIX + pidx];
-            const size_t pid = (size_t)py * a.W + px;
-            const float g0 = a.dL_dpix[pid], g1 = a.dL_dpix[plane + pid], g2 = a.dL_dpix[2 * plane + pid];
+            const float4 ck = cur.ck;
+            const float g0 = cur.g0, g1 = cur.g1, g2 = cur.g2;
             float A0 = (ck.y - pf.x) * g0;   // ar = checkpoint colour - final colour (backward.cu:522-523), dotted with dL/dpixel
             A0 = __builtin_fmaf(ck.z - pf.y, g1, A0);
             A0 = __builtin_fmaf(ck.w - pf.z, g2, A0);
-            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            // position among the active pixels of this lane's half (mbcnt_lo counts the set bits below a lane of the lower half, mbcnt_hi of the upper)
+            const uint32_t pos = half ? (uint32_t)SC_HALF + __builtin_amdgcn_mbcnt_hi(balh[1], 0u) : __builtin_amdgcn_mbcnt_lo(balh[0], 0u);
             S.ta[pos] = make_float2(ck.x, A0);
             S.rg[pos] = make_float2(g0, g1);
             S.bx[pos] = make_float2(g2, (float)lx);
             S.py[pos] = make_float2((float)ly, 0.f);
             S.hm[pos] = make_uint2(mlo, mhi);
         }
-        if (lane == 0) {   // the all-zero record: what a row without a pixel (last chunk) works on — nothing blends, every product is an exact zero
-            S.ta[npx] = S.rg[npx] = S.bx[npx] = S.py[npx] = make_float2(0.f, 0.f);
-            S.hm[npx] = make_uint2(0u, 0u);
+        if ((lane & 31) == 0) {   // the all-zero record of each half: what a row without a pixel (last chunk) works on — nothing blends, every product is an exact zero
+            const int z = half * SC_HALF + __popc(half ? balh[1] : balh[0]);
+            S.ta[z] = S.rg[z] = S.bx[z] = S.py[z] = make_float2(0.f, 0.f);
+            S.hm[z] = make_uint2(0u, 0u);
         }
-        {   // the quadrant's entries in list order: lane j with bit j of S set is entry number popcount(S below j)
-            const bool mine = lane < 32 ? ((S_lo >> lane) & 1u) : ((S_hi >> (lane - 32)) & 1u);
-            const uint32_t k = __builtin_amdgcn_mbcnt_hi(S_hi, __builtin_amdgcn_mbcnt_lo(S_lo, 0u));
-            if (mine) S.list[k] = (uint32_t)lane;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {   // the half's entries in list order: lane j with bit j of its set is entry number popcount(set below j)
+            const bool mine = lane < 32 ? ((S_lo[h] >> lane) & 1u) : ((S_hi[h] >> (lane - 32)) & 1u);
+            const uint32_t k = __builtin_amdgcn_mbcnt_hi(S_hi[h], __builtin_amdgcn_mbcnt_lo(S_lo[h], 0u));
+            if (mine) S.list[64 * h + k] = (uint32_t)lane;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        switch ((ne + 15) >> 4) {
-        case 1: quadrant_pass<1>(S, lane, npx, ne, c099); break;
-        case 2: quadrant_pass<2>(S, lane, npx, ne, c099); break;
-        case 3: quadrant_pass<3>(S, lane, npx, ne, c099); break;
-        default: quadrant_pass<4>(S, lane, npx, ne, c099); break;
+        for (int h = 0; h < 2; h++) {
+            const int npx = __popc(h ? balh[1] : balh[0]);
+            if (npx == 0) continue;
+            const int ne = h ? __popc(S_lo[1]) + __popc(S_hi[1]) : __popc(S_lo[0]) + __popc(S_hi[0]);
+            switch ((ne + 15) >> 4) {
+            case 1: block_pass<1>(S, lane, h * SC_HALF, 64 * h, npx, ne, c099); break;
+            case 2: block_pass<2>(S, lane, h * SC_HALF, 64 * h, npx, ne, c099); break;
+            case 3: block_pass<3>(S, lane, h * SC_HALF, 64 * h, npx, ne, c099); break;
+            default: block_pass<4>(S, lane, h * SC_HALF, 64 * h, npx, ne, c099); break;
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     if (valid) {   // lane = entry again: the instance's 36-byte row (as render_bwd_kernel writes it)
+        const float4 e0 = S.ent[SC_ENT_F4 * lane], e1 = S.ent[SC_ENT_F4 * lane + 1], e2 = S.ent[SC_ENT_F4 * lane + 2];
+        const ScanEntry L = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x};
+        const float rop = e2.y;
+        const uint32_t slot = __float_as_uint(e2.z);
         const float* s = S.acc + 9 * lane;
         const float Sx = s[0], Sy = s[1], cxx = s[2], cxy = s[3], cyy = s[4], op = s[5], cr = s[6], cg = s[7], cb = s[8];
         const float kx = 0.5f * (float)a.W / LOG2E, ky = 0.5f * (float)a.H / LOG2E;

@@ -21,6 +21,35 @@ __constant__ float c_G[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.0
                               0.21300552785396576f,  0.26601171493530273f,   0.21300552785396576f,  0.10936068743467331f,
                               0.036000773310661316f, 0.0075987582094967365f, 0.001028380123898387f};
 
+// blockIdx -> (tile x, tile y, plane).  Workgroup i of a 1-D grid runs on XCD i % 8 (eight private L2s); a tile shares 10 of its 42 halo columns /
+// rows with each neighbour.  With a plain dim3(W/32, H/32, planes) grid neighbouring tiles land on different XCDs and every shared halo line is
+// fetched from HBM by both (loss_fwd 2.2x, loss_bwd 2.4x its algorithmic bytes, L2 hit rate 0.23 / 0.09: profiles/r03x_cache_lds.md).  Here
+// XCD x works through the x-th contiguous eighth of the tiles (plane by plane, bands of four tile rows walked column by column), so that a
+// tile's neighbours ran shortly before it on the same L2.  Returns false for the padding workgroups of the last eighth.
+struct SsimGrid { int gx, gy, planes, per_xcd; };
+__device__ __forceinline__ bool ssim_tile(const SsimGrid& g, int& tx, int& ty, int& plane, size_t& linear)
+{
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int t = xcd * g.per_xcd + j;
+    if (j >= g.per_xcd || t >= g.gx * g.gy * g.planes) return false;
+    plane = t / (g.gx * g.gy);
+    const int r = t - plane * (g.gx * g.gy);
+    // inside a plane: bands of four tile rows, column by column — a tile's upper neighbour ran just before it, its left neighbour four tiles earlier
+    const int band = r / (4 * g.gx), rem = r - band * (4 * g.gx);
+    const int bh = (g.gy - 4 * band) < 4 ? (g.gy - 4 * band) : 4;
+    tx = rem / bh; ty = 4 * band + (rem - tx * bh);
+    linear = (size_t)t;
+    return true;
+}
+static inline SsimGrid ssim_grid(int W, int H, int planes, unsigned& blocks)
+{
+    SsimGrid g;
+    g.gx = div_up(W, 32); g.gy = div_up(H, 32); g.planes = planes;
+    g.per_xcd = div_up(g.gx * g.gy * planes, 8);
+    blocks = 8u * (unsigned)g.per_xcd;
+    return g;
+}
+
 __device__ __forceinline__ float pix_or_zero(const float* __restrict__ img, int H, int W, int y, int x)
 {
     return (x >= W || y >= H || x < 0 || y < 0) ? 0.0f : img[(size_t)y * W + x];
@@ -133,14 +162,17 @@ __device__ __forceinline__ SsimTerms ssim_terms(const FwdStats& st, float C1, fl
     return t;
 }
 
-__global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, float C1, float C2, const float* __restrict__ img1,
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(SsimGrid grid, int H, int W, float C1, float C2, const float* __restrict__ img1,
                                                        const float* __restrict__ img2, float* __restrict__ ssim_map,
                                                        float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
                                                        float* __restrict__ dm_dsigma12)
 {
     __shared__ FwdLds L;
-    const size_t plane = (size_t)blockIdx.z * H * W;
-    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
+    int tile_x, tile_y, plane_i;
+    size_t tile_linear;
+    if (!ssim_tile(grid, tile_x, tile_y, plane_i, tile_linear)) return;   // (whole workgroup: before any barrier)
+    const size_t plane = (size_t)plane_i * H * W;
+    const int x0 = tile_x * ST, y0 = tile_y * ST;
     const int tid = threadIdx.x;
     float l1_unused = 0.f;
     ssim_fwd_stage(L, img1 + plane, img2 + plane, H, W, x0, y0, l1_unused);
@@ -167,7 +199,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, float C1, f
 
 // The backward keeps three separate LDS arrays and scalar arithmetic: the interleaved / packed variant of the forward was measured slower here
 // (0.063 -> 0.071 ms: three maps do not pair up, the float2 rows of 42 conflict on the LDS banks).
-__global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
+__global__ __launch_bounds__(256) void ssim_bwd_kernel(SsimGrid grid, int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                                                        const float* __restrict__ dL_dmap, const float* __restrict__ dm_dmu1,
                                                        const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12,
                                                        float* __restrict__ dL_dimg1)
@@ -177,8 +209,11 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float
     __shared__ float s1[SH_][SH_];
     __shared__ float s2[SH_][SH_];
     __shared__ float s3[SH_][SH_];
-    const size_t plane = (size_t)blockIdx.z * H * W;
-    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
+    int tile_x, tile_y, plane_i;
+    size_t tile_linear;
+    if (!ssim_tile(grid, tile_x, tile_y, plane_i, tile_linear)) return;   // (whole workgroup: before any barrier)
+    const size_t plane = (size_t)plane_i * H * W;
+    const int x0 = tile_x * ST, y0 = tile_y * ST;
     const int tid = threadIdx.x;
     {
         float v0[HALO_TRIPS], v1[HALO_TRIPS], v2[HALO_TRIPS], v3[HALO_TRIPS];
@@ -259,15 +294,18 @@ __device__ __forceinline__ float block256_sum(float v, float* red /*[4]*/)
     return r;
 }
 
-__global__ __launch_bounds__(256) void loss_fwd_kernel(int H, int W, float C1, float C2, const float* __restrict__ img1,
+__global__ __launch_bounds__(256) void loss_fwd_kernel(SsimGrid grid, int H, int W, float C1, float C2, const float* __restrict__ img1,
                                                        const float* __restrict__ img2, float* __restrict__ dm_dmu1,
                                                        float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12,
                                                        float* __restrict__ partials)
 {
     __shared__ FwdLds L;
     __shared__ float red[4];
-    const size_t plane = (size_t)blockIdx.z * H * W;
-    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
+    int tile_x, tile_y, plane_i;
+    size_t tile_linear;
+    if (!ssim_tile(grid, tile_x, tile_y, plane_i, tile_linear)) return;   // (whole workgroup: before any barrier)
+    const size_t plane = (size_t)plane_i * H * W;
+    const int x0 = tile_x * ST, y0 = tile_y * ST;
     const int tid = threadIdx.x;
     float sum_l1 = 0.f, sum_ssim = 0.f;
     ssim_fwd_stage(L, img1 + plane, img2 + plane, H, W, x0, y0, sum_l1);
@@ -291,7 +329,7 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(int H, int W, float C1, f
     const float bl1 = block256_sum(sum_l1, red);
     const float bss = block256_sum(sum_ssim, red);
     if (tid == 0) {
-        const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const size_t blk = tile_linear;
         partials[2 * blk] = bl1;
         partials[2 * blk + 1] = bss;
     }
@@ -310,7 +348,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(size_t nblk, const flo
 // dL/dimg for dL/dloss = 1: the SSIM branch is ssim_bwd_kernel with the uniform upstream gradient dL_dmap = -lambda/N (multiplied into the
 // derivative maps before the convolutions, exactly where fusedssim_backwardCUDA multiplies by dL_dmap: ssim.cu:318-350), plus the L1 branch
 // (1-lambda)/N * sign(img - gt): bit-identical to fusedssim_backward(full(-lambda/N)) + (1-lambda)/N * sign(img - gt).
-__global__ __launch_bounds__(256) void loss_bwd_kernel(int H, int W, float w_l1, float w_ssim, const float* __restrict__ img1,
+__global__ __launch_bounds__(256) void loss_bwd_kernel(SsimGrid grid, int H, int W, float w_l1, float w_ssim, const float* __restrict__ img1,
                                                        const float* __restrict__ img2, const float* __restrict__ dm_dmu1,
                                                        const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12,
                                                        float* __restrict__ dL_dimg1)
@@ -320,8 +358,11 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(int H, int W, float w_l1,
     __shared__ float s1[SH_][SH_];
     __shared__ float s2[SH_][SH_];
     __shared__ float s3[SH_][SH_];
-    const size_t plane = (size_t)blockIdx.z * H * W;
-    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
+    int tile_x, tile_y, plane_i;
+    size_t tile_linear;
+    if (!ssim_tile(grid, tile_x, tile_y, plane_i, tile_linear)) return;   // (whole workgroup: before any barrier)
+    const size_t plane = (size_t)plane_i * H * W;
+    const int x0 = tile_x * ST, y0 = tile_y * ST;
     const int tid = threadIdx.x;
     {
         float v1[HALO_TRIPS], v2[HALO_TRIPS], v3[HALO_TRIPS];
@@ -391,9 +432,10 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(int H, int W, float w_l1,
 int loss_forward(int B, int CH, int H, int W, float C1, float C2, const float* img, const float* gt, float* d1, float* d2, float* d3,
                  float* partials, float* terms, hipStream_t s)
 {
-    dim3 grid(div_up(W, ST), div_up(H, ST), B * CH);
-    GS_LAUNCH(K_SSIM_FWD, loss_fwd_kernel, grid, dim3(256), 0, s, H, W, C1, C2, img, gt, d1, d2, d3, partials);
-    const size_t nblk = (size_t)grid.x * grid.y * grid.z;
+    unsigned blocks;
+    const SsimGrid grid = ssim_grid(W, H, B * CH, blocks);
+    GS_LAUNCH(K_SSIM_FWD, loss_fwd_kernel, dim3(blocks), dim3(256), 0, s, grid, H, W, C1, C2, img, gt, d1, d2, d3, partials);
+    const size_t nblk = (size_t)grid.gx * grid.gy * grid.planes;
     GS_LAUNCH(K_SSIM_FWD, loss_reduce_kernel, dim3(1), dim3(256), 0, s, nblk, (const float*)partials,
               1.0f / (float)((size_t)B * CH * H * W), terms);
     return GSLIC_OK;
@@ -401,9 +443,10 @@ int loss_forward(int B, int CH, int H, int W, float C1, float C2, const float* i
 int loss_backward(int B, int CH, int H, int W, float lambda_dssim, const float* img, const float* gt, const float* d1, const float* d2,
                   const float* d3, float* dL_dimg, hipStream_t s)
 {
-    dim3 grid(div_up(W, ST), div_up(H, ST), B * CH);
+    unsigned blocks;
+    const SsimGrid grid = ssim_grid(W, H, B * CH, blocks);
     const float n = (float)((size_t)B * CH * H * W);
-    GS_LAUNCH(K_SSIM_BWD, loss_bwd_kernel, grid, dim3(256), 0, s, H, W, (1.0f - lambda_dssim) / n, -lambda_dssim / n, img, gt, d1, d2,
+    GS_LAUNCH(K_SSIM_BWD, loss_bwd_kernel, dim3(blocks), dim3(256), 0, s, grid, H, W, (1.0f - lambda_dssim) / n, -lambda_dssim / n, img, gt, d1, d2,
               d3, dL_dimg);
     return GSLIC_OK;
 }
@@ -413,8 +456,9 @@ int ssim_forward(int B, int CH, int H, int W, float C1, float C2, const float* i
                  float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, hipStream_t s)
 {
     if (B * CH == 0 || H == 0 || W == 0) return GSLIC_OK;
-    dim3 grid(div_up(W, ST), div_up(H, ST), B * CH);
-    GS_LAUNCH(K_SSIM_FWD, ssim_fwd_kernel, grid, dim3(256), 0, s, H, W, C1, C2, img1, img2, ssim_map, dm_dmu1, dm_dsigma1_sq,
+    unsigned blocks;
+    const SsimGrid grid = ssim_grid(W, H, B * CH, blocks);
+    GS_LAUNCH(K_SSIM_FWD, ssim_fwd_kernel, dim3(blocks), dim3(256), 0, s, grid, H, W, C1, C2, img1, img2, ssim_map, dm_dmu1, dm_dsigma1_sq,
               dm_dsigma12);
     return GSLIC_OK;
 }
@@ -422,8 +466,9 @@ int ssim_backward(int B, int CH, int H, int W, const float* img1, const float* i
                   const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1, hipStream_t s)
 {
     if (B * CH == 0 || H == 0 || W == 0) return GSLIC_OK;
-    dim3 grid(div_up(W, ST), div_up(H, ST), B * CH);
-    GS_LAUNCH(K_SSIM_BWD, ssim_bwd_kernel, grid, dim3(256), 0, s, H, W, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
+    unsigned blocks;
+    const SsimGrid grid = ssim_grid(W, H, B * CH, blocks);
+    GS_LAUNCH(K_SSIM_BWD, ssim_bwd_kernel, dim3(blocks), dim3(256), 0, s, grid, H, W, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
               dL_dimg1);
     return GSLIC_OK;
 }

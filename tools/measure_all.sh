@@ -47,9 +47,9 @@ python $R/tools/rocpd_summary.py $(find /tmp/prof_dropin_$TAG -name "*.db" | hea
 python $R/tools/rocpd_timeline.py $(find /tmp/prof_dropin_$TAG -name "*.db" | head -1) preprocess_kernel 12 > $OUT/${TAG}_dropin_timeline.txt 2>&1
 python $R/tools/rocpd_timeline.py $(find /tmp/prof_$TAG -name "*.db" | head -1) preprocess_kernel 12 > $OUT/${TAG}_fused_timeline.txt 2>&1
 # HBM traffic (separate passes), SQ counters
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf_$TAG -o f -- python $R/tools/pmc_run.py > /tmp/pf.log 2>&1
+PMC_UNITS=/tmp/pmc_units_$TAG.json timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf_$TAG -o f -- python $R/tools/pmc_run.py > /tmp/pf.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw_$TAG -o w -- python $R/tools/pmc_run.py > /tmp/pw.log 2>&1
-python $R/tools/pmc_extract.py $(find /tmp/pf_$TAG -name "*.db" | head -1) $(find /tmp/pw_$TAG -name "*.db" | head -1) $OUT/${TAG}_pmc_traffic.json $TAG > /dev/null
+python $R/tools/pmc_extract.py $(find /tmp/pf_$TAG -name "*.db" | head -1) $(find /tmp/pw_$TAG -name "*.db" | head -1) $OUT/${TAG}_pmc_traffic.json $TAG /tmp/pmc_units_$TAG.json > /dev/null
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -d /tmp/sq_$TAG -o sq -- python $R/tools/pmc_run.py > /tmp/sq.log 2>&1
 python $R/tools/pmc_sq_extract.py $(find /tmp/sq_$TAG -name "*.db" | head -1) > $OUT/${TAG}_sq_counters.txt 2>&1
 # L2 hit rate and LDS bank conflicts (the "LDS-hit counters" of the north-star), one pass each

@@ -1,6 +1,6 @@
 """Reads the two rocprofv3 --pmc databases (FETCH_SIZE pass, WRITE_SIZE pass) and writes profiles/pmc_traffic.json:
 per-kernel average counter values, the calibration factors measured on the known 1 GiB copy, and calibrated HBM bytes
-per launch.  usage: python tools/pmc_extract.py <fetch.db> <write.db> <out.json>"""
+per launch.  usage: python tools/pmc_extract.py <fetch.db> <write.db> <out.json> [tag] [units.json]"""
 import json
 import sqlite3
 import sys
@@ -22,7 +22,7 @@ def per_kernel(db, counter):
     return out
 
 
-def main(fetch_db, write_db, out, tag="untagged"):
+def main(fetch_db, write_db, out, tag="untagged", units_file=None):
     f = per_kernel(fetch_db, "FETCH_SIZE")
     w = per_kernel(write_db, "WRITE_SIZE")
     GiB = float(1 << 30)
@@ -33,6 +33,10 @@ def main(fetch_db, write_db, out, tag="untagged"):
     res = {"workload": "random-2000000-1920x1080", "tag": tag, "calibration_kernel": cal, "fetch_factor": fetch_factor, "write_factor": write_factor,
            "note": "bytes = counter_KB * 1024 * factor; factors measured on a 1 GiB torch copy in the same runs (guide: FETCH_SIZE reads 1/2 on wide loads on gfx950)",
            "kernels": {}}
+    if units_file:   # unit counts of the workload the counters were collected on (tools/pmc_run.py, PMC_UNITS): bench.py compares them with its own
+        u = json.load(open(units_file))
+        res["units"] = {k: u[k] for k in ("P", "V", "R", "B", "R_live", "B_live", "steps_before")}
+        res["strict"] = bool(u.get("strict", True))
     for k in sorted(set(f) | set(w)):
         if "gslic::" not in k:
             continue
@@ -53,4 +57,4 @@ def main(fetch_db, write_db, out, tag="untagged"):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])
