@@ -379,6 +379,18 @@ def main():
         sec = timed_loop(step, n_extra)
         other = {"host": host["mode"], "value": round(n_extra * world / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3),
                  "steps": n_extra}
+        if host["mode"] == "dropin":
+            # the number above is the reference's host lines on the DROP-IN renderer (render() feeds the raw parameters to one autograd node: what
+            # swapping renderer.cpp for shim/renderer.cpp gives an otherwise unmodified host); beside it the same lines on renderer.cpp as written
+            # (getOpacity / getScaling / getRotation as LibTorch ops) and with the optional one-node loss
+            other["what"] = "reference operator API + LibTorch autograd, drop-in renderer (activations inside the kernels)"
+            os.environ["GSLIC_RENDER_RAW"] = "0"
+            sec2 = timed_loop(step, n_extra)
+            os.environ.pop("GSLIC_RENDER_RAW", None)
+            other["renderer_as_written"] = {"value": round(n_extra * world / sec2, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec2 / n_extra, 3)}
+            if world == 1 and not trainer._dist_on():
+                sec3 = timed_loop(lambda: trainer.training_step(model, cam, gt, bg, one_node_loss=True), n_extra)
+                other["one_node_loss"] = {"value": round(n_extra / sec3, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec3 / n_extra, 3)}
         host["mode"] = args.host
         if world == 1 and not trainer._dist_on() and args.host == "fused" and not args.split_adam:
             # the same step as ONE hipGraph replay: capacity-mode forward (no host round trip), loss, backward + Adam
@@ -682,8 +694,28 @@ def cpp_fused_host(args, model, cam, gt, n):
         if r.returncode != 0 or not line:
             return {"error": (r.stdout[-300:] + r.stderr[-300:]).strip()}
         tok = line[0].split()
-        return {"host": "C++ (LibTorch tensors + C-ABI, no autograd graph)", "value": round(float(tok[1]), 3), "unit": "views/s",
-                "ms_per_step": round(float(tok[3]), 3), "steps": n}
+        res = {"host": "C++ (LibTorch tensors + C-ABI, no autograd graph)", "value": round(float(tok[1]), 3), "unit": "views/s",
+               "ms_per_step": round(float(tok[3]), 3), "steps": n}
+        # the REFERENCE's host lines (render() -> l1_loss + fused_ssim -> loss.backward() -> SparseGaussianAdam::step(), gaussian.cpp:683-707) compiled
+        # unmodified, linked with (a) the reference's own renderer.cpp, (b) this repository's drop-in renderer.cpp (activations inside the kernels),
+        # (c) the drop-in renderer + the optional one-node loss: what an unchanged / a one-file-swapped / a five-line-edited Gaussian-LIC host runs at.
+        # Full learning rates (the program's own): the scene fades over the run, so the three are compared with each other, not with `value`.
+        pkg = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gaussian-lic_amd")
+        drop = {}
+        for key, name in (("reference_renderer_cpp", "dropin_check_render_ref"), ("dropin_renderer_cpp", "dropin_check_render"),
+                          ("dropin_renderer_cpp_one_node_loss", "dropin_check_render_loss")):
+            exe2 = os.path.join(pkg, name)
+            if not os.path.exists(exe2):
+                continue
+            env = dict(os.environ, GSLIC_CHECK_TIME="1")
+            n2 = min(n, 60) + 3
+            r2 = subprocess.run([exe2, d, str(model.P), str(args.width), str(args.height), "3", str(n2)], capture_output=True, text=True, timeout=600, env=env)
+            l2 = [l for l in r2.stdout.splitlines() if l.startswith("views_per_s")]
+            drop[key] = ({"value": round(float(l2[0].split()[1]), 3), "unit": "views/s", "ms_per_step": round(float(l2[0].split()[3]), 3), "steps": n2 - 3}
+                         if (r2.returncode == 0 and l2) else {"error": (r2.stdout[-200:] + r2.stderr[-200:]).strip()})
+        if drop:
+            res["reference_host_lines_cpp"] = drop
+        return res
     finally:
         if not keep:
             shutil.rmtree(d, ignore_errors=True)
@@ -712,21 +744,23 @@ def growth_schedule(args, dev):
     Rcw = torch.from_numpy(cam.world_view_transform[:3, :3].T.copy())
     tcw = torch.from_numpy(cam.world_view_transform[3, :3].copy())
     intr = (float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy))
-    # LiDAR frames whose points ALL survive extend()'s filter, so that every append inserts exactly n_frame Gaussians: one return per pixel, on
-    # distinct pixels of the strip the map does not cover (u > 0.75 W: transmittance 1 there; later frames land on pixels earlier ones left free)
-    x_lo = int(0.75 * W) + 1
+    # LiDAR frames with 1.6x the points an append needs, one return per pixel on distinct pixels of the strip the map does not cover yet: extend()'s
+    # filter (alpha < 0.99 at the pixel, gaussian.cpp:584-603) lets ~90 % of them through — the earlier frames' Gaussians have been trained for
+    # twenty iterations by then — and the append is cut to exactly n_frame rows (the first n_frame survivors in point order), so that the map
+    # grows 1.5M -> 2.0M in five appends of 1e5 as SURVEY 8d writes it
+    x_lo = int(0.72 * W) + 1
     strip = (W - x_lo) * H
-    assert 5 * n_frame <= strip, "the uncovered strip has too few pixels for five frames of distinct pixels"
+    n_cand = int(1.6 * n_frame)
+    assert n_cand <= strip
     g = torch.Generator().manual_seed(200)
-    pix = torch.randperm(strip, generator=g)[:5 * n_frame]
     frames = []
-    for k in (0, 0, 1, 2, 3, 4):   # the warm-up frame (its rows are dropped again, so it may share the first frame's pixels) + five timed ones
-        pk = pix[k * n_frame:(k + 1) * n_frame]
+    for k in range(6):   # one warm-up frame (its rows are dropped again) + five timed ones
+        pk = torch.randperm(strip, generator=g)[:n_cand]
         px_ = (x_lo + pk % (W - x_lo)).float() + 0.25
         py_ = (pk // (W - x_lo)).float() + 0.25
-        z = torch.rand(n_frame, generator=g) * 38.0 + 2.0
+        z = torch.rand(n_cand, generator=g) * 38.0 + 2.0
         xyz = torch.stack([(px_ - intr[2]) * z / intr[0], (py_ - intr[3]) * z / intr[1], z], 1).contiguous()
-        col = torch.rand(n_frame, 3, generator=g)
+        col = torch.rand(n_cand, 3, generator=g)
         frames.append((xyz.to(dev), col.to(dev), z.contiguous().to(dev)))
     P0 = model.P
     warm = model.extend(cam, *frames[0], Rcw, tcw, intr)     # warm-up: one-off allocations of extend(); its rows are dropped again
@@ -736,7 +770,7 @@ def growth_schedule(args, dev):
         trainer.training_step_fused(model, cam, gt, bg)
     torch.cuda.synchronize()
     clocks0 = _gpu_clocks()
-    P1, inserted, ext_ms = model.P, 0, 0.0
+    P1, inserted, ext_ms, survivors = model.P, 0, 0.0, []
     from gaussian_lic_amd import _lib
     _lib.profile_reset()
     _lib.profile_enable(True, only=["render_bwd", "preprocess_bwd", "render_fwd"])   # (three event pairs per step: where a slow run loses its time)
@@ -745,7 +779,13 @@ def growth_schedule(args, dev):
     for it in range(100):
         if it % 20 == 0:
             e0 = time.perf_counter()
-            inserted += model.extend(cam, *frames[1 + it // 20], Rcw, tcw, intr)   # (synchronises: the survivor count sizes the append)
+            p_before = model.P
+            k_ins = model.extend(cam, *frames[1 + it // 20], Rcw, tcw, intr)   # (synchronises: the survivor count sizes the append)
+            survivors.append(int(k_ins))
+            if k_ins > n_frame:                                                # keep the first n_frame survivors: exactly 1e5 per append at the default size
+                model.P = p_before + n_frame
+                model._rebind()
+            inserted += min(int(k_ins), n_frame)
             e1 = time.perf_counter()
             ext_ms += 1e3 * (e1 - e0)
             seg_ms.append(1e3 * (e0 - t0))   # (the device is idle at e0: extend() of the previous segment synchronised, or nothing ran yet)
@@ -756,7 +796,7 @@ def growth_schedule(args, dev):
     kms = _lib.profile_collect()
     _lib.profile_enable(False)
     return {"workload": f"SURVEY 8d config 3 schedule: {P1} -> {model.P} Gaussians by 5 extend() appends (every 20 iterations), 100 iterations, reference learning rates",
-            "warmup_frame_inserted_then_dropped": int(warm), "clocks_before": clocks0, "clocks_after": _gpu_clocks(),
+            "warmup_frame_inserted_then_dropped": int(warm), "candidates_per_frame": n_cand, "survivors_per_frame": survivors, "clocks_before": clocks0, "clocks_after": _gpu_clocks(),
             "value": round(100.0 / sec, 3), "unit": "views/s", "ms_per_iteration": round(10.0 * sec, 3), "iterations": 100, "appends": 5,
             "gaussians_start": P1, "gaussians_end": model.P, "inserted": inserted, "extend_ms_per_call": round(ext_ms / 5.0, 3),
             "gaussians_before_warmup_frame": P0,

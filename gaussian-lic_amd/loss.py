@@ -113,6 +113,33 @@ def evaluate_visual_quality(model, cameras, gt_images, bg, fused=True):
     return torch.stack(ps).mean(), torch.stack(ss).mean()
 
 
+class _L1SsimLoss(torch.autograd.Function):
+    """(1 - lambda) * l1_loss + lambda * (1 - fused_ssim) as ONE autograd node on gslic_l1_ssim_loss_forward / _backward: what
+    gaussian.cpp:685-691 builds from l1_loss (loss_utils.h:30-33: sub, abs, mean), fused_ssim (:130-193: the map kernel + mean) and four
+    scalar ops, with their backward nodes — two kernels forward, one backward.  dL/dimage equals the chain's bit for bit
+    (tests/test_vs_reference_kernels_gpu.py::test_fused_loss_gradient_is_the_reference_chain_bit_for_bit) times the upstream scalar."""
+
+    @staticmethod
+    def forward(ctx, image, gt, lambda_dssim):
+        fl = FusedLoss(lambda_dssim)
+        ctx.fl, ctx.shape = fl, image.shape
+        img3, gt3 = image.reshape(image.shape[-3:]), gt.reshape(gt.shape[-3:])
+        dL, terms = fl.forward_backward(img3, gt3)
+        ctx.save_for_backward(dL)
+        return fl.value(terms)
+
+    @staticmethod
+    def backward(ctx, g):
+        (dL,) = ctx.saved_tensors
+        return (dL * g).reshape(ctx.shape), None, None
+
+
+def l1_ssim_loss(image, gt, lambda_dssim=0.2):
+    """Optional one-call replacement for the loss lines of optimize() (gaussian.cpp:685-691): `loss = l1_ssim_loss(rendered_image, gt_image,
+    lambda_dssim)`.  image, gt: [3,H,W] (or [1,3,H,W])."""
+    return _L1SsimLoss.apply(image, gt, float(lambda_dssim))
+
+
 class FusedLoss:
     """loss = (1-lambda) * L1 + lambda * (1 - SSIM) of optimize() (gaussian.cpp:685-691) computed by two kernels
     (gslic_l1_ssim_loss_forward / _backward) with no LibTorch elementwise ops and no autograd graph."""

@@ -271,17 +271,73 @@ class GaussianRasterizer(torch.nn.Module):
                                                 cov3D_precomp, self.raster_settings)
 
 
-def render(camera, model, bg_color, no_color=False, scaling_modifier=1.0):
-    """renderer.cpp:21-88.  `camera` = gaussian_lic_amd.camera.Camera with device tensors attached via to_device();
-    `model` exposes get_xyz/get_opacity/get_scaling/get_rotation/get_features_dc/get_features_rest, sh_degree,
-    lambda_erank.  Returns (image, final_T, screenspace_points, visible, radii)."""
-    xyz = model.get_xyz()
-    screenspace_points = torch.zeros_like(xyz, requires_grad=True)
+class RawGaussianRasterizerFunction(torch.autograd.Function):
+    """The autograd node behind render(): same forward / backward as GaussianRasterizerFunction (rasterizer.cpp:21-183), but on the model's
+    RAW leaf tensors — sigmoid(opacity_), exp(scaling_), normalize(rotation_) of gaussian.cpp:147-175 run inside preprocess / preprocess_bwd
+    (raw_params = 1), so the six LibTorch elementwise launches of the activations, the ten of their backward nodes and the zeros_like of the
+    screen-space points disappear from the step.  Gradients are w.r.t. the raw tensors: exactly what autograd would have chained to.
+    Only the six gradients the host's optimiser reads are materialised (rasterizer.cpp:171-182 discards the other four)."""
+
+    @staticmethod
+    def forward(ctx, xyz, dc, sh, opacity_raw, scaling_raw, rotation_raw, rs):
+        e = torch.empty(0, device=xyz.device)
+        (R, B, color, final_T, radii, geom, binning, img, sample) = rasterize_gaussians(
+            rs.bg, xyz, e, opacity_raw, scaling_raw, rotation_raw, rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
+            rs.image_height, rs.image_width, rs.limx_neg, rs.limx_pos, rs.limy_neg, rs.limy_pos, dc, sh, rs.sh_degree, rs.campos, rs.prefiltered,
+            rs.debug, rs.no_color, raw_params=True)
+        ctx.rs, ctx.R, ctx.B = rs, R, B
+        ctx.save_for_backward(xyz, dc, sh, opacity_raw, scaling_raw, rotation_raw, radii, geom, binning, img, sample)
+        ctx.mark_non_differentiable(radii, final_T)
+        return color, radii, final_T
+
+    @staticmethod
+    def backward(ctx, dL_dcolor, _dL_dradii, _dL_dfinal_T):
+        rs = ctx.rs
+        xyz, dc, sh, opacity_raw, scaling_raw, rotation_raw, radii, geom, binning, img, sample = ctx.saved_tensors
+        e = torch.empty(0, device=xyz.device)
+        out = dict(xyz=torch.empty_like(xyz), features_dc=torch.empty_like(dc), features_rest=torch.empty_like(sh), opacity=torch.empty_like(opacity_raw),
+                   scaling=torch.empty_like(scaling_raw), rotation=torch.empty_like(rotation_raw))   # (every row is written by the kernel)
+        rasterize_gaussians_backward(rs.bg, xyz, radii, e, scaling_raw, rotation_raw, rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                                     rs.tanfovy, rs.limx_neg, rs.limx_pos, rs.limy_neg, rs.limy_pos, dL_dcolor, dc, sh, rs.sh_degree, rs.campos, geom, ctx.R,
+                                     binning, img, ctx.B, sample, rs.lambda_erank, False, raw_params=True, out=out)
+        return out["xyz"], out["features_dc"], out["features_rest"], out["opacity"], out["scaling"], out["rotation"], None
+
+
+def _raw_leaves(model):
+    """The six raw parameter tensors of a GaussianModel (xyz_, features_dc_, features_rest_, opacity_, scaling_, rotation_: gaussian.h:153-158),
+    or None when the model only offers the activated accessors."""
+    names = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")
+    if all(torch.is_tensor(getattr(model, n, None)) for n in names):
+        return tuple(getattr(model, n) for n in names)
+    return None
+
+
+def render(camera, model, bg_color, no_color=False, scaling_modifier=1.0, raw=None):
+    """renderer.cpp:21-88 — same signature, same five results (image, final_T, screenspace_points, visible, radii).  `camera` =
+    gaussian_lic_amd.camera.Camera with device tensors attached via to_device(); `model` exposes get_xyz / get_opacity / get_scaling /
+    get_rotation / get_features_dc / get_features_rest, sh_degree, lambda_erank.
+
+    raw (default: on whenever the model exposes its raw leaf tensors; GSLIC_RENDER_RAW=0 turns it off): the renderer feeds the RAW parameters to
+    one autograd node whose kernels apply the activations (RawGaussianRasterizerFunction) instead of calling getOpacity() / getScaling() /
+    getRotation() (renderer.cpp:57-63).  Image and gradients equal the operator path's up to fp32 rounding of the activation chain
+    (tests/test_fused_gpu.py).  screenspace_points is then a zero-stride view of one zero row: the reference allocates and zero-fills
+    [P,3] for a gradient (dL_dmeans2D) no caller of render() reads (gaussian.cpp:506,683,757,797); raw=False restores it."""
+    import os
+    leaves = _raw_leaves(model)
+    if raw is None:
+        raw = leaves is not None and os.environ.get("GSLIC_RENDER_RAW", "1") != "0"
     rs = GaussianRasterizationSettings(
         camera.image_height, camera.image_width, float(camera.tanfovx), float(camera.tanfovy), float(camera.limx_neg),
         float(camera.limx_pos), float(camera.limy_neg), float(camera.limy_pos), bg_color, scaling_modifier,
         camera.d_world_view_transform, camera.d_full_proj_transform, model.sh_degree, camera.d_camera_center, False, False,
         no_color, model.lambda_erank)
+    if raw:
+        xyz, dc, rest, opacity, scaling, rotation = leaves
+        image, radii, final_T = RawGaussianRasterizerFunction.apply(xyz, dc, rest, opacity, scaling, rotation, rs)
+        screenspace_points = torch.zeros(1, 3, dtype=xyz.dtype, device=xyz.device).expand(xyz.shape[0], 3)
+        return image, final_T, screenspace_points, radii > 0, radii
+    xyz = model.get_xyz()
+    screenspace_points = torch.zeros_like(xyz, requires_grad=True)
     rasterizer = GaussianRasterizer(rs)
     image, radii, final_T = rasterizer(xyz, screenspace_points, model.get_opacity(), model.get_features_dc(),
                                        model.get_features_rest(), None, model.get_scaling(), model.get_rotation(), None)

@@ -37,6 +37,9 @@ REF_SRC = "/root/reference/src"
 CHECK = os.path.join(PKG, "dropin_check")
 CHECK_GROUPS = os.path.join(PKG, "dropin_check_groups")
 CHECK_DIST = os.path.join(PKG, "dropin_check_dist")
+CHECK_RENDER_REF = os.path.join(PKG, "dropin_check_render_ref")   # render() of the REFERENCE's renderer.cpp (on the stand-in Camera / GaussianModel)
+CHECK_RENDER = os.path.join(PKG, "dropin_check_render")           # render() of shim/renderer.cpp, the drop-in replacement
+CHECK_RENDER_LOSS = os.path.join(PKG, "dropin_check_render_loss") # ... + the optional one-node loss (loss_utils_fused.h)
 
 
 def build_dropin_check(force=False, groups=False):
@@ -49,18 +52,27 @@ def build_dropin_check(force=False, groups=False):
     if groups == "dist":   # + the N > 1 exchange step over c10d / RCCL (shim/include/gslic_dist.h) between loss.backward() and step()
         return _build_check(CHECK_DIST, ["-DGSLIC_DIST", "-DUSE_C10D_NCCL", "-DUSE_ROCM", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(HERE, "include"),
                                          "-I", os.path.join(HERE, "include", "nccl_fwd"), "-isystem", "/opt/rocm/include"], force)
+    if groups in ("render_ref", "render", "render_loss"):
+        # this repo's optim_utils.h (one Adam launch) in all three, so that the renderer / the loss is the only thing that differs
+        inc = ["-DGSLIC_CHECK_RENDER", "-I", os.path.join(HERE, "standin"), "-I", os.path.join(HERE, "include")]
+        if groups == "render_ref":
+            return _build_check(CHECK_RENDER_REF, inc, force, extra_src=[os.path.join(REF_SRC, "rasterizer", "renderer.cpp")])
+        if groups == "render_loss":
+            inc = ["-DGSLIC_ONE_NODE_LOSS"] + inc
+        return _build_check(CHECK_RENDER_LOSS if groups == "render_loss" else CHECK_RENDER, inc, force, extra_src=[os.path.join(HERE, "renderer.cpp")])
     if groups:
         return _build_check(CHECK_GROUPS, ["-I", os.path.join(HERE, "include")], force)
     return _build_check(CHECK, [], force)
 
 
-def _build_check(CHECK, first_includes, force):
+def _build_check(CHECK, first_includes, force, extra_src=()):
     import sysconfig
     import torch
     from torch.utils import cpp_extension
     src = os.path.join(HERE, "dropin_check.cpp")
-    newest = max(os.path.getmtime(src), os.path.getmtime(OUT), os.path.getmtime(os.path.join(HERE, "include", "optim_utils.h")),
-                 os.path.getmtime(os.path.join(HERE, "include", "gslic_dist.h")))
+    newest = max([os.path.getmtime(src), os.path.getmtime(OUT), os.path.getmtime(os.path.join(HERE, "include", "optim_utils.h")),
+                  os.path.getmtime(os.path.join(HERE, "include", "gslic_dist.h")), os.path.getmtime(os.path.join(HERE, "include", "loss_utils_fused.h"))] +
+                 [os.path.getmtime(x) for x in extra_src])
     if not force and os.path.exists(CHECK) and os.path.getmtime(CHECK) > newest:
         return CHECK
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
@@ -68,7 +80,7 @@ def _build_check(CHECK, first_includes, force):
     for inc in cpp_extension.include_paths():
         cmd += ["-isystem", inc]
     cmd += first_includes
-    cmd += ["-isystem", sysconfig.get_paths()["include"], "-I", REF_SRC, src, os.path.join(REF_SRC, "rasterizer", "rasterizer.cpp"),
+    cmd += ["-isystem", sysconfig.get_paths()["include"], "-I", REF_SRC, "-I", os.path.join(REF_SRC, "rasterizer"), src, os.path.join(REF_SRC, "rasterizer", "rasterizer.cpp"), *extra_src,
             "-o", CHECK, "-L", PKG, "-lgslic_torch_shim", "-lgslic_hip", "-Wl,-rpath,$ORIGIN", "-L", tlib, "-ltorch", "-ltorch_cpu",
             "-ltorch_hip", "-lc10", "-lc10_hip", f"-Wl,-rpath,{tlib}", "-Wl,--no-as-needed", "-ltorch_hip", "-Wl,--as-needed",
             "-L", os.path.join(sysconfig.get_config_var("LIBDIR") or "/usr/lib"), f"-lpython{sysconfig.get_python_version()}"]
@@ -113,4 +125,6 @@ if __name__ == "__main__":
     print(build_dropin_check(force="--force" in sys.argv))
     print(build_dropin_check(force="--force" in sys.argv, groups=True))
     print(build_dropin_check(force="--force" in sys.argv, groups="dist"))
+    for g in ("render_ref", "render", "render_loss"):
+        print(build_dropin_check(force="--force" in sys.argv, groups=g))
     print(build_fused_check(force="--force" in sys.argv))

@@ -4,7 +4,17 @@
 //   dropin_check <dir> <P> <W> <H> <deg> <iters>
 // reads  <dir>/{xyz,scaling,rotation,opacity,dc,rest,view,proj,campos,gt}.f32 and scalars.f32 (tanfovx, tanfovy, 4 lims),
 // writes <dir>/out_{image,xyz,scaling,rotation,opacity,dc,rest}.f32 after <iters> steps (image = last render).
+#ifdef GSLIC_CHECK_RENDER
+// render() behind the reference's own signature (src/rasterizer/renderer.h, read in place) on stand-in Camera / GaussianModel types
+// (shim/standin: the reference's camera.h / gaussian.h need Eigen / OpenCV / PCL).  Linked either with the REFERENCE's renderer.cpp
+// (dropin_check_render_ref) or with this repository's drop-in replacement shim/renderer.cpp (dropin_check_render).
+#include "rasterizer/renderer.h"    // reference (includes rasterizer.h)
+#else
 #include "rasterizer/rasterizer.h"  // reference
+#endif
+#ifdef GSLIC_ONE_NODE_LOSS
+#include "loss_utils_fused.h"       // optional one-node loss (this repo)
+#endif
 #include "loss_utils.h"             // reference
 #include "optim_utils.h"            // reference
 #ifdef GSLIC_DIST
@@ -13,6 +23,8 @@
 #include <unistd.h>
 #endif
 
+#include <chrono>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -75,7 +87,24 @@ int main(int argc, char** argv)
     opt.add_param_group(g5); opt.param_groups()[5].options().set_lr(1e-3);
 
     torch::Tensor image;
+    const bool quiet = std::getenv("GSLIC_CHECK_TIME") != nullptr;   // no per-iteration .item() synchronisation: the run is timed
+    auto t_start = std::chrono::steady_clock::now();
+#ifdef GSLIC_CHECK_RENDER
+    auto cam = std::make_shared<Camera>();
+    cam->image_height_ = (int)H; cam->image_width_ = (int)W;
+    cam->FoVx_ = 2.0f * std::atan(s[0]); cam->FoVy_ = 2.0f * std::atan(s[1]);   // render() takes tan(FoV / 2) of these (renderer.cpp:31-32)
+    cam->limx_neg_ = s[2]; cam->limx_pos_ = s[3]; cam->limy_neg_ = s[4]; cam->limy_pos_ = s[5];
+    cam->world_view_transform_ = view; cam->full_proj_transform_ = proj; cam->camera_center_ = campos;
+    auto pc = std::make_shared<GaussianModel>();
+    pc->sh_degree_ = deg;
+    pc->xyz_ = xyz; pc->features_dc_ = dc; pc->features_rest_ = rest; pc->opacity_ = opacity; pc->scaling_ = scaling; pc->rotation_ = rotation;
+#endif
     for (int it = 0; it < iters; it++) {
+#ifdef GSLIC_CHECK_RENDER
+        auto render_pkg = render(cam, pc, bg, pc->apply_exposure_);        // gaussian.cpp:683
+        image = std::get<0>(render_pkg);
+        torch::Tensor radii = std::get<4>(render_pkg);
+#else
         // render() (renderer.cpp:21-88) without the Camera/GaussianModel wrappers (those need Eigen/OpenCV/PCL)
         GaussianRasterizationSettings rs((int)H, (int)W, s[0], s[1], s[2], s[3], s[4], s[5], bg, 1.0f, view, proj, deg, campos, false, false,
                                          false, 0.0f);
@@ -86,11 +115,16 @@ int main(int argc, char** argv)
                                       torch::nn::functional::normalize(rotation), cov3D_precomp);
         image = std::get<0>(res);
         torch::Tensor radii = std::get<1>(res);
+#endif
         // optimize() body (gaussian.cpp:685-707)
+#ifdef GSLIC_ONE_NODE_LOSS
+        auto loss = loss_utils::l1_ssim_loss(image, gt, 0.2);
+#else
         auto Ll1 = loss_utils::l1_loss(image, gt);
         torch::Tensor iu = image.unsqueeze(0), gu = gt.unsqueeze(0);
         auto ssim_value = loss_utils::fused_ssim(iu, gu);
         auto loss = (1.0 - 0.2) * Ll1 + 0.2 * (1.0 - ssim_value);
+#endif
         loss.backward();
         auto visible = radii > 0;
 #ifdef GSLIC_DIST
@@ -101,7 +135,13 @@ int main(int argc, char** argv)
         opt.set_visibility_and_N(visible, xyz.size(0));
         opt.step();
         opt.zero_grad(true);
-        std::cout << "iter " << it << " loss " << loss.item<float>() << " visible " << visible.sum().item<int>() << std::endl;
+        if (!quiet) std::cout << "iter " << it << " loss " << loss.item<float>() << " visible " << visible.sum().item<int>() << std::endl;
+        if (quiet && it == 2) { torch::cuda::synchronize(); t_start = std::chrono::steady_clock::now(); }
+    }
+    if (quiet && iters > 3) {   // timing mode (GSLIC_CHECK_TIME=1): views per second over the iterations after three warm-up ones
+        torch::cuda::synchronize();
+        const double sec = std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - t_start).count();
+        std::cout << "views_per_s " << (iters - 3) / sec << " ms_per_step " << 1e3 * sec / (iters - 3) << std::endl;
     }
 #ifdef GSLIC_DIST
     if (rank != 0) { torch::cuda::synchronize(); std::cout.flush(); _exit(0); }   // replicas are identical: rank 0 reports

@@ -395,13 +395,19 @@ def allreduce_gradients(grads, visible):
     return out, vis.bool()
 
 
-def training_step(model, camera, gt_image, bg, lambda_dssim=LAMBDA_DSSIM, do_step=True):
-    """One iteration of optimize()'s loop (gaussian.cpp:674-716): render -> 0.8*L1 + 0.2*(1-SSIM) -> backward ->
-    sparse Adam.  Returns (loss tensor, visible mask)."""
-    image, _final_T, _pts, visible, _radii = render(camera, model, bg)
-    Ll1 = loss_utils.l1_loss(image, gt_image)
-    ssim_value = loss_utils.fused_ssim(image.unsqueeze(0), gt_image.unsqueeze(0))
-    loss = (1.0 - lambda_dssim) * Ll1 + lambda_dssim * (1.0 - ssim_value)
+def training_step(model, camera, gt_image, bg, lambda_dssim=LAMBDA_DSSIM, do_step=True, raw_render=None, one_node_loss=False):
+    """One iteration of optimize()'s loop (gaussian.cpp:674-716) the way the reference's host writes it: render -> 0.8*L1 + 0.2*(1-SSIM) ->
+    loss.backward() -> sparse Adam, on LibTorch autograd.  Returns (loss tensor, visible mask).
+    raw_render: passed to render() — None = its default (the drop-in renderer: activations inside the kernels), False = renderer.cpp as written
+    (getOpacity / getScaling / getRotation as LibTorch ops, the pure operator path).  one_node_loss: the optional loss_utils.l1_ssim_loss node
+    instead of the reference's l1_loss + fused_ssim lines (gaussian.cpp:685-691)."""
+    image, _final_T, _pts, visible, _radii = render(camera, model, bg, raw=raw_render)
+    if one_node_loss:
+        loss = loss_utils.l1_ssim_loss(image, gt_image, lambda_dssim)
+    else:
+        Ll1 = loss_utils.l1_loss(image, gt_image)
+        ssim_value = loss_utils.fused_ssim(image.unsqueeze(0), gt_image.unsqueeze(0))
+        loss = (1.0 - lambda_dssim) * Ll1 + lambda_dssim * (1.0 - ssim_value)
     loss.backward()
     if do_step:
         params = model.parameters()

@@ -88,7 +88,7 @@ def test_reference_host_code_drives_the_hip_kernels(tmp_path):
     cam.to_device(dev)
     bg = torch.zeros(3, device=dev)
     for _ in range(iters):
-        trainer.training_step(model, cam, gt.to(dev), bg)
+        trainer.training_step(model, cam, gt.to(dev), bg, raw_render=False)   # (the C++ program runs renderer.cpp as written)
     rd = lambda name, shape: np.fromfile(os.path.join(d, f"out_{name}.f32"), np.float32).reshape(shape)
     for name, t in (("xyz", model.xyz), ("scaling", model.scaling), ("rotation", model.rotation), ("opacity", model.opacity),
                     ("dc", model.features_dc), ("rest", model.features_rest)):
@@ -282,7 +282,7 @@ def test_reference_host_two_ranks_rccl(tmp_path):
     for _ in range(iters):
         acc, vis = None, None
         for k in range(2):
-            _loss, v = trainer.training_step(model, cams[k], gts[k].to(dev), bg, do_step=False)
+            _loss, v = trainer.training_step(model, cams[k], gts[k].to(dev), bg, do_step=False, raw_render=False)
             g = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in model.parameters()]
             model.optimizer.zero_grad(True)
             acc = g if acc is None else [a + b for a, b in zip(acc, g)]
@@ -293,3 +293,49 @@ def test_reference_host_two_ranks_rccl(tmp_path):
     for name, t in (("xyz", model.xyz), ("scaling", model.scaling), ("rotation", model.rotation), ("opacity", model.opacity),
                     ("dc", model.features_dc), ("rest", model.features_rest)):
         assert rel_err(rd(name, tuple(t.shape)), t.detach().cpu().numpy()) < 1e-5, name
+
+
+def test_dropin_renderer_cpp(tmp_path):
+    """shim/renderer.cpp — the drop-in replacement for the reference's src/rasterizer/renderer.cpp (same render() signature; the model's raw
+    parameters go to one autograd node whose kernels apply sigmoid / exp / normalize) — against the REFERENCE's renderer.cpp itself.  Both are
+    compiled with the reference's renderer.h, rasterizer.{h,cpp}, loss_utils.h and the host lines of gaussian.cpp:683-707 (dropin_check.cpp with
+    -DGSLIC_CHECK_RENDER; Camera / GaussianModel are the stand-ins of shim/standin, the reference's need Eigen / OpenCV / PCL), linked once with
+    each renderer, and run three optimisation steps on the same inputs.  Same image after three steps (1e-5), same parameters up to what Adam's
+    sign-like first steps do to last-bit gradient differences of near-zero elements (the bar of test_fused_training_tracks_dropin_training);
+    a third build adds the optional one-node loss (loss_utils_fused.h)."""
+    exe_ref = os.path.join(ROOT, "gaussian-lic_amd", "dropin_check_render_ref")
+    exe_new = os.path.join(ROOT, "gaussian-lic_amd", "dropin_check_render")
+    exe_loss = os.path.join(ROOT, "gaussian-lic_amd", "dropin_check_render_loss")
+    if not (os.path.exists(exe_ref) and os.path.exists(exe_new)):
+        pytest.skip("dropin_check_render(_ref) not built (needs /root/reference at build time)")
+    from gaussian_lic_amd.synthetic import gt_image
+    P, W, H, iters = 30000, 320, 240, 3
+    raw, sc, camd, cam = make_scene("random", P, W, H, 3, 43)
+    d = str(tmp_path)
+    w = lambda name, t: np.ascontiguousarray(t, np.float32).tofile(os.path.join(d, name + ".f32"))
+    for k, n in (("xyz", "xyz"), ("scaling", "scaling"), ("rotation", "rotation"), ("opacity", "opacity"), ("features_dc", "dc"), ("features_rest", "rest")):
+        w(n, raw[k].numpy())
+    w("view", cam.world_view_transform); w("proj", cam.full_proj_transform); w("campos", cam.camera_center)
+    w("gt", gt_image(H, W).numpy())
+    w("scalars", np.array([cam.tanfovx, cam.tanfovy, cam.limx_neg, cam.limx_pos, cam.limy_neg, cam.limy_pos], np.float32))
+    names = ("image", "xyz", "scaling", "rotation", "opacity", "dc", "rest")
+    rd = lambda name: np.fromfile(os.path.join(d, f"out_{name}.f32"), np.float32)
+    lrs = dict(xyz=1.6e-4, dc=2.5e-3, rest=2.5e-3 / 20.0, opacity=5e-2, scaling=5e-3, rotation=1e-3)
+
+    def run(exe):
+        r = subprocess.run([exe, d, str(P), str(W), str(H), "3", str(iters)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        losses = [float(l.split()[3]) for l in r.stdout.splitlines() if l.startswith("iter ")]
+        return {n: rd(n).copy() for n in names}, losses
+
+    ref, loss_ref = run(exe_ref)
+    for exe in (exe_new, exe_loss):
+        if not os.path.exists(exe):
+            continue
+        got, loss_got = run(exe)
+        np.testing.assert_allclose(loss_got, loss_ref, rtol=2e-5)
+        assert rel_err(got["image"], ref["image"]) < 2e-4, os.path.basename(exe)      # (the image after three Adam steps: see the parameter bar)
+        for n in names[1:]:
+            dlt = np.abs(got[n] - ref[n])
+            assert (dlt > 1e-5 * np.abs(ref[n]).max()).mean() < 2e-3, (os.path.basename(exe), n)
+            assert dlt.max() <= 2 * iters * lrs[n] * 1.01, (os.path.basename(exe), n, float(dlt.max()))
