@@ -352,7 +352,7 @@ def main():
         value_long = {"value": round(n_long * world / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_long, 3), "steps": n_long,
                       "seconds": round(sec, 3)}
 
-    other, graphed_res, growth, cpp_host, math_legs, cycle = None, None, None, None, None, None
+    other, graphed_res, growth, cpp_host, math_legs, cycle, pose_leg = None, None, None, None, None, None, None
     if args.mode == "train" and args.host == "fused" and args.views > 1 and world == 1 and not trainer._dist_on() and not args.graph and (not args.no_extras or "--views" in sys.argv):
         try:
             cycle = views_cycle(args, model, bg, dev, args.views, min(args.steps, 200))
@@ -401,6 +401,15 @@ def main():
                            "host_round_trips_per_step": 0, "steps_repeated_for_capacity": repeated, "capacity_R": gs.bufs.cap_R, "capacity_B": gs.bufs.cap_B}
             del gs
         if world == 1 and not trainer._dist_on() and args.host == "fused":
+            # joint map + camera-pose iteration (the "cam" of the north-star): parameter gradients and the camera gradient from ONE backward
+            # (gslic_rasterize_backward_camera), Adam as its own launch, the se(3) chain and the pose update on the host (35 floats per step)
+            try:
+                pcam = synthetic_camera(W, H, 3).to_device(dev)
+                sec = timed_loop(lambda: trainer.training_step_with_pose(model, pcam, gt, bg, pose_lr=1e-6), n_extra)
+                pose_leg = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra,
+                            "what": "forward + loss + backward with camera gradient + split Adam + se(3) pose step per view (one host synchronisation per step)"}
+            except Exception as ex:
+                pose_leg = {"error": str(ex)[:200]}
             cpp_host = cpp_fused_host(args, model, cam, gt, n_extra)
             torch.cuda.empty_cache()
             growth = growth_schedule(args, dev)
@@ -528,6 +537,7 @@ def main():
         "other_host_path": other,
         "graphed": graphed_res,
         "cpp_fused_host": cpp_host,
+        "joint_pose_step": pose_leg,
         "growth_schedule": growth,
         "extend": None if args.mode != "slam" else {"calls": slam["calls"], "inserted": slam["inserted"], "final_gaussians": model.P,
                                                     "ms_per_call": round(slam["ms"] / max(slam["calls"], 1), 3)},

@@ -19,6 +19,7 @@ class Camera:
     def set_pose(self, R_wc, t_wc):
         R_wc = np.asarray(R_wc, np.float64)
         t_wc = np.asarray(t_wc, np.float64)
+        self.R_wc, self.t_wc = R_wc.copy(), t_wc.copy()
         R_cw = R_wc.T
         t_cw = -R_wc.T @ t_wc
         Rt = np.zeros((4, 4), np.float32)                      # camera.h:70-77 (trans_=0, scale_=1)
@@ -51,6 +52,35 @@ class Camera:
         self.tanfovx = np.float32(np.tan(np.float32(self.FoVx * np.float32(0.5))))
         self.tanfovy = np.float32(np.tan(np.float32(self.FoVy * np.float32(0.5))))
 
+    # ---- camera pose as an optimisation variable (the "cam" of the north-star; the reference has no counterpart: rasterizer.cpp:171-182) --------
+    def pose_gradient(self, dL_dviewmatrix, dL_dprojmatrix, dL_dcampos):
+        """Chains the three camera gradients of gslic_rasterize_backward_camera (element order of the inputs: float[16] with (r, c) at [4c + r])
+        to the six coordinates of a LEFT pose increment  T_cw <- exp(xi^) T_cw,  xi = (rho, phi) in se(3)  (rho: translation, phi: rotation,
+        both in the camera frame).  With V = [R | t] the world-to-camera matrix, the full projection P V and the centre c = -R^T t:
+            G = dL/dV + P^T dL/d(PV)            (top three rows)
+            G_R = G[:, :3] - t g_c^T,   G_t = G[:, 3] - R g_c
+            dL/drho = G_t,   dL/dphi = vee(M - M^T) + t x G_t,   M = G_R R^T
+        Returns float64 [6] = (dL/drho, dL/dphi)."""
+        f64 = lambda a, shape: np.asarray(a.detach().cpu().numpy() if hasattr(a, "detach") else a, np.float64).reshape(shape)
+        Gv, Gp, gc = f64(dL_dviewmatrix, (4, 4)).T, f64(dL_dprojmatrix, (4, 4)).T, f64(dL_dcampos, (3,))   # stored transposed -> math matrices
+        V = np.asarray(self.world_view_transform, np.float64).T
+        Pm = np.asarray(self.projection_matrix, np.float64).T
+        R, t = V[:3, :3], V[:3, 3]
+        G = (Gv + Pm.T @ Gp)[:3, :]
+        G_R = G[:, :3] - np.outer(t, gc)
+        G_t = G[:, 3] - R @ gc
+        M = G_R @ R.T
+        dphi = np.array([M[2, 1] - M[1, 2], M[0, 2] - M[2, 0], M[1, 0] - M[0, 1]]) + np.cross(t, G_t)
+        return np.concatenate([G_t, dphi])
+
+    def apply_pose_increment(self, xi):
+        """T_cw <- exp(xi^) T_cw (xi = (rho, phi) as in pose_gradient): every derived matrix is recomputed the way camera.h:70-110 does."""
+        E = se3_exp(xi)
+        R_cw, t_cw = self.R_wc.T, -self.R_wc.T @ self.t_wc
+        R_new, t_new = E[:3, :3] @ R_cw, E[:3, :3] @ t_cw + E[:3, 3]
+        self.set_pose(R_new.T, -R_new.T @ t_new)
+        return self
+
     def to_device(self, device):
         """Attach device copies of the three tensors the rasterizer reads (camera.h:86,109,60-61 keep them on CUDA)."""
         import torch
@@ -68,6 +98,22 @@ class Camera:
                     tanfovx=float(self.tanfovx), tanfovy=float(self.tanfovy),
                     limx_neg=float(self.limx_neg), limx_pos=float(self.limx_pos),
                     limy_neg=float(self.limy_neg), limy_pos=float(self.limy_pos))
+
+
+def se3_exp(xi):
+    """exp of (rho, phi) in se(3) as a 4x4 matrix (Rodrigues + the left Jacobian for the translation), float64."""
+    xi = np.asarray(xi, np.float64)
+    rho, phi = xi[:3], xi[3:]
+    th = float(np.linalg.norm(phi))
+    K = np.array([[0, -phi[2], phi[1]], [phi[2], 0, -phi[0]], [-phi[1], phi[0], 0]])
+    if th < 1e-8:
+        Rm, Vm = np.eye(3) + K + 0.5 * K @ K, np.eye(3) + 0.5 * K + K @ K / 6.0
+    else:
+        a, b, c = math.sin(th) / th, (1.0 - math.cos(th)) / th ** 2, (th - math.sin(th)) / th ** 3
+        Rm, Vm = np.eye(3) + a * K + b * K @ K, np.eye(3) + b * K + c * K @ K
+    E = np.eye(4)
+    E[:3, :3], E[:3, 3] = Rm, Vm @ rho
+    return E
 
 
 def synthetic_camera(W, H, view_index=None):

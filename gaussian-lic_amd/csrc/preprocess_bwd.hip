@@ -504,7 +504,11 @@ __device__ __forceinline__ void bwd_rest(const PreprocessBwdArgs& a, const int i
     const float g_tz = -fx * tz2 * gJ00 - fy * tz2 * gJ11 + (2 * fx * t0) * tz3 * gJ02 + (2 * fy * t1) * tz3 * gJ12;
     if constexpr (CAM) {
         const float pc[4] = {mx3, my3, mz3, 1.0f};
-        const float gt[3] = {g_tx, g_ty, g_tz};
+        // exact through the clamp (the parameter gradients keep the reference's convention, backward.cu:225-233: a clamped t.x = lim t.z
+        // still moves with t.z; for the camera that term is kept: + lim * the unmasked dL/dt.x — oracle/gs_oracle.c, same lines)
+        const float ex = (1.0f - keep_x) * (t0 * tz) * (-fx * tz2 * gJ02);
+        const float ey = (1.0f - keep_y) * (t1 * tz) * (-fy * tz2 * gJ12);
+        const float gt[3] = {g_tx, g_ty, g_tz + ex + ey};
         // t = V [p, 1]: d/dV[4c + r] = dL/dt_r * p_c
 #pragma unroll
         for (int c = 0; c < 4; c++)

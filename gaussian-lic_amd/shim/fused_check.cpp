@@ -10,6 +10,7 @@
 #include "gslic_fused.h"
 
 #include <chrono>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -53,6 +54,11 @@ int main(int argc, char** argv)
 
     // trainingSetup (gaussian.cpp:399-418) with config/fastlivo.yaml learning rates
     gslic::FusedStep fs({xyz, dc, rest, opacity, scaling, rotation}, {1.6e-4f * ls, 2.5e-3f * ls, (float)(2.5e-3 / 20.0) * ls, 5e-2f * ls, 5e-3f * ls, 1e-3f * ls}, deg);
+    if (std::getenv("GSLIC_CHECK_POSE")) {   // the camera-pose gradient of the initial map (before any step), six numbers
+        const auto g = fs.pose_gradient(cam, gt);
+        std::cout.precision(9);
+        std::cout << "pose_gradient " << g[0] << " " << g[1] << " " << g[2] << " " << g[3] << " " << g[4] << " " << g[5] << std::endl;
+    }
     for (int it = 0; it < iters; it++) {
         torch::Tensor terms = fs.step(cam, gt);
         std::cout << "iter " << it << " loss " << fs.loss_value(terms) << " visible " << fs.visible().sum().item<int>() << std::endl;

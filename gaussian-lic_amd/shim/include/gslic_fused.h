@@ -173,6 +173,69 @@ public:
         return terms;
     }
 
+    // Gradient of the training loss w.r.t. a LEFT se(3) increment of the camera pose, T_cw <- exp(xi^) T_cw, xi = (rho, phi) — the "cam" of the
+    // north-star; the reference's autograd node returns nothing for its camera inputs (rasterizer.cpp:171-182).  Forward + loss kernels +
+    // gslic_rasterize_backward_camera (the map is NOT updated), then the chain of gaussian-lic_amd/camera.py:Camera.pose_gradient:
+    //   G = dL/dV + Proj^T dL/d(Proj V) (top three rows; Proj = (Proj V) V^-1),  G_R = G[:, :3] - t g_c^T,  G_t = G[:, 3] - R g_c,
+    //   dL/drho = G_t,  dL/dphi = vee(M - M^T) + t x G_t,  M = G_R R^T.          Returns {d/drho[3], d/dphi[3]}; synchronises (35 floats to the host).
+    std::array<double, 6> pose_gradient(const FusedCamera& cam, const torch::Tensor& gt_image)
+    {
+        torch::NoGradGuard ng;
+        const int64_t P = prm_[0].size(0);
+        const int W = cam.image_width, H = cam.image_height;
+        gslic_raster_params rp{};
+        rp.P = (int32_t)P; rp.D = deg_; rp.M = prm_[2].numel() ? (int32_t)prm_[2].size(1) : 0; rp.width = W; rp.height = H;
+        rp.tan_fovx = cam.tanfovx; rp.tan_fovy = cam.tanfovy;
+        rp.limx_neg = cam.limx_neg; rp.limx_pos = cam.limx_pos; rp.limy_neg = cam.limy_neg; rp.limy_pos = cam.limy_pos;
+        rp.scale_modifier = 1.0f; rp.raw_params = 1;
+        auto fo = prm_[0].options().requires_grad(false);
+        torch::Tensor image = torch::empty({3, H, W}, fo), final_T = torch::empty({H, W}, fo), radii = torch::empty({P}, fo.dtype(torch::kInt32));
+        torch::Tensor d1 = torch::empty({3, H, W}, fo), d2 = torch::empty({3, H, W}, fo), d3 = torch::empty({3, H, W}, fo), dL = torch::empty({3, H, W}, fo);
+        torch::Tensor partials = torch::empty({gslic_loss_partials_count(1, 3, H, W)}, fo), terms = torch::empty({2}, fo), camg = torch::zeros({35}, fo);
+        std::array<torch::Tensor, 6> g;
+        for (int i = 0; i < 6; i++) g[i] = torch::empty_like(prm_[i], fo);
+        const float *xyz = f(prm_[0]), *dc = f(prm_[1]), *rest = f(prm_[2]), *op = f(prm_[3]), *sc = f(prm_[4]), *rot = f(prm_[5]);
+        const float *view = f(cam.world_view_transform), *proj = f(cam.full_proj_transform), *cpos = f(cam.camera_center);
+        int32_t R = 0, B = 0;
+        check(gslic_rasterize_forward(&rp, grow_cb, &scratch_[0], grow_cb, &scratch_[1], grow_cb, &scratch_[2], grow_cb, &scratch_[3], f(bg_), xyz, dc, rest,
+                                      nullptr, op, sc, rot, nullptr, view, proj, cpos, image.data_ptr<float>(), final_T.data_ptr<float>(),
+                                      radii.data_ptr<int32_t>(), &R, &B, current_stream()), "gslic_rasterize_forward");
+        check(gslic_l1_ssim_loss_forward(1, 3, H, W, 0.01f * 0.01f, 0.03f * 0.03f, f(image), f(gt_image), d1.data_ptr<float>(), d2.data_ptr<float>(),
+                                         d3.data_ptr<float>(), partials.data_ptr<float>(), terms.data_ptr<float>(), current_stream()), "gslic_l1_ssim_loss_forward");
+        check(gslic_l1_ssim_loss_backward(1, 3, H, W, lambda_dssim_, f(image), f(gt_image), f(d1), f(d2), f(d3), dL.data_ptr<float>(), current_stream()),
+              "gslic_l1_ssim_loss_backward");
+        auto w = [](torch::Tensor& t) { return t.numel() ? t.data_ptr<float>() : nullptr; };
+        float* cg = camg.data_ptr<float>();
+        check(gslic_rasterize_backward_camera(&rp, R, B, f(bg_), xyz, dc, rest, nullptr, sc, rot, nullptr, view, proj, cpos, radii.data_ptr<int32_t>(),
+                                              cptr(scratch_[0]), cptr(scratch_[1]), cptr(scratch_[2]), cptr(scratch_[3]), f(dL), nullptr, nullptr, w(g[3]), nullptr,
+                                              w(g[0]), nullptr, w(g[1]), w(g[2]), w(g[4]), w(g[5]), lambda_erank_, cg, cg + 16, cg + 32, current_stream()),
+              "gslic_rasterize_backward_camera");
+        torch::Tensor hc = camg.to(torch::kCPU), hv = cam.world_view_transform.to(torch::kCPU).contiguous(), hp = cam.full_proj_transform.to(torch::kCPU).contiguous();
+        return se3_pose_gradient(hv.data_ptr<float>(), hp.data_ptr<float>(), hc.data_ptr<float>(), hc.data_ptr<float>() + 16, hc.data_ptr<float>() + 32);
+    }
+    // the chain alone, on host arrays in the element order of the kernels' inputs (float[16] with (r, c) at [4c + r])
+    static std::array<double, 6> se3_pose_gradient(const float* view16, const float* fullproj16, const float* dview16, const float* dproj16, const float* dcampos3)
+    {
+        auto at = [](const float* m, int r, int c) { return (double)m[4 * c + r]; };
+        double V[4][4], PV[4][4], Vi[4][4], Pj[4][4];
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { V[r][c] = at(view16, r, c); PV[r][c] = at(fullproj16, r, c); }
+        // V^-1 of a rigid [R | t; 0 0 0 1]: [R^T | -R^T t]
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Vi[r][c] = V[c][r]; Vi[r][3] = -(V[0][r] * V[0][3] + V[1][r] * V[1][3] + V[2][r] * V[2][3]); }
+        Vi[3][0] = Vi[3][1] = Vi[3][2] = 0.0; Vi[3][3] = 1.0;
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { Pj[r][c] = 0; for (int k = 0; k < 4; k++) Pj[r][c] += PV[r][k] * Vi[k][c]; }   // Proj = (Proj V) V^-1
+        double G[3][4];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) { G[r][c] = at(dview16, r, c); for (int k = 0; k < 4; k++) G[r][c] += Pj[k][r] * at(dproj16, k, c); }
+        const double gc[3] = {dcampos3[0], dcampos3[1], dcampos3[2]}, t[3] = {V[0][3], V[1][3], V[2][3]};
+        double GR[3][3], Gt[3], M[3][3];
+        for (int j = 0; j < 3; j++) {
+            for (int i = 0; i < 3; i++) GR[j][i] = G[j][i] - t[j] * gc[i];
+            Gt[j] = G[j][3] - (V[j][0] * gc[0] + V[j][1] * gc[1] + V[j][2] * gc[2]);
+        }
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { M[i][j] = 0; for (int k = 0; k < 3; k++) M[i][j] += GR[i][k] * V[j][k]; }   // G_R R^T
+        return {Gt[0], Gt[1], Gt[2], M[2][1] - M[1][2] + (t[1] * Gt[2] - t[2] * Gt[1]), M[0][2] - M[2][0] + (t[2] * Gt[0] - t[0] * Gt[2]),
+                M[1][0] - M[0][1] + (t[0] * Gt[1] - t[1] * Gt[0])};
+    }
+
     float loss_value(const torch::Tensor& terms) const   // (1 - lambda) L1 + lambda (1 - SSIM), gaussian.cpp:685-691; synchronises
     {
         torch::Tensor t = terms.to(torch::kCPU);

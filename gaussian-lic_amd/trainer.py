@@ -420,6 +420,62 @@ def training_step(model, camera, gt_image, bg, lambda_dssim=LAMBDA_DSSIM, do_ste
     return loss.detach(), visible
 
 
+def pose_gradient(model, camera, gt_image, bg, fused_loss=None):
+    """dL/dxi of the training loss w.r.t. a left se(3) increment of the camera pose (Camera.pose_gradient) for the current map: forward -> loss
+    kernels -> gslic_rasterize_backward_camera -> the chain.  The map is not touched.  Returns (float64 [6] = (d/drho, d/dphi), terms).
+    One step of pose refinement is `camera.apply_pose_increment(-lr * g); camera.to_device(dev)`."""
+    from . import rasterizer as rz
+    fl = fused_loss or _default_fused_loss()
+    e = torch.empty(0, device=model.device)
+    cam = camera
+    with torch.no_grad():
+        xyz, dc, rest = model.xyz.detach(), model.features_dc.detach(), model.features_rest.detach()
+        op, sc, rot = model.opacity.detach(), model.scaling.detach(), model.rotation.detach()
+        (R, B, image, _final_T, radii, geom, binning, img, sample) = rz.rasterize_gaussians(
+            bg, xyz, e, op, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
+            cam.image_height, cam.image_width, float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dc, rest,
+            model.sh_degree, cam.d_camera_center, False, False, False, raw_params=True)
+        dL_dimage, terms = fl.forward_backward(image, gt_image)
+        out = rz.rasterize_gaussians_backward(
+            bg, xyz, radii, e, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
+            float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dL_dimage, dc, rest, model.sh_degree,
+            cam.d_camera_center, geom, R, binning, img, B, sample, model.lambda_erank, False, raw_params=True, camera_grads=True)
+    return cam.pose_gradient(out[9], out[10], out[11]), terms
+
+
+def training_step_with_pose(model, camera, gt_image, bg, pose_lr=0.0, fused_loss=None):
+    """One joint map + pose iteration: forward -> loss kernels -> gslic_rasterize_backward_camera (parameter gradients AND the camera gradient in
+    one pass) -> masked Adam on the map -> `camera` moved by -pose_lr * dL/dxi (left se(3) increment; 35 floats cross to the host, which is the
+    step's only synchronisation).  Returns (terms, visible, dL/dxi)."""
+    from . import rasterizer as rz
+    fl = fused_loss or _default_fused_loss()
+    dev = model.device
+    e = torch.empty(0, device=dev)
+    cam = camera
+    with torch.no_grad():
+        xyz, dc, rest = model.xyz.detach(), model.features_dc.detach(), model.features_rest.detach()
+        op, sc, rot = model.opacity.detach(), model.scaling.detach(), model.rotation.detach()
+        (R, B, image, _final_T, radii, geom, binning, img, sample) = rz.rasterize_gaussians(
+            bg, xyz, e, op, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
+            cam.image_height, cam.image_width, float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dc, rest,
+            model.sh_degree, cam.d_camera_center, False, False, False, raw_params=True)
+        dL_dimage, terms = fl.forward_backward(image, gt_image)
+        slab = getattr(model, "_grad_slab", None)
+        if slab is None or slab.P != model.P:
+            slab = model._grad_slab = GradSlab(model)
+        out = rz.rasterize_gaussians_backward(
+            bg, xyz, radii, e, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
+            float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dL_dimage, dc, rest, model.sh_degree,
+            cam.d_camera_center, geom, R, binning, img, B, sample, model.lambda_erank, False, raw_params=True, out=slab.views, camera_grads=True)
+        visible = radii > 0
+        model.optimizer.set_visibility_and_N(visible, model.P)
+        model.optimizer.step(slab.grads(model))
+        g = cam.pose_gradient(out[9], out[10], out[11])
+        if pose_lr:
+            cam.apply_pose_increment(-float(pose_lr) * g).to_device(dev)
+    return terms, visible, g
+
+
 def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=True, adam_in_backward=True):
     """The same iteration as training_step — identical arithmetic up to fp32 rounding — on the fused entry points
     (SURVEY.md §8f row 2): sigmoid / exp / normalize and their backward run inside preprocess / preprocess_bwd (raw_params),

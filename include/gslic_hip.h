@@ -278,8 +278,9 @@ int gslic_sh_grad_from_rgb_adam(
  * north-star; no reference counterpart: the reference's autograd node returns an undefined tensor for the raster settings,
  * src/rasterizer/rasterizer.cpp:171-182).  viewmatrix, projmatrix and cam_pos are treated as the three independent inputs they
  * are at this boundary; a host that derives them from a pose chains through its own (tiny) LibTorch graph:
- *   dL_dviewmatrix [16]  same element order as viewmatrix ([4c+r]); rows 0..2 carry gradient — through t = V [p,1] (cov2D Jacobian,
- *                        clamp-masked like backward.cu:225-233) and through the rotation part W of T = W J (backward.cu:180-197)
+ *   dL_dviewmatrix [16]  same element order as viewmatrix ([4c+r]); rows 0..2 carry gradient — through t = V [p,1] (cov2D Jacobian; EXACT
+ *                        through the frustum clamp: a clamped t.x = lim t.z still moves with t.z, a term the reference's parameter
+ *                        gradients drop, backward.cu:225-233, and this one keeps) and through the rotation part W of T = W J (:180-197)
  *   dL_dprojmatrix [16]  rows 0, 1, 3 — through p_hom = P [p,1] -> mean2D (backward.cu:339-350)
  *   dL_dcampos     [3]   through the SH view direction normalize(p - campos) (backward.cu:27-136)
  * All three are sums over the visible Gaussians, reduced in a fixed order (bit-reproducible).  Depth ordering, culling and the

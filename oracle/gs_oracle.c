@@ -674,7 +674,14 @@ static void preprocess_backward_impl(int P, int D, int M, const real* means, con
                             (2 * fy * c2.t[1]) * tz3 * dL_dJ12;
         if (cam) {
             const real pc[4] = {mean[0], mean[1], mean[2], RC(1.)};
-            const real gt[3] = {dL_dtx, dL_dty, dL_dtz};
+            /* The camera gradient is the EXACT derivative of the forward: where the reference clamps t.x / t.z to the frustum limit
+             * (forward.cu:88-91) the clamped t.x = lim * t.z still moves with t.z, a dependence the reference's parameter gradient drops
+             * (x_grad_mul zeroes dL/dt.x and nothing is added to dL/dt.z: backward.cu:225-233 — reproduced above for dL_dmeans).  For the
+             * camera that term is kept: d/dt.z += lim * (the unmasked dL/dt.x), lim = clamped t.x / t.z — finite differences over a pose
+             * with clamped Gaussians then agree (tests/test_camera_grad.py). */
+            const real ex = (RC(1.) - x_grad_mul) * (c2.t[0] * tz) * (-fx * tz2 * dL_dJ02);
+            const real ey = (RC(1.) - y_grad_mul) * (c2.t[1] * tz) * (-fy * tz2 * dL_dJ12);
+            const real gt[3] = {dL_dtx, dL_dty, dL_dtz + ex + ey};
             for (int c = 0; c < 4; c++)
                 for (int r = 0; r < 3; r++) camacc[4 * c + r] += (double)(gt[r] * pc[c]);          /* t = V [p,1] */
             const real J00 = fx * tz, J11 = fy * tz, J02 = -(fx * c2.t[0]) * tz2, J12 = -(fy * c2.t[1]) * tz2;
