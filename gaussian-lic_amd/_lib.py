@@ -40,7 +40,8 @@ EXPORTS = [
     "gslic_profile_enable", "gslic_profile_reset", "gslic_profile_collect", "gslic_profile_num_kernels",
     "gslic_profile_kernel_name", "gslic_profile_get", "gslic_debug_export", "gslic_extend_select", "gslic_extend_emit", "gslic_loss_partials_count", "gslic_l1_ssim_loss_forward",
     "gslic_l1_ssim_loss_backward", "gslic_set_math_mode", "gslic_rasterize_forward_capacity", "gslic_rasterize_backward_rgb",
-    "gslic_rasterize_backward_rgb_rows", "gslic_sh_grad_from_rgb", "gslic_sh_grad_from_rgb_adam",
+    "gslic_rasterize_backward_rgb_rows", "gslic_sh_grad_from_rgb", "gslic_sh_grad_from_rgb_adam", "gslic_rasterize_backward_rgb_payload",
+    "gslic_sh_grad_from_rgb_adam_all",
 ]
 
 _lib = None
@@ -86,6 +87,10 @@ def lib():
         [ctypes.POINTER(RasterParams), i32, i32] + [vp] * 12 + [vp] * 4 + [vp] + [vp] * 5 + [f32, vp])
     L.gslic_rasterize_backward_rgb_rows.argtypes = (
         [ctypes.POINTER(RasterParams), i32, i32] + [vp] * 12 + [vp] * 4 + [vp] + [vp] * 5 + [f32, i32, i32, i32, vp])
+    L.gslic_rasterize_backward_rgb_payload.argtypes = (
+        [ctypes.POINTER(RasterParams), i32, i32] + [vp] * 12 + [vp] * 4 + [vp] + [vp] * 5 + [f32, vp, vp, vp])
+    L.gslic_sh_grad_from_rgb_adam_all.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, vp, ctypes.c_int64, vp, ctypes.POINTER(AdamFused), vp, vp, vp, vp,
+                                                  ctypes.c_int64, vp]
     L.gslic_sh_grad_from_rgb.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, ctypes.c_int64, vp]
     L.gslic_sh_grad_from_rgb_adam.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, vp, ctypes.POINTER(AdamFused), vp, vp, ctypes.c_int64, vp]
     L.gslic_adam_update.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, u32, u32, vp]
@@ -102,7 +107,7 @@ def lib():
     L.gslic_l1_ssim_loss_forward.argtypes = [i32, i32, i32, i32, f32, f32] + [vp] * 7 + [vp]
     L.gslic_l1_ssim_loss_backward.argtypes = [i32, i32, i32, i32, f32] + [vp] * 6 + [vp]
     L.gslic_set_math_mode.argtypes = [i32]
-    if L.gslic_abi_version() != 5:
+    if L.gslic_abi_version() != 6:
         raise GslicError("libgslic_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -535,7 +535,8 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
                              char* sample_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                              float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_ddc, float* dL_dsh, float* dL_dscale,
                              float* dL_drot, float lambda_erank, const gslic_adam_fused* adam, float* const dL_dcam[3], void* stream,
-                             float* dL_drgb = nullptr, int32_t row_begin = 0, int32_t row_end = -1, bool skip_blend = false)
+                             float* dL_drgb = nullptr, int32_t row_begin = 0, int32_t row_end = -1, bool skip_blend = false, uint8_t* vis_out = nullptr,
+                             float* campos_out = nullptr)
 {
     (void)background; (void)dc;
     GS_TRY(check_params(prm));
@@ -601,6 +602,7 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
     }
     pb.status = geom.flags;
     pb.cam_partials = nullptr; pb.cam_out = nullptr;
+    pb.vis_out = vis_out; pb.campos_out = campos_out;
     if (dL_dcam) {
         // scratch: the depth-sort ping-pong arrays of the geometry buffer are dead after the forward.  The per-wave partial rows
         // (128 B per wave; the generic 256-thread path writes 4 rows per block even when P < 256, i.e. up to 512 * ceil(P / 256) B)
@@ -646,6 +648,20 @@ int gslic_rasterize_backward_rgb(const gslic_raster_params* prm, int32_t R, int3
                                    nullptr, nullptr, stream, dL_drgb);
 }
 
+int gslic_rasterize_backward_rgb_payload(const gslic_raster_params* prm, int32_t R, int32_t B, const float* background, const float* means3D,
+                                         const float* dc, const float* shs, const float* colors_precomp, const float* scales,
+                                         const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                         const float* cam_pos, const int32_t* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
+                                         char* sample_buffer, const float* dL_dpix, float* dL_dopacity, float* dL_dmean3D, float* dL_drgb,
+                                         float* dL_dscale, float* dL_drot, float lambda_erank, uint8_t* vis_out, float* campos_out, void* stream)
+{
+    if (!dL_drgb) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_rasterize_backward_rgb_payload: dL_drgb is NULL");
+    return rasterize_backward_impl(prm, R, B, background, means3D, dc, shs, colors_precomp, scales, rotations, cov3D_precomp, viewmatrix,
+                                   projmatrix, cam_pos, radii, geom_buffer, binning_buffer, img_buffer, sample_buffer, dL_dpix, nullptr,
+                                   nullptr, dL_dopacity, nullptr, dL_dmean3D, nullptr, nullptr, nullptr, dL_dscale, dL_drot, lambda_erank,
+                                   nullptr, nullptr, stream, dL_drgb, 0, -1, false, vis_out, campos_out);
+}
+
 int gslic_rasterize_backward_rgb_rows(const gslic_raster_params* prm, int32_t R, int32_t B, const float* background, const float* means3D,
                                       const float* dc, const float* shs, const float* colors_precomp, const float* scales,
                                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
@@ -672,7 +688,8 @@ int gslic_sh_grad_from_rgb(int32_t P, int32_t D, int32_t M, int32_t n_views, con
     a.P = P; a.D = D; a.M = M; a.n_views = n_views; a.input_is_ddc = input_is_ddc ? 1 : 0;
     a.means3D = means3D; a.campos_all = campos_all; a.rgb_all = rgb_all; a.dL_ddc = dL_ddc; a.dL_dsh = dL_dsh;
     a.rgb_stride = view_stride ? (size_t)view_stride : (size_t)3 * (size_t)P; a.campos_stride = view_stride ? (size_t)view_stride : 3;
-    a.visible = nullptr;
+    a.visible = nullptr; a.vis_stride = 0; a.vis_out = nullptr;
+    for (auto& g : a.g_small) g = nullptr;
     memset(&a.adam, 0, sizeof(a.adam));
     return launch_sh_grad_from_rgb(a, (hipStream_t)stream);
 }
@@ -693,9 +710,39 @@ int gslic_sh_grad_from_rgb_adam(int32_t P, int32_t D, int32_t M, int32_t n_views
     a.P = P; a.D = D; a.M = M; a.n_views = n_views; a.input_is_ddc = input_is_ddc ? 1 : 0;
     a.means3D = means3D; a.campos_all = campos_all; a.rgb_all = rgb_all; a.dL_ddc = dL_ddc; a.dL_dsh = M > 0 ? dL_dsh : nullptr;
     a.rgb_stride = view_stride ? (size_t)view_stride : (size_t)3 * (size_t)P; a.campos_stride = view_stride ? (size_t)view_stride : 3;
-    a.visible = visible;
+    a.visible = visible; a.vis_stride = 0; a.vis_out = nullptr;
+    for (auto& g : a.g_small) g = nullptr;
     memset(&a.adam, 0, sizeof(a.adam));
     for (int g = 1; g <= 2; g++) { a.adam.p[g] = adam->param[g]; a.adam.m[g] = adam->exp_avg[g]; a.adam.v[g] = adam->exp_avg_sq[g]; a.adam.lr[g] = adam->lr[g]; }
+    a.adam.b1 = adam->b1; a.adam.b2 = adam->b2; a.adam.eps = adam->eps; a.adam.on = 1;
+    return launch_sh_grad_from_rgb(a, (hipStream_t)stream);
+}
+
+int gslic_sh_grad_from_rgb_adam_all(int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D, const float* campos_all,
+                                    const float* rgb_all, int32_t input_is_ddc, const uint8_t* vis_all, int64_t vis_stride, uint8_t* vis_out,
+                                    const gslic_adam_fused* adam, const float* dL_dmean3D, const float* dL_dopacity, const float* dL_dscale,
+                                    const float* dL_drot, int64_t view_stride, void* stream)
+{
+    if (view_stride < 0 || (view_stride > 0 && view_stride < 3 * (int64_t)P)) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_sh_grad_from_rgb_adam_all: bad view_stride");
+    if (P < 0 || D < 0 || D > 3 || M < 0 || n_views < 1 || vis_stride < 0 || (vis_stride > 0 && vis_stride < (int64_t)P))
+        return set_error(GSLIC_ERR_INVALID_ARG, "gslic_sh_grad_from_rgb_adam_all: bad P / D / M / n_views / vis_stride");
+    if (P == 0) return GSLIC_OK;
+    if (!means3D || !campos_all || !rgb_all || !vis_all || !adam) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_sh_grad_from_rgb_adam_all: NULL pointer");
+    const bool small = dL_dmean3D || dL_dopacity || dL_dscale || dL_drot;
+    if (small && !(dL_dmean3D && dL_dopacity && dL_dscale && dL_drot))
+        return set_error(GSLIC_ERR_INVALID_ARG, "gslic_sh_grad_from_rgb_adam_all: the four small gradients are given together or not at all");
+    for (int g = 0; g < 6; g++) {
+        if ((g == 2 && M == 0) || (!small && g != 1 && g != 2)) continue;
+        if (!adam->param[g] || !adam->exp_avg[g] || !adam->exp_avg_sq[g]) return set_error(GSLIC_ERR_INVALID_ARG, "gslic_sh_grad_from_rgb_adam_all: group %d has a NULL pointer", g);
+    }
+    ShGradFromRgbArgs a;
+    a.P = P; a.D = D; a.M = M; a.n_views = n_views; a.input_is_ddc = input_is_ddc ? 1 : 0;
+    a.means3D = means3D; a.campos_all = campos_all; a.rgb_all = rgb_all; a.dL_ddc = nullptr; a.dL_dsh = nullptr;
+    a.rgb_stride = view_stride ? (size_t)view_stride : (size_t)3 * (size_t)P; a.campos_stride = view_stride ? (size_t)view_stride : 3;
+    a.visible = vis_all; a.vis_stride = (size_t)vis_stride; a.vis_out = vis_out;
+    a.g_small[0] = dL_dmean3D; a.g_small[1] = dL_dopacity; a.g_small[2] = dL_dscale; a.g_small[3] = dL_drot;
+    memset(&a.adam, 0, sizeof(a.adam));
+    for (int g = 0; g < 6; g++) { a.adam.p[g] = adam->param[g]; a.adam.m[g] = adam->exp_avg[g]; a.adam.v[g] = adam->exp_avg_sq[g]; a.adam.lr[g] = adam->lr[g]; }
     a.adam.b1 = adam->b1; a.adam.b2 = adam->b2; a.adam.eps = adam->eps; a.adam.on = 1;
     return launch_sh_grad_from_rgb(a, (hipStream_t)stream);
 }

@@ -103,6 +103,8 @@ struct PreprocessBwdArgs {
                              // Gaussian and every rank rebuilds dL_ddc / dL_dsh of all views from them (launch_sh_grad_from_rgb)
     AdamFusedArgs adam;
     const uint32_t* status;  // device status words: a non-zero [2] (capacity overflow in the forward) aborts the kernel (no gradients, no Adam)
+    uint8_t* vis_out;     // optional [P]: 1 = radii > 0 — the visibility byte of the N > 1 exchange's payload, written here instead of by a host compare + copy
+    float* campos_out;    // optional [3]: a copy of campos next to it (the payload's camera centre)
     float* cam_partials;  // optional [ceil(P/64)][32]: per-wave sums of the 27 camera-gradient terms (NULL: not computed)
     float* cam_out;       // [35] = dL_dviewmatrix[16] | dL_dprojmatrix[16] | dL_dcampos[3]
 };
@@ -116,7 +118,11 @@ struct ShGradFromRgbArgs {
     size_t rgb_stride, campos_stride;   // floats between consecutive views in rgb_all / campos_all (3 P and 3 for the dense layouts)
     const float *means3D, *campos_all, *rgb_all;
     float *dL_ddc, *dL_dsh;     // outputs; both may be NULL when the Adam update below consumes the rows
-    const uint8_t* visible;     // [P] the exchanged (OR-ed) visibility mask: rows the Adam update applies to
+    const uint8_t* visible;     // [P] the exchanged visibility mask: rows the Adam update applies to.  vis_stride > 0: the views' masks sit vis_stride
+    size_t vis_stride;          // bytes apart (an all-gathered payload) and are OR-ed here; vis_out (optional [P]) receives the OR
+    uint8_t* vis_out;
+    const float* g_small[4];    // optional: the summed (all-reduced) dL_dxyz [P,3], dL_dopacity [P,1], dL_dscaling [P,3], dL_drotation [P,4]: when set, the
+                                // masked Adam of groups 0, 3, 4, 5 runs here too — one launch for the whole optimiser step of an N > 1 rank
     AdamFusedArgs adam;         // on: groups 1 (features_dc) and 2 (features_rest) are updated in place from the rebuilt rows
 };
 int launch_sh_grad_from_rgb(const ShGradFromRgbArgs& a, hipStream_t s);

@@ -252,6 +252,8 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
     bool visible = false;
     if (idx < a.row_end) visible = bwd_gather(a, idx, LDS_SH, ps);
     lds_vis[threadIdx.x] = visible ? 1 : 0;
+    if (a.vis_out && idx < a.row_end) a.vis_out[idx] = visible ? 1 : 0;                                            // the exchange payload's mask ...
+    if (a.campos_out && blockIdx.x == 0 && threadIdx.x < 3) a.campos_out[threadIdx.x] = a.campos[threadIdx.x];     // ... and camera centre
     if constexpr (LDS_SH) {
         // ---- this Gaussian's row of the table (zeros when invisible: its gradient elements and products are then exact zeros)
         float trow[18];
@@ -808,7 +810,17 @@ __global__ __launch_bounds__(64) void sh_grad_from_rgb_kernel(ShGradFromRgbArgs 
         // the masked Adam of optim_utils.h:102-137 on features_dc and features_rest straight from the rebuilt rows (adam_scalar: the one
         // definition every call site shares), on float4 columns of the block's contiguous regions like the fused backward's phase C
         __shared__ uint8_t lds_vis[64];
-        lds_vis[t] = (idx < a.P && a.visible[idx]) ? 1 : 0;   // (entries 32..63: never read)
+        uint8_t myvis = 0;
+        if (idx < a.P) {
+            if (a.vis_stride) {   // the views' masks of an all-gathered payload, OR-ed here (no MAX-reduce launch in front of the step)
+                for (int v = 0; v < a.n_views; v++) myvis |= a.visible[(size_t)v * a.vis_stride + idx];
+                myvis = myvis ? 1 : 0;
+                if (a.vis_out) a.vis_out[idx] = myvis;
+            } else {
+                myvis = a.visible[idx] ? 1 : 0;
+            }
+        }
+        lds_vis[t] = myvis;   // (entries 32..63: never read)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const AdamFusedArgs& A = a.adam;
@@ -856,6 +868,12 @@ __global__ __launch_bounds__(64) void sh_grad_from_rgb_kernel(ShGradFromRgbArgs 
                     if (lds_vis[i / width]) adam_scalar(A.p[grp][base + i], rows_lds[i], A.m[grp][base + i], A.v[grp][base + i], A.lr[grp], A.b1, A.b2, A.eps);
             }
         };
+        if (a.g_small[0]) {   // the four small groups from their all-reduced gradients (read in place from the slab): the whole optimiser step in this launch
+            update(0, 3, a.g_small[0] + (size_t)row0 * 3, (size_t)row0 * 3);
+            update(3, 1, a.g_small[1] + (size_t)row0, (size_t)row0);
+            update(4, 3, a.g_small[2] + (size_t)row0 * 3, (size_t)row0 * 3);
+            update(5, 4, a.g_small[3] + (size_t)row0 * 4, (size_t)row0 * 4);
+        }
         update(1, 3, lds_rows, (size_t)row0 * 3);
         if (a.M == 15) {
             update(2, 45, lds_rows + 3 * SGR, (size_t)row0 * 45);

@@ -125,6 +125,20 @@ class SparseGaussianAdam:
                 if self.state[i] is not None:
                     self.state[i]["step"] += 1
 
+    def step_all_from_exchange(self, means3D, campos_all, rgb_all, degree, n_views, view_stride, vis_all, vis_stride, vis_out, small_grads):
+        """The whole optimiser step of an N > 1 rank in one launch (gslic_sh_grad_from_rgb_adam_all): the views' masks are OR-ed in the kernel
+        (vis_all: view 0's mask inside the all-gathered payload, vis_stride bytes to the next view's; the OR lands in vis_out [P] uint8),
+        dL_ddc / dL_dsh are rebuilt from the gathered colour gradients and consumed by the masked Adam of features_dc / features_rest, and
+        the four small groups are updated from `small_grads` = (dL_dxyz, dL_dopacity, dL_dscaling, dL_drotation), the all-reduced slab views."""
+        P = means3D.size(0)
+        M = self.params[2].size(1) if self.params[2].numel() else 0
+        d = self.fused_descriptor()
+        gx, go, gs, gr = small_grads
+        _lib.check(_lib.lib().gslic_sh_grad_from_rgb_adam_all(P, int(degree), M, int(n_views), _lib.ptr(means3D.contiguous()), _lib.ptr(campos_all), _lib.ptr(rgb_all), 0,
+                                                              _lib.ptr(vis_all), int(vis_stride), _lib.ptr(vis_out), ctypes.byref(d), _lib.ptr(gx), _lib.ptr(go),
+                                                              _lib.ptr(gs), _lib.ptr(gr), int(view_stride), _lib.current_stream_ptr()))
+        self.count_step()
+
     def count_step(self):
         for st in self.state:
             if st is not None:

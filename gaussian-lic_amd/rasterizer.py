@@ -140,7 +140,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                  projmatrix, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, dL_dout_color, dc, sh,
                                  degree, campos, geomBuffer, R, binningBuffer, imageBuffer, B, sampleBuffer, lambda_erank, debug,
                                  raw_params=False, out=None, adam=None, camera_grads=False, rgb_out=None, rows=None, skip_blend=False,
-                                 out_addr=None):
+                                 out_addr=None, payload=None):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:151-246): returns (dL_dmeans2D, dL_dcolors_precomp,
     dL_dopacities, dL_dmeans3D, dL_dcov3Ds_precomp, dL_ddc, dL_dsh, dL_dscales, dL_drotations).
     raw_params=True: scales / rotations are raw and dL_dopacities / dL_dscales / dL_drotations are w.r.t. the raw parameters.
@@ -189,12 +189,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                     vp(addr["opacity"]), vp(addr["xyz"]), vp(rgb_addr), vp(addr["scaling"]), vp(addr["rotation"]),
                     float(lambda_erank), int(rows[0]), int(rows[1]), int(bool(skip_blend)), _lib.current_stream_ptr()))
                 return None
-            _lib.check(L.gslic_rasterize_backward_rgb(
+            pay_vis, pay_campos = (payload or (None, None))   # the rest of the rank's all-gather payload, written by the kernel (no compare / copy launches)
+            _lib.check(L.gslic_rasterize_backward_rgb_payload(
                 ctypes.byref(prm), int(R), int(B), p(background), p(means3D), p(dc), p(sh_c), p(colors), p(scales), p(rotations),
                 p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos), p(radii.contiguous()),
                 ctypes.c_void_p(geomBuffer.data_ptr()), ctypes.c_void_p(binningBuffer.data_ptr()), ctypes.c_void_p(imageBuffer.data_ptr()),
                 ctypes.c_void_p(sampleBuffer.data_ptr()), p(dL), p(out["opacity"]), p(out["xyz"]), p(rgb_out), p(out["scaling"]), p(out["rotation"]),
-                float(lambda_erank), _lib.current_stream_ptr()))
+                float(lambda_erank), p(pay_vis), p(pay_campos), _lib.current_stream_ptr()))
         return None
     if out is not None:
         # caller-provided gradient storage (e.g. views of one flat slab for a zero-copy all-reduce); the tensors the host

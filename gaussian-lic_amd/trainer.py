@@ -276,20 +276,36 @@ def exchange_rank1(slab, rgb_local, visible, model, campos):
     dist = torch.distributed
     n = dist.get_world_size()
     assert rgb_local.data_ptr() == slab.rgb.data_ptr(), "the colour gradient must have been written into the slab's payload"
-    slab.pay_campos.copy_(campos.reshape(3))
-    slab.pay_vis.copy_(visible)
+    if campos is not None:   # (None: the backward kernel has filled the payload's camera centre and mask itself: gslic_rasterize_backward_rgb_payload)
+        slab.pay_campos.copy_(campos.reshape(3))
+        slab.pay_vis.copy_(visible)
     if slab.payload_all is None or slab.payload_all.size(0) != n:
         slab.payload_all = torch.empty(n, slab.pay_bytes, dtype=torch.uint8, device=slab.flat.device)
     w_pay = dist.all_gather_into_tensor(slab.payload_all, slab.payload.view(1, slab.pay_bytes), async_op=True)
     works = [(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True), idx) for seg, idx in (slab.run(model, 0, 1), slab.run(model, 3, 6))]
     P = slab.P
-    w_pay.wait()   # (orders the current stream behind the gather; the host does not block on RCCL)
-    vis = slab.payload_all[:, 12 * P + 12:12 * P + 12 + P].max(0).values.bool()   # OR of the views' masks
     rgb0 = slab.payload_all[0, :12 * P].view(torch.float32)            # view 0's block; view v sits pay_bytes / 4 floats further
     cam0 = slab.payload_all[0, 12 * P:12 * P + 12].view(torch.float32)
     stride = slab.pay_bytes // 4
-
     fused = getattr(model, "optimizer", None) is not None and os.environ.get("GSLIC_RANK1_SPLIT_ADAM") != "1"
+    if fused and os.environ.get("GSLIC_RANK1_FOLD_ADAM", "1") != "0":
+        # ONE launch behind the three collectives: OR of the gathered masks, SH rows rebuilt and consumed, Adam of all six groups
+        # (gslic_sh_grad_from_rgb_adam_all) — no MAX-reduce, no mask copies, no separate Adam launches on the step's critical path
+        if getattr(slab, "vis_or", None) is None:
+            slab.vis_or = torch.zeros(P, dtype=torch.uint8, device=slab.flat.device)
+        vis_all0 = slab.payload_all[0, 12 * P + 12:12 * P + 12 + P]
+
+        class _All:
+            def wait(self_inner):
+                w_pay.wait()
+                for w, _ in works:
+                    w.wait()
+                v = slab.views
+                model.optimizer.step_all_from_exchange(model.xyz.detach(), cam0, rgb0, model.sh_degree, n, stride, vis_all0, slab.pay_bytes, slab.vis_or,
+                                                       (v["xyz"], v["opacity"], v["scaling"], v["rotation"]))
+        return slab.vis_or.view(torch.bool), [(_All(), [])]
+    w_pay.wait()   # (orders the current stream behind the gather; the host does not block on RCCL)
+    vis = slab.payload_all[:, 12 * P + 12:12 * P + 12 + P].max(0).values.bool()   # OR of the views' masks
 
     class _Rebuild:   # rebuilds dL_ddc / dL_dsh of all views from the gathered colour gradients (the mask has to be set first: see the caller)
         def wait(self_inner):
@@ -518,9 +534,10 @@ def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=Tr
             rz.rasterize_gaussians_backward(
                 bg, xyz, radii, e, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
                 float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dL_dimage, dc, rest, model.sh_degree,
-                cam.d_camera_center, geom, R, binning, img, B, sample, model.lambda_erank, False, raw_params=True, out=slab.views, rgb_out=slab.rgb)
+                cam.d_camera_center, geom, R, binning, img, B, sample, model.lambda_erank, False, raw_params=True, out=slab.views, rgb_out=slab.rgb,
+                payload=(slab.pay_vis, slab.pay_campos))   # mask and camera centre of the all-gather payload come out of the same kernel
             _dist_mark("bwd_done")
-            visible, works = exchange_rank1(slab, slab.rgb, radii > 0, model, cam.d_camera_center)
+            visible, works = exchange_rank1(slab, slab.rgb, None, model, None)
             model.optimizer.set_visibility_and_N(visible, model.P)
             grads = slab.grads(model)
             for work, idx in works:

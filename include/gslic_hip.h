@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSLIC_ABI_VERSION 5
+#define GSLIC_ABI_VERSION 6
 
 typedef enum gslic_status {
     GSLIC_OK = 0,
@@ -250,6 +250,17 @@ int gslic_rasterize_backward_rgb(
     char* geom_buffer, char* binning_buffer, char* img_buffer, char* sample_buffer, const float* dL_dpix,
     float* dL_dopacity, float* dL_dmean3D, float* dL_drgb, float* dL_dscale, float* dL_drot,
     float lambda_erank, void* stream);
+/* gslic_rasterize_backward_rgb that also fills the rest of a rank's all-gather payload {dRGB [P,3], camera centre [3], visibility [P] bytes}:
+ * vis_out[g] = radii[g] > 0 and campos_out[0..2] = cam_pos are written by the per-Gaussian kernel, so the host issues no compare / copy
+ * launches between the backward and the collective.  Either may be NULL. */
+int gslic_rasterize_backward_rgb_payload(
+    const gslic_raster_params* prm, int32_t R, int32_t B,
+    const float* background, const float* means3D, const float* dc, const float* shs, const float* colors_precomp,
+    const float* scales, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos, const int32_t* radii,
+    char* geom_buffer, char* binning_buffer, char* img_buffer, char* sample_buffer, const float* dL_dpix,
+    float* dL_dopacity, float* dL_dmean3D, float* dL_drgb, float* dL_dscale, float* dL_drot,
+    float lambda_erank, uint8_t* vis_out, float* campos_out, void* stream);
 /* gslic_rasterize_backward_rgb in row chunks: the per-Gaussian half of the backward for Gaussians [row_begin, row_end) only (row_begin a
  * multiple of 64; the gradient pointers are still indexed by the ABSOLUTE Gaussian index), the blend half (one pass over the whole image) unless
  * skip_blend.  A host that exchanges gradients calls it once per chunk — the first call with skip_blend = 0 — and puts chunk c on the wire
@@ -272,6 +283,16 @@ int gslic_sh_grad_from_rgb(
 int gslic_sh_grad_from_rgb_adam(
     int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D, const float* campos_all, const float* rgb_all,
     int32_t input_is_ddc, const uint8_t* visible, const gslic_adam_fused* adam, float* dL_ddc, float* dL_dsh, int64_t view_stride, void* stream);
+/* The whole optimiser step of an N > 1 rank in ONE launch, straight from what the exchange delivered: the views' visibility masks are OR-ed
+ * here (view v's mask at vis_all + v * vis_stride bytes; vis_stride = 0: vis_all is one already OR-ed mask; the OR is also written to vis_out
+ * when that is non-NULL), dL_ddc / dL_dsh are rebuilt from the views' colour gradients and consumed by the masked Adam of groups 1 and 2,
+ * and — when the four summed (all-reduced) small gradients dL_dmean3D [P,3], dL_dopacity [P,1], dL_dscale [P,3], dL_drot [P,4] are given —
+ * the masked Adam of groups 0, 3, 4, 5 reads them in place.  Bit-identical to gslic_sh_grad_from_rgb_adam + gslic_adam_update_groups on the
+ * OR-ed mask.  (src/gaussian.cpp:697-707 is the step this replaces on every rank: set_visibility_and_N + SparseGaussianAdam::step.) */
+int gslic_sh_grad_from_rgb_adam_all(
+    int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D, const float* campos_all, const float* rgb_all,
+    int32_t input_is_ddc, const uint8_t* vis_all, int64_t vis_stride, uint8_t* vis_out, const gslic_adam_fused* adam,
+    const float* dL_dmean3D, const float* dL_dopacity, const float* dL_dscale, const float* dL_drot, int64_t view_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * gslic_rasterize_backward_camera — gslic_rasterize_backward plus the gradient w.r.t. the CAMERA inputs (the "cam" of the

@@ -31,14 +31,14 @@ def test_trained_and_grown_device_map_exports_like_the_reference(tmp_path):
     gt, bg = gt_image(H, W).to(dev), torch.zeros(3, device=dev)
     for _ in range(3):
         trainer.training_step_fused(model, cam, gt, bg)
-    cap0 = model.capacity()
+    cap0 = model.capacity
     frame = lidar_scene(4000, W, H, sh_degree=3, seed=72)
     pts = frame["xyz"].to(dev)
     col = (frame["features_dc"].reshape(-1, 3) * 0.28209479177387814 + 0.5).to(dev)
     Rcw = torch.from_numpy(cam.world_view_transform[:3, :3].T.copy())
     tcw = torch.from_numpy(cam.world_view_transform[3, :3].copy())
     k = model.extend(cam, pts, col, frame["xyz"][:, 2].contiguous().to(dev), Rcw, tcw, (float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy)))
-    assert k > 0 and model.P == P + k and model.capacity() >= 2 * cap0, (k, model.P, cap0, model.capacity())   # capacity doubling (trainer._reserve)
+    assert k > 0 and model.P == P + k and model.capacity >= 2 * cap0, (k, model.P, cap0, model.capacity)   # capacity doubling (trainer._reserve)
     for _ in range(2):
         trainer.training_step_fused(model, cam, gt, bg)           # the grown map trains on: new rows have moments and move
     torch.cuda.synchronize()

@@ -358,7 +358,7 @@ def test_fused_cpp_host_pose_gradient(tmp_path):
     d = str(tmp_path)
     gt = gt_image(H, W)
     _write_case(d, raw, cam, gt)
-    r = subprocess.run([CHECK_FUSED, d, str(P), str(W), str(H), str(deg), "0"], capture_output=True, text=True, timeout=300, env=dict(os.environ, GSLIC_CHECK_POSE="1"))
+    r = subprocess.run([CHECK_FUSED, d, str(P), str(W), str(H), str(deg), "1"], capture_output=True, text=True, timeout=300, env=dict(os.environ, GSLIC_CHECK_POSE="1"))   # (the gradient is printed before the one step)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     got = np.array([float(v) for v in [l for l in r.stdout.splitlines() if l.startswith("pose_gradient")][-1].split()[1:]])
     dev = torch.device("cuda:0")
