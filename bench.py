@@ -222,6 +222,13 @@ def main():
 
     if args.graph:
         assert world == 1 and args.mode == "train" and args.host == "fused" and not args.split_adam, "--graph: single GPU, --mode train --host fused"
+    # ---- N > 1 (and the one-rank group that stands in for it): prime the exchange path before the W warm-up steps.  The 79th step of a process
+    # group stalls for 36-39 ms, once, reproducibly (tools/diag_dist_warmup.py: a runtime-side pool growing after ~240 collectives); inside
+    # a 20- or 100-step timed region that one stall reads as +0.4 .. +1.9 ms per step.  Priming is initialisation, not part of W or K.
+    if trainer._dist_on() and args.mode == "train" and args.host == "fused":
+        for _ in range(int(os.environ.get("GSLIC_DIST_PRIME_STEPS", "90"))):
+            step()
+        torch.cuda.synchronize()
     # ---- warm-up (untimed); the last warm-up steps double as the per-kernel breakdown pass
     nprof = min(3, args.warmup)
     for _ in range(args.warmup - nprof):
