@@ -601,8 +601,9 @@ class GraphedStep:
     device.  If they outgrow the buffers the step turns itself into a no-op (status bits; no gradients, no Adam) and `check()` —
     called every `check_every` steps (at most 32: the device keeps one did-not-fit bit per issued step), and by the caller at the
     end — grows the buffers from the largest counts seen, re-captures and repeats exactly the steps that did not fit, each with ITS
-    camera and ground truth (kept by reference since the last check: do not overwrite those tensors in between), after the ones that
-    did.  extend() changes P: build a new GraphedStep afterwards."""
+    pose (snapshotted by value) and ground truth (kept by reference with its version counter: a target that was modified in place, or
+    replaced while steps were issued with gt_image=None, makes the repeat fail loudly instead of training on the wrong data), after the
+    ones that did.  extend() changes P: build a new GraphedStep afterwards."""
 
     def __init__(self, model, camera, gt_image, bg, headroom=1.25, check_every=16, cap_R=None, cap_B=None):
         from . import rasterizer as rz
@@ -676,14 +677,40 @@ class GraphedStep:
         self.steps_issued = 0
         self.window = []
 
+    _BAKED = ("tanfovx", "tanfovy", "limx_neg", "limx_pos", "limy_neg", "limy_pos")   # scalars of the camera that are constants of the captured graph
+
     def _load(self, camera, gt_image):
-        """Refresh the static buffers the captured step reads."""
-        if camera is not None and camera is not self.cam:
-            assert (float(camera.tanfovx), float(camera.tanfovy)) == (float(self.cam.tanfovx), float(self.cam.tanfovy)), "intrinsics are baked into the graph"
+        """Refresh the static buffers the captured step reads.  The pose is copied on every call that names a camera (the same Camera object
+        may have been moved in place since it was loaded last)."""
+        if camera is not None:
+            for k in self._BAKED:
+                assert float(getattr(camera, k)) == float(getattr(self.cam, k)), f"{k} is baked into the graph"
             self.view.copy_(camera.d_world_view_transform); self.proj.copy_(camera.d_full_proj_transform); self.campos.copy_(camera.d_camera_center)
             self.cam = camera
         if gt_image is not None and gt_image.data_ptr() != self.gt.data_ptr():
             self.gt.copy_(gt_image)
+            self._gt_serial = getattr(self, "_gt_serial", 0) + 1
+
+    def _snapshot(self, gt_image):
+        """What a repeat of this step needs, independent of what the caller does to its objects afterwards: the three pose tensors by VALUE
+        (35 floats) and the target by reference together with the evidence that it is still the same data (the tensor's version counter; for
+        gt_image=None — "the target that is loaded" — the serial number of the load)."""
+        return dict(view=self.view.clone(), proj=self.proj.clone(), campos=self.campos.clone(), gt=gt_image,
+                    gt_version=None if gt_image is None else gt_image._version, gt_serial=getattr(self, "_gt_serial", 0))
+
+    def _load_snapshot(self, snap):
+        self.view.copy_(snap["view"]); self.proj.copy_(snap["proj"]); self.campos.copy_(snap["campos"])
+        gt = snap["gt"]
+        if gt is None:
+            if snap["gt_serial"] != getattr(self, "_gt_serial", 0):
+                raise RuntimeError("GraphedStep: a step that has to be repeated ran on a target that has been replaced since (it was issued with "
+                                   "gt_image=None); pass the target explicitly to step() when targets change between checks")
+        else:
+            if gt._version != snap["gt_version"]:
+                raise RuntimeError("GraphedStep: the ground-truth tensor of a step that has to be repeated was modified in place after the step was issued")
+            if gt.data_ptr() != self.gt.data_ptr():
+                self.gt.copy_(gt)
+                self._gt_serial = getattr(self, "_gt_serial", 0) + 1
 
     def step(self, camera=None, gt_image=None):
         """One optimiser step (replay).  Returns the device tensor [mean L1, mean SSIM] of this step's loss terms."""
@@ -691,7 +718,7 @@ class GraphedStep:
         self.graph.replay()
         self.steps_issued += 1
         if len(self.window) < 32:
-            self.window.append((self.cam, gt_image))
+            self.window.append(self._snapshot(gt_image))
         self.model.optimizer.count_step()
         if self.check_every and self.steps_issued >= self.check_every:
             self.check()
@@ -710,18 +737,18 @@ class GraphedStep:
                 break
             # which steps: one bit per issue index while the window is at most 32 steps long; a longer unchecked run (check_every = 0)
             # can only be repeated on the view that is loaded now
-            todo = [self.window[i] for i in range(min(issued, len(self.window))) if (failed_mask >> i) & 1] if issued <= 32 else [(self.cam, None)] * missed
+            todo = [self.window[i] for i in range(min(issued, len(self.window))) if (failed_mask >> i) & 1] if issued <= 32 else [self._snapshot(None)] * missed
             self.cap_R = max(self.cap_R, int(max_R * self.headroom) + 65536)
             self.cap_B = max(self.cap_B, int(max_B * self.headroom) + 1024)
             if max_R > 0x7fffffff // 2 or bits & 16:
                 raise RuntimeError("GraphedStep: the instance count does not fit 31 bits")
             self.recaptures += 1
             self._capture()                     # (zeroes the status words, empties the window)
-            for cam, gt in todo:
-                self._load(cam, gt)
+            for snap in todo:
+                self._load_snapshot(snap)
                 self.graph.replay()
                 self.steps_issued += 1
-                self.window.append((self.cam, gt))
+                self.window.append(snap)
             repeated += len(todo)
         else:
             raise RuntimeError("GraphedStep: steps keep overflowing their capacity buffers")

@@ -160,3 +160,62 @@ def test_graphed_step_repeats_overflowed_steps_with_their_own_views():
     for n in model.NAMES:
         assert torch.equal(getattr(model, n).detach(), getattr(eager, n).detach()), n
         assert torch.equal(model._m[n][:P], eager._m[n][:P]) and torch.equal(model._v[n][:P], eager._v[n][:P]), n
+
+
+def test_graphed_step_repeats_with_the_pose_of_the_step_when_one_camera_object_moves():
+    """The host keeps ONE Camera object and moves it in place between steps (pose refinement, a reused staging object): a step that has to
+    be repeated must run on the pose it was ISSUED with (snapshotted by value), not on the pose the object holds at check time; and a target
+    tensor that was overwritten in place after its step makes the repeat fail loudly instead of training on the wrong data."""
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import rasterizer as rz
+    from gaussian_lic_amd import trainer
+    from gaussian_lic_amd.camera import synthetic_camera
+    from gaussian_lic_amd.synthetic import gt_image
+    dev = torch.device("cuda:0")
+    P, W, H = 40000, 320, 240
+    raw, sc, camd, cam0 = make_scene("random", P, W, H, 3, 8)
+    poses = [synthetic_camera(W, H, k) for k in range(6)]
+    gts = [gt_image(H, W, seed=20 + k).to(dev) for k in range(6)]
+    bg = torch.zeros(3, device=dev)
+
+    def fresh():
+        m = trainer.GaussianModel(raw, dev)
+        m.training_setup()
+        return m
+    probe, e, Rs = fresh(), torch.empty(0, device=dev), []
+    with torch.no_grad():
+        for c in poses:
+            c.to_device(dev)
+            Rs.append(rz.rasterize_gaussians(bg, probe.xyz.detach(), e, probe.opacity.detach(), probe.scaling.detach(), probe.rotation.detach(), 1.0, e,
+                                             c.d_world_view_transform, c.d_full_proj_transform, float(c.tanfovx), float(c.tanfovy), H, W,
+                                             float(c.limx_neg), float(c.limx_pos), float(c.limy_neg), float(c.limy_pos), probe.features_dc.detach(),
+                                             probe.features_rest.detach(), 3, c.d_camera_center, False, False, False, raw_params=True)[0])
+    cap_R = (max(Rs) + sorted(Rs)[len(Rs) // 2]) // 2
+    fits = [r <= cap_R - 64 for r in Rs]
+    assert any(fits) and not all(fits)
+    moving = synthetic_camera(W, H, fits.index(True)).to_device(dev)       # the one object the host moves around
+    model = fresh()
+    gs = trainer.GraphedStep(model, moving, gts[fits.index(True)], bg, check_every=0, cap_R=cap_R)
+    for k in range(6):
+        moving.set_pose(poses[k].R_wc, poses[k].t_wc)
+        moving.to_device(dev)
+        gs.step(moving, gts[k])
+    _issued, mask, _mr, _mb = gs.bufs.read_window()
+    failed = [k for k in range(6) if (mask >> k) & 1]
+    assert failed
+    moving.set_pose(poses[0].R_wc, poses[0].t_wc); moving.to_device(dev)    # wherever the object points now must not matter
+    assert gs.check() == len(failed)
+    eager = fresh()
+    for k in [k for k in range(6) if k not in failed] + failed:
+        trainer.training_step_fused(eager, poses[k], gts[k], bg)
+    for n in model.NAMES:
+        assert torch.equal(getattr(model, n).detach(), getattr(eager, n).detach()), n
+    # a target modified in place after its step was issued: the repeat refuses
+    model2 = fresh()
+    gs2 = trainer.GraphedStep(model2, poses[fits.index(True)], gts[fits.index(True)], bg, check_every=0, cap_R=cap_R)
+    k_bad = fits.index(False)
+    staging = gts[k_bad].clone()
+    gs2.step(poses[k_bad], staging)
+    staging.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        gs2.check()
