@@ -93,6 +93,25 @@ VALU_CYCLES_PER_INST = {
 SHADER_CLOCK_GHZ = 2.0        # what the part sustains under this workload (2.4 nominal)
 
 
+_T0 = time.perf_counter()
+
+
+_LEG = ["start"]
+
+
+def _trace(msg):
+    """Progress line on stderr (never on stdout: the contract is ONE JSON line there): which leg runs and since when — a leg that stalls is then
+    visible in the driver's log instead of being a silent timeout."""
+    _LEG[0] = msg
+    print(f"[bench {time.perf_counter() - _T0:7.1f} s] {msg}", file=sys.stderr, flush=True)
+    try:   # a leg that makes no progress for 90 s gets the Python stacks of all threads dumped to stderr (once), then goes on waiting
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
+        faulthandler.dump_traceback_later(90, repeat=False, file=sys.stderr)
+    except Exception:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,6 +248,7 @@ def main():
         for _ in range(int(os.environ.get("GSLIC_DIST_PRIME_STEPS", "90"))):
             step()
         torch.cuda.synchronize()
+    _trace("model on the device; warm-up")
     # ---- warm-up (untimed); the last warm-up steps double as the per-kernel breakdown pass
     nprof = min(3, args.warmup)
     for _ in range(args.warmup - nprof):
@@ -247,6 +267,7 @@ def main():
         for _ in range(3):
             step()
 
+    _trace("timed region")
     # ---- timed region: exactly K steps, dominant kernel bracketed by HIP events on its launch stream
     dist_on = trainer._dist_on() and args.mode == "train" and args.host == "fused"
     if dist_on:
@@ -301,6 +322,7 @@ def main():
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(dt.item())
 
+    _trace(f"timed region done: {1e3 * (t1 - t0) / args.steps:.3f} ms/step; unit counts")
     # ---- unit counts of this workload (one extra forward, untimed), taken RIGHT AFTER the timed steps: the secondary legs below train the map
     # further, and the counts (live instances above all) drift with it — the roofline and the replayed counters must describe the timed region
     with torch.no_grad():
@@ -352,80 +374,7 @@ def main():
         return float(odt.item())
 
     # ---- the same step over a window of at least one second (the driver's --steps 20 is a 50 ms window): reported beside `value`
-    value_long = None
-    if graphed["gs"] is None and args.mode != "slam":
-        n_long = int(min(4000, max(args.steps, np.ceil(1.2 * args.steps / max(elapsed, 1e-6)))))
-        sec = timed_loop(step, n_long)
-        value_long = {"value": round(n_long * world / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_long, 3), "steps": n_long,
-                      "seconds": round(sec, 3)}
-
-    other, graphed_res, growth, cpp_host, math_legs, cycle, pose_leg = None, None, None, None, None, None, None
-    if args.mode == "train" and args.host == "fused" and args.views > 1 and world == 1 and not trainer._dist_on() and not args.graph and (not args.no_extras or "--views" in sys.argv):
-        try:
-            cycle = views_cycle(args, model, bg, dev, args.views, min(args.steps, 200))
-        except Exception as ex:   # a secondary leg must never take the line down
-            cycle = {"error": str(ex)[:300]}
-    n_extra = min(args.steps, 200)
-    if args.mode == "train" and not args.no_extras and not args.graph and world == 1 and not trainer._dist_on():
-        # the two arithmetic modes of the blend kernels, same workload: throughput, and what the fast mode moves element for element
-        # (the strict mode is held bit-identical to the reference's kernels by tests/test_fullsize_reference_gpu.py, so these ARE the
-        # fast mode's differences from the reference: counts of elements more than 1e-4 of the tensor's max-abs away)
-        math_legs = {}
-        for name, flag in (("strict", True), ("fast", False)):
-            _lib.set_math_mode(flag)
-            sec = timed_loop(step, n_extra)
-            math_legs[name] = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra}
-        math_legs["default"] = "strict" if strict_mode else "fast"
-        try:
-            math_legs["fast_vs_strict_full_size"] = mode_differences(model, cam, dL, bg)
-        except Exception as ex:   # a diagnostic leg must never take the line down
-            math_legs["fast_vs_strict_full_size"] = {"error": str(ex)[:200]}
-        _lib.set_math_mode(strict_mode)
-    if args.mode == "train" and not args.no_extras and not args.graph:
-        host["mode"] = "dropin" if args.host == "fused" else "fused"
-        sec = timed_loop(step, n_extra)
-        other = {"host": host["mode"], "value": round(n_extra * world / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3),
-                 "steps": n_extra}
-        if host["mode"] == "dropin":
-            # the number above is the reference's host lines on the DROP-IN renderer (render() feeds the raw parameters to one autograd node: what
-            # swapping renderer.cpp for shim/renderer.cpp gives an otherwise unmodified host); beside it the same lines on renderer.cpp as written
-            # (getOpacity / getScaling / getRotation as LibTorch ops) and with the optional one-node loss
-            other["what"] = "reference operator API + LibTorch autograd, drop-in renderer (activations inside the kernels)"
-            os.environ["GSLIC_RENDER_RAW"] = "0"
-            sec2 = timed_loop(step, n_extra)
-            os.environ.pop("GSLIC_RENDER_RAW", None)
-            other["renderer_as_written"] = {"value": round(n_extra * world / sec2, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec2 / n_extra, 3)}
-            if world == 1 and not trainer._dist_on():
-                sec3 = timed_loop(lambda: trainer.training_step(model, cam, gt, bg, one_node_loss=True), n_extra)
-                other["one_node_loss"] = {"value": round(n_extra / sec3, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec3 / n_extra, 3)}
-        host["mode"] = args.host
-        if world == 1 and not trainer._dist_on() and args.host == "fused" and not args.split_adam:
-            # the same step as ONE hipGraph replay: capacity-mode forward (no host round trip), loss, backward + Adam
-            gs = trainer.GraphedStep(model, cam, gt, bg, check_every=0)
-            sec = timed_loop(gs.step, n_extra)
-            repeated = gs.check()
-            graphed_res = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra,
-                           "host_round_trips_per_step": 0, "steps_repeated_for_capacity": repeated, "capacity_R": gs.bufs.cap_R, "capacity_B": gs.bufs.cap_B}
-            del gs
-        if world == 1 and not trainer._dist_on() and args.host == "fused":
-            # joint map + camera-pose iteration (the "cam" of the north-star): parameter gradients and the camera gradient from ONE backward
-            # (gslic_rasterize_backward_camera), Adam as its own launch, the se(3) chain and the pose update on the host (35 floats per step)
-            try:
-                pcam = synthetic_camera(W, H, 3).to_device(dev)
-                sec = timed_loop(lambda: trainer.training_step_with_pose(model, pcam, gt, bg, pose_lr=1e-6), n_extra)
-                pose_leg = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra,
-                            "what": "forward + loss + backward with camera gradient + split Adam + se(3) pose step per view (one host synchronisation per step)"}
-            except Exception as ex:
-                pose_leg = {"error": str(ex)[:200]}
-            cpp_host = cpp_fused_host(args, model, cam, gt, n_extra)
-            torch.cuda.empty_cache()
-            growth = growth_schedule(args, dev)
-
-    if rank != 0:
-        if torch.distributed.is_initialized():
-            torch.distributed.destroy_process_group()
-        return
-
+    _trace("roofline / cpu_baseline")
     # ---- roofline of the dominant kernel
     dom_ms, dom_n = timed.get(dominant, (0.0, 0))
     avg_ms = dom_ms / max(dom_n, 1)
@@ -537,15 +486,15 @@ def main():
                    "buckets_live": stats.get("B_live")},
         "roofline": roofline,
         "cpu_baseline": cpu,
-        "value_long": value_long,
+        "value_long": None,
         "exchange": exchange,
-        "views_cycle": cycle,
-        "math_modes": math_legs,
-        "other_host_path": other,
-        "graphed": graphed_res,
-        "cpp_fused_host": cpp_host,
-        "joint_pose_step": pose_leg,
-        "growth_schedule": growth,
+        "views_cycle": None,
+        "math_modes": None,
+        "other_host_path": None,
+        "graphed": None,
+        "cpp_fused_host": None,
+        "joint_pose_step": None,
+        "growth_schedule": None,
         "extend": None if args.mode != "slam" else {"calls": slam["calls"], "inserted": slam["inserted"], "final_gaussians": model.P,
                                                     "ms_per_call": round(slam["ms"] / max(slam["calls"], 1), 3)},
         # per-kernel time of the fully INSTRUMENTED warm-up pass (a HIP-event pair around every launch: the events' own overhead makes the
@@ -555,6 +504,118 @@ def main():
         "kernel_roofline": (kernel_table(timed, stats, fused_adam, rank1=dist_on and trainer.exchange_mode() == "rank1") if args.profile_all else
                             (kernel_table(timed_all, stats, False, rank1=trainer.exchange_mode() == "rank1") if timed_all else None)),
     }
+
+    # ---- the contract line is complete at this point.  The secondary legs below are optional: a watchdog prints the line as it stands and ends the
+    # process if they overrun their budget (a leg that stalls must not cost the run its headline), and every finished leg is added as it completes
+    import threading
+
+    def _give_up():
+        out["secondary_legs"] = f"stopped after {budget_s:.0f} s inside leg '{_LEG[0]}': the legs finished until then are reported, the others are null"
+        print(json.dumps(out), flush=True)
+        _trace("secondary legs overran their budget: line printed, leaving")
+        os._exit(0)
+    budget_s = float(os.environ.get("GSLIC_BENCH_LEGS_BUDGET_S", "300"))
+    watchdog = threading.Timer(budget_s, _give_up)
+    watchdog.daemon = True
+    if rank == 0 and not args.no_extras:
+        watchdog.start()
+    _trace("value_long")
+    value_long = None
+    if graphed["gs"] is None and args.mode != "slam":
+        n_long = int(min(4000, max(args.steps, np.ceil(1.2 * args.steps / max(elapsed, 1e-6)))))
+        sec = timed_loop(step, n_long)
+        value_long = {"value": round(n_long * world / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_long, 3), "steps": n_long,
+                      "seconds": round(sec, 3)}
+
+    out["value_long"] = value_long
+    other, graphed_res, growth, cpp_host, math_legs, cycle, pose_leg = None, None, None, None, None, None, None
+    _trace("secondary legs: views_cycle")
+    if args.mode == "train" and args.host == "fused" and args.views > 1 and world == 1 and not trainer._dist_on() and not args.graph and (not args.no_extras or "--views" in sys.argv):
+        try:
+            cycle = views_cycle(args, model, bg, dev, args.views, min(args.steps, 200))
+        except Exception as ex:   # a secondary leg must never take the line down
+            cycle = {"error": str(ex)[:300]}
+    n_extra = min(args.steps, 200)
+    if args.mode == "train" and not args.no_extras and not args.graph and world == 1 and not trainer._dist_on():
+        # the two arithmetic modes of the blend kernels, same workload: throughput, and what the fast mode moves element for element
+        # (the strict mode is held bit-identical to the reference's kernels by tests/test_fullsize_reference_gpu.py, so these ARE the
+        # fast mode's differences from the reference: counts of elements more than 1e-4 of the tensor's max-abs away)
+        out["views_cycle"] = cycle
+        _trace("math_modes")
+        math_legs = {}
+        for name, flag in (("strict", True), ("fast", False)):
+            _lib.set_math_mode(flag)
+            sec = timed_loop(step, n_extra)
+            math_legs[name] = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra}
+        math_legs["default"] = "strict" if strict_mode else "fast"
+        try:
+            math_legs["fast_vs_strict_full_size"] = mode_differences(model, cam, dL, bg)
+        except Exception as ex:   # a diagnostic leg must never take the line down
+            math_legs["fast_vs_strict_full_size"] = {"error": str(ex)[:200]}
+        _lib.set_math_mode(strict_mode)
+    if args.mode == "train" and not args.no_extras and not args.graph:
+        out["math_modes"] = math_legs
+        _trace("other_host_path")
+        host["mode"] = "dropin" if args.host == "fused" else "fused"
+        sec = timed_loop(step, n_extra)
+        other = {"host": host["mode"], "value": round(n_extra * world / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3),
+                 "steps": n_extra}
+        if host["mode"] == "dropin":
+            # the number above is the reference's host lines on the DROP-IN renderer (render() feeds the raw parameters to one autograd node: what
+            # swapping renderer.cpp for shim/renderer.cpp gives an otherwise unmodified host); beside it the same lines on renderer.cpp as written
+            # (getOpacity / getScaling / getRotation as LibTorch ops) and with the optional one-node loss
+            other["what"] = "reference operator API + LibTorch autograd, drop-in renderer (activations inside the kernels)"
+            os.environ["GSLIC_RENDER_RAW"] = "0"
+            sec2 = timed_loop(step, n_extra)
+            os.environ.pop("GSLIC_RENDER_RAW", None)
+            other["renderer_as_written"] = {"value": round(n_extra * world / sec2, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec2 / n_extra, 3)}
+            if world == 1 and not trainer._dist_on():
+                sec3 = timed_loop(lambda: trainer.training_step(model, cam, gt, bg, one_node_loss=True), n_extra)
+                other["one_node_loss"] = {"value": round(n_extra / sec3, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec3 / n_extra, 3)}
+        host["mode"] = args.host
+        if world == 1 and not trainer._dist_on() and args.host == "fused" and not args.split_adam:
+            # the same step as ONE hipGraph replay: capacity-mode forward (no host round trip), loss, backward + Adam
+            out["other_host_path"] = other
+            _trace("graphed")
+            gs = trainer.GraphedStep(model, cam, gt, bg, check_every=0)
+            sec = timed_loop(gs.step, n_extra)
+            repeated = gs.check()
+            graphed_res = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra,
+                           "host_round_trips_per_step": 0, "steps_repeated_for_capacity": repeated, "capacity_R": gs.bufs.cap_R, "capacity_B": gs.bufs.cap_B}
+            del gs
+        if world == 1 and not trainer._dist_on() and args.host == "fused":
+            # joint map + camera-pose iteration (the "cam" of the north-star): parameter gradients and the camera gradient from ONE backward
+            # (gslic_rasterize_backward_camera), Adam as its own launch, the se(3) chain and the pose update on the host (35 floats per step)
+            out["graphed"] = graphed_res
+            _trace("joint_pose_step")
+            try:
+                pcam = synthetic_camera(W, H, 3).to_device(dev)
+                sec = timed_loop(lambda: trainer.training_step_with_pose(model, pcam, gt, bg, pose_lr=1e-6), n_extra)
+                pose_leg = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra,
+                            "what": "forward + loss + backward with camera gradient + split Adam + se(3) pose step per view (one host synchronisation per step)"}
+            except Exception as ex:
+                pose_leg = {"error": str(ex)[:200]}
+            out["joint_pose_step"] = pose_leg
+            _trace("cpp hosts")
+            cpp_host = cpp_fused_host(args, model, cam, gt, n_extra)
+            out["cpp_fused_host"] = cpp_host
+            _trace("growth_schedule")
+            torch.cuda.empty_cache()
+            growth = growth_schedule(args, dev)
+
+    if rank != 0:
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return
+
+    watchdog.cancel()
+    try:
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
+    except Exception:
+        pass
+    out.update({"value_long": value_long, "views_cycle": cycle, "math_modes": math_legs, "other_host_path": other, "graphed": graphed_res,
+                "cpp_fused_host": cpp_host, "joint_pose_step": pose_leg, "growth_schedule": growth})
     print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
@@ -706,7 +767,7 @@ def cpp_fused_host(args, model, cam, gt, n):
         w("gt", gt.cpu().numpy())
         w("scalars", np.array([cam.tanfovx, cam.tanfovy, cam.limx_neg, cam.limx_pos, cam.limy_neg, cam.limy_pos], np.float32))
         r = subprocess.run([exe, d, str(model.P), str(args.width), str(args.height), "3", "1", str(n), str(args.lr_scale)], capture_output=True,
-                           text=True, timeout=600)
+                           text=True, timeout=180)
         line = [l for l in r.stdout.splitlines() if l.startswith("views_per_s")]
         if r.returncode != 0 or not line:
             return {"error": (r.stdout[-300:] + r.stderr[-300:]).strip()}
@@ -726,7 +787,7 @@ def cpp_fused_host(args, model, cam, gt, n):
                 continue
             env = dict(os.environ, GSLIC_CHECK_TIME="1")
             n2 = min(n, 60) + 3
-            r2 = subprocess.run([exe2, d, str(model.P), str(args.width), str(args.height), "3", str(n2)], capture_output=True, text=True, timeout=600, env=env)
+            r2 = subprocess.run([exe2, d, str(model.P), str(args.width), str(args.height), "3", str(n2)], capture_output=True, text=True, timeout=120, env=env)
             l2 = [l for l in r2.stdout.splitlines() if l.startswith("views_per_s")]
             drop[key] = ({"value": round(float(l2[0].split()[1]), 3), "unit": "views/s", "ms_per_step": round(float(l2[0].split()[3]), 3), "steps": n2 - 3}
                          if (r2.returncode == 0 and l2) else {"error": (r2.stdout[-200:] + r2.stderr[-200:]).strip()})

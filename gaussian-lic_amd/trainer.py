@@ -679,6 +679,12 @@ class GraphedStep:
 
     _BAKED = ("tanfovx", "tanfovy", "limx_neg", "limx_pos", "limy_neg", "limy_pos")   # scalars of the camera that are constants of the captured graph
 
+    @staticmethod
+    def _pose_of(camera):
+        """The three pose arrays of a Camera by VALUE, on the host (they are numpy members of the object: no device work, no allocation on the
+        device between two replays)."""
+        return (camera.world_view_transform.copy(), camera.full_proj_transform.copy(), camera.camera_center.copy())
+
     def _load(self, camera, gt_image):
         """Refresh the static buffers the captured step reads.  The pose is copied on every call that names a camera (the same Camera object
         may have been moved in place since it was loaded last)."""
@@ -687,19 +693,24 @@ class GraphedStep:
                 assert float(getattr(camera, k)) == float(getattr(self.cam, k)), f"{k} is baked into the graph"
             self.view.copy_(camera.d_world_view_transform); self.proj.copy_(camera.d_full_proj_transform); self.campos.copy_(camera.d_camera_center)
             self.cam = camera
+            self._pose_host = self._pose_of(camera)
         if gt_image is not None and gt_image.data_ptr() != self.gt.data_ptr():
             self.gt.copy_(gt_image)
             self._gt_serial = getattr(self, "_gt_serial", 0) + 1
 
     def _snapshot(self, gt_image):
-        """What a repeat of this step needs, independent of what the caller does to its objects afterwards: the three pose tensors by VALUE
-        (35 floats) and the target by reference together with the evidence that it is still the same data (the tensor's version counter; for
-        gt_image=None — "the target that is loaded" — the serial number of the load)."""
-        return dict(view=self.view.clone(), proj=self.proj.clone(), campos=self.campos.clone(), gt=gt_image,
-                    gt_version=None if gt_image is None else gt_image._version, gt_serial=getattr(self, "_gt_serial", 0))
+        """What a repeat of this step needs, independent of what the caller does to its objects afterwards: the pose by VALUE (host copies of the
+        35 floats that are loaded now) and the target by reference together with the evidence that it is still the same data (the tensor's
+        version counter; for gt_image=None — "the target that is loaded" — the serial number of the load)."""
+        if getattr(self, "_pose_host", None) is None:
+            self._pose_host = self._pose_of(self.cam)
+        return dict(pose=self._pose_host, gt=gt_image, gt_version=None if gt_image is None else gt_image._version, gt_serial=getattr(self, "_gt_serial", 0))
 
     def _load_snapshot(self, snap):
-        self.view.copy_(snap["view"]); self.proj.copy_(snap["proj"]); self.campos.copy_(snap["campos"])
+        dev = self.view.device
+        v, p, c = snap["pose"]
+        self.view.copy_(torch.from_numpy(v).to(dev)); self.proj.copy_(torch.from_numpy(p).to(dev)); self.campos.copy_(torch.from_numpy(c).to(dev))
+        self._pose_host = snap["pose"]
         gt = snap["gt"]
         if gt is None:
             if snap["gt_serial"] != getattr(self, "_gt_serial", 0):
