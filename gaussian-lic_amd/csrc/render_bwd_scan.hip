@@ -222,7 +222,11 @@ __device__ __forceinline__ void block_pass(ScanLds& S, const int lane, const int
     }
 }
 
-__global__ __launch_bounds__(64, 4) void render_bwd_scan_kernel(RenderBwdArgs a)
+#ifndef GS_SCAN_WAVES
+#define GS_SCAN_WAVES 4   // waves per SIMD the register allocation aims at (124 VGPRs, no spills).  5 (96 VGPRs, 34 spilled, all but three reloads outside the
+                          // chunk loops) was measured: 0.449 -> 0.592 ms (profiles/r04w_bwd_scan_five_waves_ab.log)
+#endif
+__global__ __launch_bounds__(64, GS_SCAN_WAVES) void render_bwd_scan_kernel(RenderBwdArgs a)
 {
     __shared__ ScanLds S;
     const int lane = threadIdx.x;
