@@ -24,6 +24,13 @@
 #include "kernels.h"
 #include <stdlib.h>
 
+// Timing by elimination (results are WRONG with any bit set; profiles/r04y_bwd_scan_by_elimination.log): 1 = no block passes, 2 = no quadrant loop at
+// all, 4 = block passes without their chunk loops, 8 = dead buckets do not flag their instances, 16 = no partial rows stored, 32 = no records gathered.
+// (the conditions also test a kernel argument that is never negative, so the code stays in the binary)
+#ifndef GS_SCAN_SKIP
+#define GS_SCAN_SKIP 0
+#endif
+
 namespace gslic {
 
 typedef float v2f_s __attribute__((ext_vector_type(2)));
@@ -62,25 +69,28 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
     return readlane_u(v, 0);
 }
 #else
+#ifndef GS_DPP_WAIT
+#define GS_DPP_WAIT "s_nop 1\n\t"   // (timing experiment: with "" the results are WRONG and the kernel is no faster — the wait states hide behind the other waves)
+#endif
 // inclusive product / sum over the 16 lanes of a row (lanes without a source keep the identity)
 // (the product scan is written out: with the builtin the compiler materialises the identity 1.0 for every step — v_mov + v_mov_dpp + v_mul —
 // where the add scan folds into v_add_f32_dpp with bound_ctrl; in place, a lane without a source lane is not written and keeps its own value.
 // s_nop 1: a DPP source written by the preceding VALU instruction needs two wait states)
 __device__ __forceinline__ float row_scan_mul(float x)
 {
-    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
+    asm(GS_DPP_WAIT "v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        GS_DPP_WAIT "v_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        GS_DPP_WAIT "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        GS_DPP_WAIT "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
         : "+v"(x));
     return x;
 }
 __device__ __forceinline__ float row_scan_add(float x)
 {
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
+    asm(GS_DPP_WAIT "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        GS_DPP_WAIT "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        GS_DPP_WAIT "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        GS_DPP_WAIT "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
         : "+v"(x));
     return x;
 }
@@ -161,7 +171,7 @@ __device__ __forceinline__ void block_pass(ScanLds& S, const int lane, const int
             ent[g] = e; kbit[g] = e & 31u; klo[g] = e < 32u ? 0xffffffffu : 0u;
         }
     }
-    const int nchunk = (npx_ + 3) >> 2;
+    const int nchunk = ((GS_SCAN_SKIP & 4) && c099 > 0.f) ? 0 : (npx_ + 3) >> 2;
     int off = rb + row;   // record index of this row's pixel; clamped to the block's all-zero record
     for (int c = 0; c < nchunk; c++, off += 4) {
         const int idx = off < npx ? off : npx;
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(64, GS_SCAN_WAVES) void render_bwd_scan_kernel(Rend
     const bool valid = kit < n;
     const uint32_t slot = valid ? a.inst_slot[range.x + kit] : 0u;
     if (bstart >= a.max_contrib[tile]) {   // bucket behind every pixel's last contributor (backward.cu:428)
-        if (valid) a.dead[slot] = 1;
+        if (valid && !((GS_SCAN_SKIP & 8) && a.T > -1)) a.dead[slot] = 1;
         return;
     }
     const int tx0 = (int)(tile % (uint32_t)a.gx) * GS_TILE, ty0 = (int)(tile / (uint32_t)a.gx) * GS_TILE;
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(64, GS_SCAN_WAVES) void render_bwd_scan_kernel(Rend
     {
     ScanEntry L = {0.f, 0.f, 0.f, 0.f, 0.f, -__builtin_inff(), 0.f, 0.f, 0.f};
     float rop = 0.f;
-    if (valid) {
+    if (valid && !((GS_SCAN_SKIP & 32) && a.T > -1)) {
         const uint32_t g = a.point_list[range.x + kit];
         const float4* rp = a.rec + GS_REC_F4 * (size_t)g;
         const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(64, GS_SCAN_WAVES) void render_bwd_scan_kernel(Rend
 #if GS_SCAN_PREFETCH
     PixIn nxt = load_pix(0);
 #endif
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < (((GS_SCAN_SKIP & 2) && a.T > -1) ? 0 : 4); q++) {
         // ---- lane = pixel of quadrant q
 #if GS_SCAN_PREFETCH
         const PixIn cur = nxt;
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(64, GS_SCAN_WAVES) void render_bwd_scan_kernel(Rend
         __builtin_amdgcn_wave_barrier();
         for (int h = 0; h < 2; h++) {
             const int npx = __popc(h ? balh[1] : balh[0]);
-            if (npx == 0) continue;
+            if (npx == 0 || ((GS_SCAN_SKIP & 1) && a.T > -1)) continue;
             const int ne = h ? __popc(S_lo[1]) + __popc(S_hi[1]) : __popc(S_lo[0]) + __popc(S_hi[0]);
             switch ((ne + 15) >> 4) {
             case 1: block_pass<1>(S, lane, h * SC_HALF, 64 * h, npx, ne, c099); break;
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(64, GS_SCAN_WAVES) void render_bwd_scan_kernel(Rend
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    if (valid) {   // lane = entry again: the instance's 36-byte row (as render_bwd_kernel writes it)
+    if (valid && !((GS_SCAN_SKIP & 16) && a.T > -1)) {   // lane = entry again: the instance's 36-byte row (as render_bwd_kernel writes it)
         const float4 e0 = S.ent[SC_ENT_F4 * lane], e1 = S.ent[SC_ENT_F4 * lane + 1], e2 = S.ent[SC_ENT_F4 * lane + 2];
         const ScanEntry L = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x};
         const float rop = e2.y;
