@@ -126,7 +126,7 @@ BinningState BinningState::carve(const void* base, size_t R, int end_bit, bool n
         g.gauss[i] = c.take<uint32_t>(R);
     }
     g.sort_scratch = c.take<char>(sort_scratch_bytes(g.plan));
-    g.partials = no_color ? nullptr : c.take<float>(9 * R);
+    g.partials = no_color ? nullptr : c.take<float>((size_t)GS_PROW * R);
     g.dead = no_color ? nullptr : c.take<uint8_t>(R);
     if (bytes) *bytes = c.used(base) + 256;
     return g;

@@ -11,6 +11,10 @@
 #define GS_REC_F4 3       // float4 slots per Gaussian record.  4 (64-byte stride: a record never straddles a 128-byte line) was measured:
                           // keybuild 0.0905 -> 0.089 ms, preprocess +2.5 %, render_bwd +1 % — the depth-order gather is not what the stride fixes
 #endif
+#ifndef GS_PROW
+#define GS_PROW 9         // floats per partial-gradient row of an instance (BinningState::partials).  12 / 16 (48- / 64-byte rows: fewer line straddles for the
+                          // scattered row stores of the blend backward, more bytes for the per-Gaussian kernel to read) were measured: render_bwd 0.449 -> 0.448 / 0.445 ms, no gain (profiles/r04y_bwd_scan_by_elimination.log)
+#endif
 #define GS_BUCKET 64      // checkpoint period = one wave of list entries (reference: 32 = one CUDA warp)
 #define GS_WAVE 64
 

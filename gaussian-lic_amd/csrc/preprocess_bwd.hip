@@ -387,7 +387,7 @@ __device__ __forceinline__ bool bwd_gather(const PreprocessBwdArgs& a, const int
 #pragma unroll
             for (int j = 0; j < UP; j++) {
                 if (live[j]) {
-                    const float* p = a.partials + 9 * (size_t)(u + j);
+                    const float* p = a.partials + GS_PROW * (size_t)(u + j);
                     q0[j] = *reinterpret_cast<const gs_v4f_u*>(p);
                     q1[j] = *reinterpret_cast<const gs_v4f_u*>(p + 4);
                     q2[j] = p[8];

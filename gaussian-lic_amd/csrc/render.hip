@@ -608,7 +608,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(RenderBwdArgs a)
         const float gy = __builtin_fmaf(2.0f * L.hAC.y, acc_S.y, L.nB * acc_S.x) * ky;
         // nine floats, one 36-byte row per instance (dword-aligned wide stores; plain, not non-temporal: rows at scattered slots need the
         // L2 to merge them — non-temporal: 0.59 -> 0.94 ms).  acc_op = sum of opacity * G * dL/dalpha (backward.cu:580 sums G * dL/dalpha)
-        float* o = a.partials + 9 * (size_t)slot;
+        float* o = a.partials + GS_PROW * (size_t)slot;
         *reinterpret_cast<gs_v4f_u*>(o) = (gs_v4f_u){gx, gy, -0.5f * acc_cxy.x, -0.5f * acc_cxy.y};
         *reinterpret_cast<gs_v4f_u*>(o + 4) = (gs_v4f_u){-0.5f * acc_cw, acc_op * rop, acc_rg.x, acc_rg.y};
         o[8] = acc_b;

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64, GS_SCAN_WAVES) void render_bwd_scan_kernel(Rend
         const float kx = 0.5f * (float)a.W / LOG2E, ky = 0.5f * (float)a.H / LOG2E;
         const float gx = __builtin_fmaf(2.0f * L.hA, Sx, L.nB * Sy) * kx;
         const float gy = __builtin_fmaf(2.0f * L.hC, Sy, L.nB * Sx) * ky;
-        float* o = a.partials + 9 * (size_t)slot;
+        float* o = a.partials + GS_PROW * (size_t)slot;
         *reinterpret_cast<gs_v4f_u*>(o) = (gs_v4f_u){gx, gy, -0.5f * cxx, -0.5f * cxy};
         *reinterpret_cast<gs_v4f_u*>(o + 4) = (gs_v4f_u){-0.5f * cyy, op * rop, cr, cg};
         o[8] = cb;
