@@ -421,7 +421,9 @@ def main():
         cpi = VALU_CYCLES_PER_INST["render_bwd" if (dominant == "render_bwd" and scan_on) else ("render_bwd_pipeline" if dominant == "render_bwd" else "render_fwd")]
         roofline["valu"] = dict(modelled_issue_cycles_per_inst=cpi, shader_clock_ghz=SHADER_CLOCK_GHZ, simds=1024,
                                 note="frac = VALU instructions per launch (rocprofv3 SQ_INSTS_VALU of the same workload) x modelled issue cycles per "
-                                     "instruction (instruction mix of the inner loop x tools/ubench/issue_rate) / (launch duration x 1024 SIMDs x clock)")
+                                     "instruction (instruction mix of the inner loop x tools/ubench/issue_rate) / (launch duration x 1024 SIMDs x clock).  "
+                                     "An upper bound on how issue-bound the kernel is: it counts the set-up code's instructions too, and timed by elimination "
+                                     "(profiles/r04y_bwd_scan_by_elimination.log) the row-scan backward's inner loops are 37 % of its time")
         try:
             import ast
             import glob
