@@ -1,4 +1,4 @@
-"""CPU: the list-order invariant behind `tools/experiments/dead_cutoff.patch` (open items: render_bwd).
+"""CPU: a list-order invariant of the binning (and what `tools/experiments/dead_cutoff.patch` relied on; measured and rejected, profiles/r04v).
 
 The blend backward skips every 64-entry bucket of a tile that lies behind the tile's last contributor (backward.cu:428) and tells the
 per-Gaussian backward which instances those are.  Today that is one flag byte per instance, scattered; the experiment replaces it by ONE key per
