@@ -58,6 +58,12 @@ __device__ __forceinline__ float strip_max_p2(float hA, float hC, float nB, floa
 // SPLIT = waves per tile (1, 2 or 4): each takes 4 / SPLIT of the tile's four 8x8 quadrants.  The kernel's duration is set by its
 // longest tiles (one wave alone on a SIMD issues a VALU instruction every 4.3 cycles, half the rate of a busy SIMD), so the default
 // splits every tile over two waves: +9 % instructions (the per-entry setup is repeated), half the latency of a long tile.
+// Timing by elimination (results are WRONG with any bit set; the counterpart of GS_SCAN_SKIP in render_bwd_scan.hip): 1 = no entry is blended,
+// 2 = no checkpoints stored, 4 = no decision masks stored, 8 = no records gathered.  (The conditions also test a kernel argument that is never
+// negative, so the code stays in the binary.)
+#ifndef GS_FWD_SKIP
+#define GS_FWD_SKIP 0
+#endif
 template <bool STRICT, int SPLIT>
 __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(RenderFwdArgs a)
 {
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
 #pragma unroll
         for (int q = 0; q < QN; q++) alldone = alldone && (T[q] < 0.f);
         if (__all(alldone)) break;
-        if (color && fits) {
+        if (color && fits && !((GS_FWD_SKIP & 2) && a.gx > -1)) {
             float4* ck = a.ckpt + ((size_t)(bbm + (uint32_t)(base / GS_BUCKET)) * GS_TILE_PIX) + lane;
 #pragma unroll
             for (int q = 0; q < QN; q++)
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
         float fdx = 0, fdy = 0, fhA = 0, fhC = 0, fnB = 0, fop = 0, flop = -__builtin_inff(), fr = 0, fg = 0, fb = 0;
         uint32_t fmask = 0;
         float fthr = 0.f;
-        if (lane < m) {
+        if (lane < m && !((GS_FWD_SKIP & 8) && a.gx > -1)) {
             const uint32_t g = a.point_list[range.x + (uint32_t)(base + lane)];
             const float4* rp = a.rec + GS_REC_F4 * (size_t)g;
             const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
             fthr = -0.6931472f * (flop + 7.9943534f) - 0.001f;
         }
         if constexpr (STRICT) {  // raw record: absolute mean, unscaled conic
-            if (lane < m) {
+            if (lane < m && !((GS_FWD_SKIP & 8) && a.gx > -1)) {
                 const uint32_t g = a.point_list[range.x + (uint32_t)(base + lane)];
                 const float4* rp = a.rec + GS_REC_F4 * (size_t)g;
                 const float4 r0 = rp[0], r1 = rp[1];
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
         };
         // two entries per trip: the records alternate between two register sets, each fetched (LDS broadcast) while the other is blended
         float4 a0 = s_rec[0], a1 = s_rec[1], a2 = s_rec[2], b0, b1, b2;
-        for (int j = 0; j < m; j += 2) {
+        for (int j = 0; j < (((GS_FWD_SKIP & 1) && a.gx > -1) ? 0 : m); j += 2) {
             if constexpr (STRICT) {
                 if (j == 32) {
 #pragma unroll
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(Rend
             blend_entry(b0, b1, b2, (uint32_t)(base + j + 2));
         }
         if constexpr (STRICT) {
-            if (color && fits) {   // pixel-major like the checkpoints: one coalesced 512-byte store per quadrant
+            if (color && fits && !((GS_FWD_SKIP & 4) && a.gx > -1)) {   // pixel-major like the checkpoints: one coalesced 512-byte store per quadrant
                 uint64_t* hp = a.hit + ((size_t)(bbm + (uint32_t)(base / GS_BUCKET)) * GS_TILE_PIX) + lane;
 #pragma unroll
                 for (int q = 0; q < QN; q++)
