@@ -7,8 +7,9 @@
 A "step" = one iteration of the reference's optimize() loop (src/gaussian.cpp:674-716) on one camera view:
 render forward -> 0.8*L1 + 0.2*(1-SSIM) -> backward -> visibility-masked Adam, at BASELINE.json config 3
 (2M Gaussians, 1920x1080, SH degree 3).  N > 1: one rank per GPU, each rank renders a different view of the same
-replica and the ranks exchange ONE gradient all-reduce (+ visibility max-reduce) per step ("weak" scaling: views
-per step = N).  value = views (fwd+bwd) per second over the whole job.
+replica and the ranks meet in ONE exchange step per optimiser step (default: an all-gather of the colour gradients +
+masks and two all-reduces of the small gradients; "weak" scaling: views per step = N).
+value = views (fwd+bwd) per second over the whole job.
 
 Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed inside the timed region) and
 `cpu_baseline` (the CPU oracle on a bounded 1/16-scale sample, N=1 only).
@@ -22,6 +23,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # multi-process GPU work on this driver needs dmabuf IPC (already exported on the GPU boxes)
 
 import numpy as np
 import torch
