@@ -116,14 +116,48 @@ def se3_exp(xi):
     return E
 
 
+def rotation_ypr(yaw_deg, pitch_deg, roll_deg):
+    """R_wc = R_y(yaw) R_x(pitch) R_z(roll) (camera convention of the scenes: +x right, +y down, +z forward), float64."""
+    y, p, r = (math.radians(float(v)) for v in (yaw_deg, pitch_deg, roll_deg))
+    Ry = np.array([[math.cos(y), 0, math.sin(y)], [0, 1, 0], [-math.sin(y), 0, math.cos(y)]])
+    Rx = np.array([[1, 0, 0], [0, math.cos(p), -math.sin(p)], [0, math.sin(p), math.cos(p)]])
+    Rz = np.array([[math.cos(r), -math.sin(r), 0], [math.sin(r), math.cos(r), 0], [0, 0, 1]])
+    return Ry @ Rx @ Rz
+
+
+# General SE(3) poses of the parity suites (VERDICT round 4: pitch AND roll >= 20 deg, translation on all axes, so that the W matrix of
+# forward.cu:101-104 / backward.cu:185 is dense and campos != 0).  "place": the scene (generated in the identity camera frame) is moved rigidly
+# into this pose's frame, so the camera still sees all of it; without it the camera looks at the identity-frame scene from the side: a large part
+# of it leaves the image, and Gaussians beyond the 15 % margins have their cov2D Jacobian clamped (forward.cu:91-94, backward.cu:177-178).
+SE3_POSES = {
+    "se3_a": dict(ypr=(25.0, -22.0, 31.0), t=(0.8, -0.5, 0.6), place=True),
+    "se3_b": dict(ypr=(-33.0, 24.0, -27.0), t=(-1.2, 0.7, -0.9), place=True),
+    "se3_c": dict(ypr=(21.0, -20.0, 23.0), t=(0.4, 0.3, -0.5), place=False),
+    "se3_d": dict(ypr=(-12.0, 26.0, -40.0), t=(-0.3, -0.6, 0.2), place=False),
+}
+
+
+def resolve_view(view):
+    """view spec -> (R_wc, t_wc, place) or None for the identity pose.  Accepted: None; k in 0..7 (SURVEY.md section 8d's config-4 views);
+    a name of SE3_POSES; a dict(ypr=(yaw, pitch, roll) degrees, t=(x, y, z), place=bool)."""
+    if view is None:
+        return None
+    if isinstance(view, str):
+        view = SE3_POSES[view]
+    if isinstance(view, dict):
+        return rotation_ypr(*view["ypr"]), np.asarray(view["t"], np.float64), bool(view.get("place", False))
+    a = math.radians((int(view) - 3.5) * 4.0)
+    R = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+    return R, np.array([(int(view) - 3.5) * 0.25, 0.0, 0.0]), False
+
+
 def synthetic_camera(W, H, view_index=None):
     """SURVEY.md §8d camera: fx = fy = 0.675 W, cx = 0.4857 W, cy = 0.5215 H (config/fastlivo.yaml:1-6 ratios).
-    view_index None -> identity pose; k in 0..7 -> yaw (k-3.5)*4 deg about +y, translation x = (k-3.5)*0.25 m."""
+    view_index None -> identity pose; k in 0..7 -> yaw (k-3.5)*4 deg about +y, translation x = (k-3.5)*0.25 m; a name of SE3_POSES or a
+    dict(ypr, t) -> that general pose (resolve_view)."""
     fx = fy = 0.675 * W
     cx, cy = 0.4857 * W, 0.5215 * H
-    if view_index is None:
+    pose = resolve_view(view_index)
+    if pose is None:
         return Camera(W, H, fx, fy, cx, cy)
-    a = math.radians((view_index - 3.5) * 4.0)
-    R = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
-    t = np.array([(view_index - 3.5) * 0.25, 0.0, 0.0])
-    return Camera(W, H, fx, fy, cx, cy, R, t)
+    return Camera(W, H, fx, fy, cx, cy, pose[0], pose[1])

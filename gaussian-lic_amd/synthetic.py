@@ -64,6 +64,46 @@ def lidar_scene(P, W, H, sh_degree=3, seed=0):
                 features_rest=rest.float().contiguous(), sh_degree=int(sh_degree))
 
 
+def _quat_from_matrix(R):
+    """(r, x, y, z) of a rotation matrix, float64 (Shepperd's branch on the largest diagonal term)."""
+    import numpy as np
+    R = np.asarray(R, np.float64)
+    tr = R[0, 0] + R[1, 1] + R[2, 2]
+    if tr > 0:
+        s = math.sqrt(tr + 1.0) * 2
+        q = (0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s)
+    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
+        s = math.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
+        q = ((R[2, 1] - R[1, 2]) / s, 0.25 * s, (R[0, 1] + R[1, 0]) / s, (R[0, 2] + R[2, 0]) / s)
+    elif R[1, 1] > R[2, 2]:
+        s = math.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
+        q = ((R[0, 2] - R[2, 0]) / s, (R[0, 1] + R[1, 0]) / s, 0.25 * s, (R[1, 2] + R[2, 1]) / s)
+    else:
+        s = math.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
+        q = ((R[1, 0] - R[0, 1]) / s, (R[0, 2] + R[2, 0]) / s, (R[1, 2] + R[2, 1]) / s, 0.25 * s)
+    return np.array(q, np.float64)
+
+
+def place_scene(raw, R_wc, t_wc):
+    """Moves a scene generated in the identity camera frame rigidly into the frame of the pose (R_wc, t_wc): xyz <- R_wc xyz + t_wc and
+    every Gaussian's quaternion <- q(R_wc) * q, computed in double and rounded to fp32 once.  A camera at that pose then sees what the
+    identity camera saw of the original scene (up to rounding and the view dependence of the SH colour)."""
+    import numpy as np
+    R = np.asarray(R_wc, np.float64)
+    t = np.asarray(t_wc, np.float64)
+    out = dict(raw)
+    xyz = raw["xyz"].double().numpy() @ R.T + t
+    out["xyz"] = torch.from_numpy(xyz).float().contiguous()
+    a = _quat_from_matrix(R)
+    b = raw["rotation"].double().numpy()
+    ar, ax, ay, az = a
+    br, bx, by, bz = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    q = np.stack([ar * br - ax * bx - ay * by - az * bz, ar * bx + ax * br + ay * bz - az * by,
+                  ar * by - ax * bz + ay * br + az * bx, ar * bz + ax * by - ay * bx + az * br], 1)
+    out["rotation"] = torch.from_numpy(q).float().contiguous()
+    return out
+
+
 def pixel_grad(H, W, seed=1):
     """dL/dimage ~ N(0,1), CHW, for backward-only parity."""
     return torch.randn(3, H, W, generator=_gen(seed)).float().contiguous()

@@ -26,6 +26,14 @@ CASES = [  # name, kind, P, W, H, deg, seed, lambda_erank
     ("random_1024_128x96_d3_erank", "random", 1024, 128, 96, 3, 15, 0.01),
 ]
 
+# Round 5: general SE(3) camera poses (camera.SE3_POSES: pitch and roll of 20-40 deg, translation on all axes), a scale_modifier != 1 and a
+# scene whose visible Gaussians are clamp-masked by the frustum limits (forward.cu:91-94).  name, kind, P, W, H, deg, seed, lambda_erank, extras
+POSED_CASES = [
+    ("random_1536_160x120_d3_se3a", "random", 1536, 160, 120, 3, 41, 0.0, dict(view="se3_a")),
+    ("lidar_1536_160x120_d3_se3c_mod07", "lidar", 1536, 160, 120, 3, 42, 0.0, dict(view="se3_c", scale_modifier=0.7)),
+    ("random_1024_128x96_d2_se3d_clamp", "random", 1024, 128, 96, 2, 43, 0.01, dict(view="se3_d", sigma_scale=2.5)),
+]
+
 
 def input_digest(sc, cam):
     h = hashlib.sha256()
@@ -36,17 +44,17 @@ def input_digest(sc, cam):
     return h.hexdigest()
 
 
-def main(outdir):
-    from conftest import make_scene
+def rasterizer_golden(rk, outdir, cases):
+    from conftest import clamp_masked_visible, make_scene
     from gaussian_lic_amd.synthetic import pixel_grad
-    from oracle.ref_build.refkernels import RefKernels
-    os.makedirs(outdir, exist_ok=True)
-    rk = RefKernels()
-    for name, kind, P, W, H, deg, seed, le in CASES:
-        raw, sc, camd, cam = make_scene(kind, P, W, H, deg, seed)
+    for case in cases:
+        name, kind, P, W, H, deg, seed, le = case[:8]
+        extra = case[8] if len(case) > 8 else {}
+        view, sigma_scale, mod = extra.get("view"), extra.get("sigma_scale", 1.0), extra.get("scale_modifier", 1.0)
+        raw, sc, camd, cam = make_scene(kind, P, W, H, deg, seed, view=view, sigma_scale=sigma_scale)
         dL = pixel_grad(H, W, seed=1).numpy()
-        out = rk.run(sc, camd, dL, lambda_erank=le)
-        nc = rk.run(sc, camd, None, no_color=True)
+        out = rk.run(sc, camd, dL, lambda_erank=le, scale_modifier=mod)
+        nc = rk.run(sc, camd, None, no_color=True, scale_modifier=mod)
         keep = {k: v for k, v in out.items() if isinstance(v, np.ndarray)}
         keep["final_T_no_color"] = nc["final_T"]
         for k in ("means", "scales", "rots", "opac", "dc", "shs"):
@@ -57,8 +65,18 @@ def main(outdir):
         keep["in_dL_dpix"] = dL
         meta = dict(kind=kind, P=P, W=W, H=H, deg=deg, seed=seed, lambda_erank=le, R=out["R"], B32=out["B"],
                     R_no_color=nc["R"], B_no_color=nc["B"], digest=input_digest(sc, camd))
+        if extra:
+            meta.update(view=view, sigma_scale=sigma_scale, scale_modifier=mod, clamp_masked_visible=clamp_masked_visible(sc, camd, out["radii"]))
         np.savez_compressed(os.path.join(outdir, name + ".npz"), meta=np.array(repr(meta)), **keep)
-        print(name, "R", out["R"], "B32", out["B"], "visible", int((out["radii"] > 0).sum()), flush=True)
+        print(name, "R", out["R"], "B32", out["B"], "visible", int((out["radii"] > 0).sum()),
+              "clamp-masked visible", meta.get("clamp_masked_visible"), flush=True)
+
+
+def main(outdir):
+    from oracle.ref_build.refkernels import RefKernels
+    os.makedirs(outdir, exist_ok=True)
+    rk = RefKernels()
+    rasterizer_golden(rk, outdir, CASES + POSED_CASES)
     # Adam golden (adam.cu through ADAM::adamUpdate)
     rng = np.random.default_rng(0)
     N, M = 500, 45
@@ -116,9 +134,12 @@ def ssim_golden(rk, outdir):
 
 if __name__ == "__main__":
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "golden")
-    if len(sys.argv) > 2 and sys.argv[2] in ("ssim", "knn"):   # only the fused-SSIM / simple-knn vectors
+    if len(sys.argv) > 2 and sys.argv[2] in ("ssim", "knn", "posed"):   # only the fused-SSIM / simple-knn / posed-camera vectors
         from oracle.ref_build.refkernels import RefKernels
         os.makedirs(out, exist_ok=True)
-        (ssim_golden if sys.argv[2] == "ssim" else knn_golden)(RefKernels(), out)
+        if sys.argv[2] == "posed":
+            rasterizer_golden(RefKernels(), out, POSED_CASES)
+        else:
+            (ssim_golden if sys.argv[2] == "ssim" else knn_golden)(RefKernels(), out)
     else:
         main(out)

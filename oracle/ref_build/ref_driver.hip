@@ -15,6 +15,7 @@ struct Ctx {
     std::vector<void*> allocs;
     int P = 0, D = 0, M = 0, W = 0, H = 0, R = 0, B = 0;
     float tanfovx, tanfovy, lxn, lxp, lyn, lyp;
+    float scale_modifier = 1.0f;  // renderer.h:36; set through ref_set_scale_modifier before ref_forward
     float *means = nullptr, *dc = nullptr, *shs = nullptr, *opac = nullptr, *scales = nullptr, *rots = nullptr;
     float *view = nullptr, *proj = nullptr, *campos = nullptr, *bg = nullptr;
     float *out_color = nullptr, *out_T = nullptr;
@@ -49,6 +50,7 @@ extern "C" {
 
 void* ref_create() { return new Ctx(); }
 void ref_destroy(void* c) { delete (Ctx*)c; }
+void ref_set_scale_modifier(void* c, float m) { ((Ctx*)c)->scale_modifier = m; }
 
 int ref_forward(void* vc, int P, int D, int M, int W, int H, const float* means, const float* dc, const float* shs,
                 const float* opac, const float* scales, const float* rots, const float* view, const float* proj,
@@ -71,7 +73,7 @@ int ref_forward(void* vc, int P, int D, int M, int W, int H, const float* means,
     std::function<char*(size_t)> fi = [&](size_t n) { return c.img = c.scratch(n); };
     std::function<char*(size_t)> fs = [&](size_t n) { return c.sample = c.scratch(n); };
     auto t = CudaRasterizer::Rasterizer::forward(fg, fb, fi, fs, P, D, M, c.bg, W, H, c.means, c.dc, c.shs, nullptr, c.opac, c.scales,
-                                                 1.0f, c.rots, nullptr, c.view, c.proj, c.campos, tanfovx, tanfovy, lxn, lxp, lyn, lyp,
+                                                 c.scale_modifier, c.rots, nullptr, c.view, c.proj, c.campos, tanfovx, tanfovy, lxn, lxp, lyn, lyp,
                                                  false, c.out_color, c.out_T, c.radii, false, no_color != 0);
     HCHK(hipDeviceSynchronize());
     c.R = std::get<0>(t); c.B = std::get<1>(t);
@@ -118,7 +120,7 @@ int ref_backward(void* vc, const float* dL_dpix, float lambda_erank, float* dL_d
     float *g2 = c.dev<float>(nullptr, 3 * P), *gc = c.dev<float>(nullptr, 4 * P), *go = c.dev<float>(nullptr, P), *gcol = c.dev<float>(nullptr, 3 * P);
     float *g3 = c.dev<float>(nullptr, 3 * P), *gcov = c.dev<float>(nullptr, 6 * P), *gdc = c.dev<float>(nullptr, 3 * P);
     float *gsh = c.dev<float>(nullptr, 3 * (size_t)c.M * P + 4), *gs = c.dev<float>(nullptr, 3 * P), *gr = c.dev<float>(nullptr, 4 * P);
-    CudaRasterizer::Rasterizer::backward(c.P, c.D, c.M, c.R, c.B, c.bg, c.W, c.H, c.means, c.dc, c.shs, nullptr, c.scales, 1.0f, c.rots,
+    CudaRasterizer::Rasterizer::backward(c.P, c.D, c.M, c.R, c.B, c.bg, c.W, c.H, c.means, c.dc, c.shs, nullptr, c.scales, c.scale_modifier, c.rots,
                                          nullptr, c.view, c.proj, c.campos, c.tanfovx, c.tanfovy, c.lxn, c.lxp, c.lyn, c.lyp, c.radii, c.geom,
                                          c.binning, c.img, c.sample, d_pix, g2, gc, go, gcol, g3, gcov, gdc, gsh, gs, gr, lambda_erank, false);
     HCHK(hipDeviceSynchronize());

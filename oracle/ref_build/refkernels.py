@@ -24,7 +24,7 @@ class RefKernels:
         self.lib.ref_create.restype = ctypes.c_void_p
         self.lib.ref_destroy.argtypes = [ctypes.c_void_p]
 
-    def run(self, sc, cam, dL_dpix=None, no_color=False, lambda_erank=0.0):
+    def run(self, sc, cam, dL_dpix=None, no_color=False, lambda_erank=0.0, scale_modifier=1.0):
         """sc: activated numpy scene (synthetic.to_numpy(activate(raw))); cam: Camera.as_dict().  Returns dict of
         every stage boundary the reference's forward/backward produce."""
         L = self.lib
@@ -41,6 +41,9 @@ class RefKernels:
         ctx = ctypes.c_void_p(L.ref_create())
         cf = ctypes.c_float
         try:
+            if scale_modifier != 1.0:
+                L.ref_set_scale_modifier.argtypes = [ctypes.c_void_p, ctypes.c_float]
+                L.ref_set_scale_modifier(ctx, cf(scale_modifier))
             rc = L.ref_forward(ctx, P, int(sc["D"]), M, W, H, _p(means), _p(dc), _p(shs), _p(opac), _p(scales), _p(rots), _p(view),
                                _p(proj), _p(campos), cf(cam["tanfovx"]), cf(cam["tanfovy"]), cf(cam["limx_neg"]), cf(cam["limx_pos"]),
                                cf(cam["limy_neg"]), cf(cam["limy_pos"]), int(no_color), _p(out["color"]), _p(out["final_T"]),

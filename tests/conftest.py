@@ -27,14 +27,35 @@ def oracle64():
     return Oracle(np.float64)
 
 
-def make_scene(kind, P, W, H, deg, seed=0, view=None):
-    """(raw torch params, activated numpy dict for the oracle, camera dict, Camera)"""
+def make_scene(kind, P, W, H, deg, seed=0, view=None, sigma_scale=1.0):
+    """(raw torch params, activated numpy dict for the oracle, camera dict, Camera).
+    view: None (identity pose) | k in 0..7 (config-4 views) | a name of camera.SE3_POSES | dict(ypr=, t=, place=) — see camera.resolve_view;
+    with place=True the scene is moved rigidly into the pose's frame (synthetic.place_scene).  sigma_scale multiplies every Gaussian's extent
+    (adds log(sigma_scale) to the raw scaling): large Gaussians reach the image from beyond the 15 % margins where the cov2D Jacobian is clamped."""
+    import math
     import gaussian_lic_amd  # noqa: F401
-    from gaussian_lic_amd.camera import synthetic_camera
-    from gaussian_lic_amd.synthetic import activate, lidar_scene, random_scene, to_numpy
+    from gaussian_lic_amd.camera import resolve_view, synthetic_camera
+    from gaussian_lic_amd.synthetic import activate, lidar_scene, place_scene, random_scene, to_numpy
     cam = synthetic_camera(W, H, view)
     raw = (random_scene if kind == "random" else lidar_scene)(P, W, H, sh_degree=deg, seed=seed)
+    pose = resolve_view(view)
+    if pose is not None and pose[2]:
+        raw = place_scene(raw, pose[0], pose[1])
+    if sigma_scale != 1.0:
+        raw["scaling"] = (raw["scaling"] + math.log(sigma_scale)).contiguous()
     return raw, to_numpy(activate(raw)), cam.as_dict(), cam
+
+
+def clamp_masked_visible(sc, camd, radii):
+    """Number of visible Gaussians (radii > 0) whose view-space t.x / t.z or t.y / t.z lies outside the lim window, i.e. whose cov2D Jacobian
+    the reference clamps (forward.cu:91-94) and whose backward zeroes the x / y chain (backward.cu:177-178,248-249).  float64 estimate."""
+    V = np.asarray(camd["view"], np.float64).reshape(4, 4).T      # stored transposed: element (r, c) at [4c + r]
+    p = np.asarray(sc["means"], np.float64)
+    t = p @ V[:3, :3].T + V[:3, 3]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tx, ty = t[:, 0] / t[:, 2], t[:, 1] / t[:, 2]
+    out = (tx < camd["limx_neg"]) | (tx > camd["limx_pos"]) | (ty < camd["limy_neg"]) | (ty > camd["limy_pos"])
+    return int((out & (np.asarray(radii) > 0)).sum())
 
 
 def rel_err(a, b):

@@ -9,19 +9,53 @@ TOL = 1e-4
 GRADS = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_ddc", "dL_dsh", "dL_dscale", "dL_drot")
 
 
-def _err_stats(got, ref, scale=None):
+def _err_stats(got, ref, scale=None, keep_over=False):
     got = np.asarray(got, np.float64).reshape(-1)
     ref = np.asarray(ref, np.float64).reshape(-1)
     if ref.size == 0:
         return dict(n=0, over=0, max_rel=0.0, bit_equal=True)
     scale = max(float(np.abs(ref).max()), 1e-30) if scale is None else scale
     err = np.abs(got - ref) / scale
-    return dict(n=int(ref.size), over=int((err > TOL).sum()), max_rel=float(err.max()), bit_equal=bool(np.array_equal(got, ref)))
+    out = dict(n=int(ref.size), over=int((err > TOL).sum()), max_rel=float(err.max()), bit_equal=bool(np.array_equal(got, ref)))
+    if keep_over and out["over"]:
+        out["_over_idx"], out["_scale"] = np.nonzero(err > TOL)[0], scale
+    return out
 
 
-def compare(kind, P, W, H, deg, seed, modes=("fast", "strict"), backward=True):
+PROBE_MAX_P = 80000      # the conditioning probe runs the CPU oracle twice: small scenes only
+ILL_CONDITIONED = 1e-5   # fp32 (sequential C oracle) vs fp64 at the element, relative to the tensor's max-abs
+
+
+def conditioning_probe(st, sc, camd, dL, scale_modifier, lambda_erank=0.0):
+    """For every gradient of `st` with elements beyond 1e-4: how many of THOSE elements are ill-conditioned in fp32, i.e. the fp32 C oracle — the
+    reference's arithmetic in sequential order — is itself more than 1e-5 of the tensor's max-abs away from the double-precision oracle on the same
+    inputs.  Adds st[k]["over_ill_conditioned"] and st[k]["fp32_vs_fp64_at_over"]; drops the private index arrays."""
+    from oracle.oracle import Oracle, build
+    need = [k for k in GRADS if k in st and "_over_idx" in st[k]]
+    if need:
+        build()
+        sc = dict(sc, scale_modifier=scale_modifier)
+        g = {}
+        for dt in (np.float32, np.float64):
+            o = Oracle(dt)
+            f = o.forward(sc, camd)
+            g[dt] = o.backward(sc, camd, f, dL, lambda_erank=lambda_erank)
+        for k in need:
+            idx, scale = st[k]["_over_idx"], st[k]["_scale"]
+            a, b = np.asarray(g[np.float32][k], np.float64).reshape(-1)[idx], np.asarray(g[np.float64][k], np.float64).reshape(-1)[idx]
+            e = np.abs(a - b) / scale
+            st[k]["over_ill_conditioned"] = int((e > ILL_CONDITIONED).sum())
+            st[k]["fp32_vs_fp64_at_over"] = [float(f"{v:.2e}") for v in e[:8]]
+    for k in GRADS:
+        if k in st:
+            st[k].pop("_over_idx", None); st[k].pop("_scale", None)
+
+
+def compare(kind, P, W, H, deg, seed, modes=("fast", "strict"), backward=True, view=None, sigma_scale=1.0, scale_modifier=1.0):
     """Returns {"scene":…, "ref": {...unit counts}, "<mode>": {stage: stats}}.  P must be a multiple of 256 (with a partial last block
-    the reference's duplicateWithKeys races pad keys over the last Gaussian's slots, rasterizer_impl.cu:73-131)."""
+    the reference's duplicateWithKeys races pad keys over the last Gaussian's slots, rasterizer_impl.cu:73-131).
+    view / sigma_scale: conftest.make_scene (camera pose: identity, a config-4 view, a general SE(3) pose; extent of the Gaussians);
+    scale_modifier: the rasterizer setting of renderer.h:36 / forward.cu:120-149, passed to both sides."""
     import torch
     from conftest import make_scene
     from gpu_helpers import hip_backward, hip_forward, npy
@@ -30,17 +64,18 @@ def compare(kind, P, W, H, deg, seed, modes=("fast", "strict"), backward=True):
     from oracle.ref_build import refkernels
     assert P % 256 == 0
     rk = refkernels.RefKernels()
-    raw, sc, camd, cam = make_scene(kind, P, W, H, deg, seed)
+    from conftest import clamp_masked_visible
+    raw, sc, camd, cam = make_scene(kind, P, W, H, deg, seed, view=view, sigma_scale=sigma_scale)
     dL = pixel_grad(H, W, seed=1)
-    ref = rk.run(sc, camd, dL.numpy() if backward else None)
+    ref = rk.run(sc, camd, dL.numpy() if backward else None, scale_modifier=scale_modifier)
     vis = ref["radii"] > 0
-    out = dict(scene=dict(kind=kind, P=P, W=W, H=H, deg=deg, seed=seed),
-               ref=dict(R=int(ref["R"]), B32=int(ref["B"]), visible=int(vis.sum())))
+    out = dict(scene=dict(kind=kind, P=P, W=W, H=H, deg=deg, seed=seed, view=view, sigma_scale=sigma_scale, scale_modifier=scale_modifier),
+               ref=dict(R=int(ref["R"]), B32=int(ref["B"]), visible=int(vis.sum()), clamp_masked_visible=clamp_masked_visible(sc, camd, ref["radii"])))
     for mode in modes:
         prev = _lib.set_math_mode(mode == "strict")
         try:
             got = hip_forward(raw, cam, export=("tiles_touched", "means2D", "depths", "conic_opacity", "rgb", "point_list", "ranges",
-                                                "n_contrib"))
+                                                "n_contrib"), scale_modifier=scale_modifier)
             d = got["dbg"]
             st = {}
             tt_h = npy(d["tiles_touched"]).astype(np.uint32)
@@ -66,7 +101,9 @@ def compare(kind, P, W, H, deg, seed, modes=("fast", "strict"), backward=True):
                     scale = None
                     if k == "dL_drot":   # unnormalised-quaternion gradient: scale of the chain it belongs to (as test_vs_reference_kernels_gpu.py)
                         scale = max(float(np.abs(ref["dL_drot"]).max()), float(np.abs(ref["dL_dscale"]).max() * sc["scales"].max()))
-                    st[k] = _err_stats(g[k], ref[k], scale)
+                    st[k] = _err_stats(g[k], ref[k], scale, keep_over=(mode == "strict" and P <= PROBE_MAX_P))
+                if mode == "strict" and P <= PROBE_MAX_P:
+                    conditioning_probe(st, sc, camd, dL.numpy(), scale_modifier)
             out[mode] = st
             del got
             torch.cuda.empty_cache()
@@ -130,7 +167,11 @@ def summarize(res):
     """One line per mode: what a reader of the test log needs."""
     lines = []
     s = res["scene"]
-    lines.append(f"{s['kind']} P={s['P']} {s['W']}x{s['H']} deg{s['deg']}: R={res['ref']['R']} visible={res['ref']['visible']}")
+    pose = "" if s.get("view") is None else f" view={s['view']}"
+    pose += "" if s.get("sigma_scale", 1.0) == 1.0 else f" sigma_scale={s['sigma_scale']}"
+    pose += "" if s.get("scale_modifier", 1.0) == 1.0 else f" scale_modifier={s['scale_modifier']}"
+    lines.append(f"{s['kind']} P={s['P']} {s['W']}x{s['H']} deg{s['deg']} seed={s['seed']}{pose}: R={res['ref']['R']} visible={res['ref']['visible']} "
+                 f"clamp-masked visible={res['ref'].get('clamp_masked_visible')}")
     for mode in ("fast", "strict"):
         if mode not in res:
             continue
@@ -144,6 +185,7 @@ def summarize(res):
                  f"n_contrib!={st['n_contrib_mismatch']}/{npx}"]
         for k in GRADS:
             if k in st:
-                parts.append(f"{k} over={st[k]['over']}/{st[k]['n']} max={st[k]['max_rel']:.2e}")
+                ill = f" (ill-conditioned in fp32: {st[k]['over_ill_conditioned']}, fp32 vs fp64 there {st[k]['fp32_vs_fp64_at_over']})" if "over_ill_conditioned" in st[k] else ""
+                parts.append(f"{k} over={st[k]['over']}/{st[k]['n']} max={st[k]['max_rel']:.2e}{ill}")
         lines.append(f"  [{mode}] " + "  ".join(parts))
     return "\n".join(lines)

@@ -197,3 +197,43 @@ def test_adam_formula(oracle32):
     assert rel_err(p[vis], p_ref[vis]) < 1e-6
     np.testing.assert_array_equal(p[~vis], p0[~vis])
     assert float(np.abs(m[~vis]).max()) == 0.0 and float(np.abs(v[~vis]).max()) == 0.0
+
+
+@pytest.mark.parametrize("pose", ["se3_a", "se3_b", 6])
+def test_rigid_motion_of_scene_and_camera_leaves_the_render_unchanged(oracle64, pose):
+    """Pins the oracle's handling of a NON-IDENTITY pose mathematically, independent of the reference: moving the world rigidly (positions and
+    Gaussian orientations) and the camera with it must reproduce the identity-pose render — image, final_T, radii, per-tile lists — and rotate the
+    position gradients (dL/dxyz_world = R_wc dL/dxyz_cam), at SH degree 0 (no view dependence of the colour left).  A transposed or mis-indexed view
+    matrix in transformPoint4x3 / the W of cov2D (auxiliary.h:70-78, forward.cu:101-104, backward.cu:185), or a wrong camera centre, breaks it.
+    Double precision on double inputs, so the bar is tight."""
+    from gaussian_lic_amd.camera import resolve_view, synthetic_camera
+    from gaussian_lic_amd.synthetic import _quat_from_matrix, pixel_grad
+    W, H, P = 128, 96, 1500
+    raw, sc, camd0, cam0 = make_scene("random", P, W, H, 0, 5)
+    R, t, _ = resolve_view(pose)
+    cam1 = synthetic_camera(W, H, pose)
+    sc0 = {k: (np.asarray(v, np.float64) if isinstance(v, np.ndarray) else v) for k, v in sc.items()}
+    sc1 = dict(sc0)
+    sc1["means"] = sc0["means"] @ R.T + t
+    a, b = _quat_from_matrix(R), sc0["rots"]
+    ar, ax, ay, az = a
+    br, bx, by, bz = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    sc1["rots"] = np.stack([ar * br - ax * bx - ay * by - az * bz, ar * bx + ax * br + ay * bz - az * by,
+                            ar * by - ax * bz + ay * br + az * bx, ar * bz + ax * by - ay * bx + az * br], 1)
+    # the camera matrices in double as well (camera.py rounds them to fp32 as camera.h does: rebuild them from the pose here)
+    camd1 = cam1.as_dict()
+    V = np.eye(4); V[:3, :3] = R.T; V[:3, 3] = -R.T @ t
+    Pm = np.asarray(cam0.projection_matrix, np.float64).T
+    camd1["view"], camd1["proj"], camd1["campos"] = V.T.reshape(16).copy(), (Pm @ V).T.reshape(16).copy(), t.copy()
+    f0, f1 = oracle64.forward(sc0, camd0), oracle64.forward(sc1, camd1)
+    assert f0["num_rendered"] > 3000
+    assert (f0["pre"]["radii"] != f1["pre"]["radii"]).sum() <= 1 and abs(f0["num_rendered"] - f1["num_rendered"]) <= 2
+    assert rel_err(f1["color"], f0["color"]) < 1e-6 and rel_err(f1["final_T"], f0["final_T"]) < 1e-6
+    dL = pixel_grad(H, W, seed=1).numpy()
+    g0, g1 = oracle64.backward(sc0, camd0, f0, dL), oracle64.backward(sc1, camd1, f1, dL)
+    assert rel_err(g1["dL_dmean3D"], g0["dL_dmean3D"] @ R.T) < 1e-6
+    for k in ("dL_dscale", "dL_dopacity", "dL_ddc", "dL_dmean2D"):
+        assert rel_err(g1[k], g0[k]) < 1e-6, k
+    # ... and the identity-pose render is NOT reproduced when the camera alone moves (the test has teeth)
+    f2 = oracle64.forward(sc0, camd1)
+    assert rel_err(f2["color"], f0["color"]) > 1e-2
