@@ -4,6 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+Both forms work for N > 1: without WORLD_SIZE in the environment `--gpus N` spawns the N ranks itself (torch.distributed.run on 127.0.0.1).
+
 A "step" = one iteration of the reference's optimize() loop (src/gaussian.cpp:674-716) on one camera view:
 render forward -> 0.8*L1 + 0.2*(1-SSIM) -> backward -> visibility-masked Adam, at BASELINE.json config 3
 (2M Gaussians, 1920x1080, SH degree 3).  N > 1: one rank per GPU, each rank renders a different view of the same
@@ -12,7 +14,13 @@ masks and two all-reduces of the small gradients; "weak" sc
 value = views (fwd+bwd) per second over the whole job.
 
 Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed inside the timed region) and
-`cpu_baseline` (the CPU oracle on a bounded 1/16-scale sample, N=1 only).
+`cpu_baseline` (the CPU oracle, N=1 only).  At N > 1 the line also carries `rccl_ranks` (ranks a real all-reduce reached), `per_rank_ms_per_step`,
+`exchange`, `launch` and `rccl_microbench` (the step's collectives alone at the step's sizes).
+
+The process that measures the contract line measures nothing else.  At N = 1 it then runs SURVEY 8d's literal config-3 schedule (1.5M -> 2.0M
+Gaussians by five extend() appends, the reference's learning rates) in a SECOND process and puts it into `config.growth_schedule` beside the
+stationary line; `--extras` adds the secondary legs (views_cycle, math_modes, other_host_path, graphed, joint_pose_step, C++ hosts) the same way;
+`--no-extras` runs neither.
 """
 import argparse
 import json
@@ -115,6 +123,52 @@ def _trace(msg):
         pass
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run ourselves under torch.distributed.run with N ranks on this node (rendezvous on
+    127.0.0.1, a free port) — exactly the command the driver uses for N > 1 — and hand its exit code back.  Rank 0 of the child prints the line."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without WORLD_SIZE: launching {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    env = dict(os.environ, GSLIC_BENCH_SELF_LAUNCHED="1")
+    return subprocess.call(cmd, env=env)
+
+
+def run_leg_process(leg, budget_s, args):
+    """A secondary leg in a process of its own (`bench.py --leg NAME` with this run's size flags): the contract line's process measures the
+    contract and nothing else.  Returns the leg's JSON dict, or {"error": ...}; a leg that overruns its budget is killed (its PID, nothing else)."""
+    import subprocess
+    keep = ["--gaussians", str(args.gaussians), "--width", str(args.width), "--height", str(args.height), "--scene", args.scene, "--lr-scale", repr(args.lr_scale),
+            "--views", str(args.views), "--steps", str(args.steps), "--density", repr(args.density), "--opacity-shift", repr(args.opacity_shift), "--math", args.math, "--map-order", args.map_order]
+    keep += ["--ply", args.ply] if args.ply else []
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", leg, "--no-cpu-baseline"] + keep
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GSLIC_FORCE_DIST")}
+    t0 = time.perf_counter()
+    try:
+        pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=sys.stderr, text=True)
+        try:
+            so, _ = pr.communicate(timeout=budget_s)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            pr.communicate()
+            return {"error": f"leg '{leg}' stopped after its budget of {budget_s:.0f} s"}
+        line = [l for l in so.splitlines() if l.startswith("{")]
+        if pr.returncode != 0 or not line:
+            return {"error": f"leg '{leg}' rc {pr.returncode}: {so[-300:]}"}
+        res = json.loads(line[-1])
+        res["process_seconds"] = round(time.perf_counter() - t0, 1)
+        return res
+    except Exception as ex:
+        return {"error": str(ex)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,28 +202,49 @@ def main():
     ap.add_argument("--views", type=int, default=16, help="views of the `views_cycle` leg: K synthetic cameras (yaw / translation rig of SURVEY 8d continued) with K "
                                                              "different targets, visited in a shuffled order, every step's target uploaded from pinned host memory on a "
                                                              "side stream while the previous step runs — the reference's optimize() pattern (gaussian.cpp:645-678); 0 = skip")
+    ap.add_argument("--map-order", default="morton", choices=["morton", "insertion"],
+                    help="row order of the map in device memory (trainer.GaussianModel(order=...)).  morton (default): the library keeps the rows sorted along a "
+                         "space-filling curve, as a SLAM map's frame-by-frame insertion order does by itself and the synthetic scene's random order does not; "
+                         "results are bit-identical to the insertion order (tests/test_morton_order_gpu.py).  insertion: the rows as generated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements of the default run (other host path, graphed step, growth schedule)")
+    ap.add_argument("--no-extras", action="store_true", help="the contract line only: no second process at all (neither the growth-schedule leg nor --extras)")
+    ap.add_argument("--extras", action="store_true", help="after the contract measurements, run the secondary legs (views_cycle, math_modes, other_host_path, graphed, "
+                                                          "joint_pose_step, cpp hosts) in a SECOND process and merge its results into the line")
+    ap.add_argument("--leg", default=None, choices=["growth_schedule", "extras"], help=argparse.SUPPRESS)   # child mode of the two lines above
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every kernel inside the timed region (adds overhead)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))   # `python bench.py --gpus N`, the shape of the driver's N = 1 command: spawn the N ranks ourselves
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    dev = torch.device("cuda", local_rank)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run (or let bench.py spawn the ranks: unset WORLD_SIZE)"
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)   # before the process group: RCCL binds the communicator to the current device
+    # one rank per GPU over RCCL is the product path.  On a box with fewer GPUs than ranks (a one-GPU box running `--gpus 2`) the ranks share
+    # devices, which RCCL refuses (duplicate GPU in a communicator): the SAME step then runs its collectives through gloo on device tensors,
+    # the line says so in `launch.backend`, and `rccl_ranks` stays null — a plumbing check, not a scaling number.
+    backend = "nccl" if world <= ndev else "gloo"
     if world > 1 or os.environ.get("GSLIC_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
 
     import gaussian_lic_amd  # noqa: F401
     from gaussian_lic_amd import _lib, trainer
     from gaussian_lic_amd.camera import synthetic_camera
     from gaussian_lic_amd.synthetic import gt_image, lidar_scene, pixel_grad, random_scene
 
+    if args.leg is not None:   # child mode: one secondary leg in this process, its JSON dict on stdout, nothing else
+        res = growth_schedule(args, dev) if args.leg == "growth_schedule" else secondary_legs(args, dev)
+        print(json.dumps(res), flush=True)
+        return
     W, H, P = args.width, args.height, args.gaussians
     if args.math != "default":
         _lib.set_math_mode(args.math == "strict")
@@ -192,7 +267,7 @@ def main():
         u_pix = raw["xyz"][:, 0] * (0.675 * W) / raw["xyz"][:, 2].abs().clamp_min(0.2) + 0.4857 * W
         keep = u_pix < 0.7 * W
         raw = {k: (v[keep].contiguous() if torch.is_tensor(v) else v) for k, v in raw.items()}
-    model = trainer.GaussianModel(raw, dev, capacity=P if args.mode == "slam" else None)
+    model = trainer.GaussianModel(raw, dev, capacity=P if args.mode == "slam" else None, order=args.map_order)
     from gaussian_lic_amd.trainer import DEFAULT_LRS
     model.training_setup({k: v * args.lr_scale for k, v in DEFAULT_LRS.items()})
     cam = synthetic_camera(W, H, None if world == 1 else rank % 8).to_device(dev)
@@ -247,8 +322,10 @@ def main():
     # ---- N > 1 (and the one-rank group that stands in for it): prime the exchange path before the W warm-up steps.  The 79th step of a process
     # group stalls for 36-39 ms, once, reproducibly (tools/diag_dist_warmup.py: a runtime-side pool growing after ~240 collectives); inside
     # a 20- or 100-step timed region that one stall reads as +0.4 .. +1.9 ms per step.  Priming is initialisation, not part of W or K.
+    prime_steps = 0
     if trainer._dist_on() and args.mode == "train" and args.host == "fused":
-        for _ in range(int(os.environ.get("GSLIC_DIST_PRIME_STEPS", "90"))):
+        prime_steps = int(os.environ.get("GSLIC_DIST_PRIME_STEPS", "90"))
+        for _ in range(prime_steps):
             step()
         torch.cuda.synchronize()
     _trace("model on the device; warm-up")
@@ -400,6 +477,7 @@ def main():
             # depends on (visible Gaussians, instances, live instances / buckets) within 2 % of this run's — otherwise traffic is null
             pu = pmc.get("units") or {}
             pmc_units_ok = (pmc.get("workload") == f"{args.scene}-{P}-{W}x{H}" and strict_mode == bool(pmc.get("strict", True)) and
+                            pmc.get("map_order", "insertion") == args.map_order and
                             all(k in pu and stats.get(k) and abs(pu[k] - stats[k]) <= 0.02 * stats[k] for k in ("V", "R", "R_live", "B_live")))
             scan_key = f"{dominant}_scan_kernel" if (strict_mode and os.environ.get("GSLIC_BWD_SCAN", "1") != "0") else None
             for key in (scan_key, f"{dominant}_kernel", dominant):
@@ -480,13 +558,14 @@ def main():
                                + (" (fused entry points: activations and loss inside the kernels)" if args.host == "fused" and args.mode != "render"
                                   else " (reference operator API + LibTorch autograd)")
                                + (f"; learning rates x{args.lr_scale:g} (stationary synthetic scene)" if args.mode != "render" else "")
+                               + ("; map rows kept in Morton order by the library (bit-identical results; `insertion_order` beside it with --extras)" if args.map_order == "morton" else "")
                                + ("; step replayed as one hipGraph (capacity-mode forward)" if args.graph else "")
                                + ("; extend() append of a LiDAR frame every 10 steps, timed" if args.mode == "slam" else "")
                                + ("" if world == 1 else f"; {world} views/step, one gradient exchange per step ({trainer.exchange_mode()}: "
                                   + {"rank1": "xyz / opacity / scaling / rotation all-reduced, the 3-float colour gradients all-gathered and the SH rows rebuilt locally",
                                      "dense": "the [P x 59] slab all-reduced", "sparse": "the visible rows of the slab all-reduced"}[trainer.exchange_mode()] + ")"),
                    "mode": args.mode, "host": args.host if args.mode != "render" else "dropin", "parallelism": f"dp{world}" if world > 1 else "single",
-                   "math": "strict" if strict_mode else "fast",
+                   "math": "strict" if strict_mode else "fast", "map_order": args.map_order,
                    "visible": stats["V"], "instances_R": stats["R"], "buckets_B": stats["B"], "instances_live": stats.get("R_live"),
                    "buckets_live": stats.get("B_live")},
         "roofline": roofline,
@@ -510,120 +589,236 @@ def main():
                             (kernel_table(timed_all, stats, False, rank1=trainer.exchange_mode() == "rank1") if timed_all else None)),
     }
 
-    # ---- the contract line is complete at this point.  The secondary legs below are optional: a watchdog prints the line as it stands and ends the
-    # process if they overrun their budget (a leg that stalls must not cost the run its headline), and every finished leg is added as it completes
-    import threading
-
-    def _give_up():
-        out["secondary_legs"] = f"stopped after {budget_s:.0f} s inside leg '{_LEG[0]}': the legs finished until then are reported, the others are null"
-        print(json.dumps(out), flush=True)
-        _trace("secondary legs overran their budget: line printed, leaving")
-        os._exit(0)
-    budget_s = float(os.environ.get("GSLIC_BENCH_LEGS_BUDGET_S", "300"))
-    watchdog = threading.Timer(budget_s, _give_up)
-    watchdog.daemon = True
-    if rank == 0 and not args.no_extras:
-        watchdog.start()
+    # ---- the contract measurements are complete at this point; this process adds the same step over a >= 1 s window (`value_long`) and, at N > 1,
+    # per-rank times and the collectives alone.  Every other leg runs in a process of its own AFTER this one has released the GPU.
     _trace("value_long")
     value_long = None
-    if graphed["gs"] is None and args.mode != "slam":
+    if args.mode != "slam":
         n_long = int(min(4000, max(args.steps, np.ceil(1.2 * args.steps / max(elapsed, 1e-6)))))
         sec = timed_loop(step, n_long)
         value_long = {"value": round(n_long * world / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_long, 3), "steps": n_long,
                       "seconds": round(sec, 3)}
-
     out["value_long"] = value_long
-    other, graphed_res, growth, cpp_host, math_legs, cycle, pose_leg = None, None, None, None, None, None, None
-    _trace("secondary legs: views_cycle")
-    if args.mode == "train" and args.host == "fused" and args.views > 1 and world == 1 and not trainer._dist_on() and not args.graph and (not args.no_extras or "--views" in sys.argv):
+    if torch.distributed.is_initialized():   # N > 1, and the one-rank group that stands in for it (GSLIC_FORCE_DIST=1)
+        _trace("per-rank times, collectives alone")
+        per = torch.zeros(world, dtype=torch.float64, device=dev)
+        per[rank] = 1e3 * (t1 - t0) / args.steps
+        torch.distributed.all_reduce(per)
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)   # a real collective: every rank contributes 1
+        out["per_rank_ms_per_step"] = [round(float(v), 3) for v in per.tolist()]
+        out["rccl_ranks"] = int(ones.item()) if backend == "nccl" else None
+        out["launch"] = {"backend": ("nccl (RCCL), one rank per GPU" if backend == "nccl" else
+                                     "gloo on device tensors: more ranks than GPUs on this box, RCCL refuses duplicate devices — plumbing check, not a scaling number"),
+                         "ranks": world, "devices": ndev, "ranks_reached_by_all_reduce": int(ones.item()),
+                         "self_launched": os.environ.get("GSLIC_BENCH_SELF_LAUNCHED") == "1",
+                         "prime_steps": prime_steps, "prime_note": "untimed optimiser steps before the W warm-up steps: the ~79th step of a process group stalls "
+                                                                   "once for 36-39 ms (profiles/r04_dist_warmup_stall.txt); `value` is the steady state behind it"}
         try:
-            cycle = views_cycle(args, model, bg, dev, args.views, min(args.steps, 200))
-        except Exception as ex:   # a secondary leg must never take the line down
-            cycle = {"error": str(ex)[:300]}
-    n_extra = min(args.steps, 200)
-    if args.mode == "train" and not args.no_extras and not args.graph and world == 1 and not trainer._dist_on():
-        # the two arithmetic modes of the blend kernels, same workload: throughput, and what the fast mode moves element for element
-        # (the strict mode is held bit-identical to the reference's kernels by tests/test_fullsize_reference_gpu.py, so these ARE the
-        # fast mode's differences from the reference: counts of elements more than 1e-4 of the tensor's max-abs away)
-        out["views_cycle"] = cycle
-        _trace("math_modes")
-        math_legs = {}
-        for name, flag in (("strict", True), ("fast", False)):
-            _lib.set_math_mode(flag)
-            sec = timed_loop(step, n_extra)
-            math_legs[name] = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra}
-        math_legs["default"] = "strict" if strict_mode else "fast"
-        try:
-            math_legs["fast_vs_strict_full_size"] = mode_differences(model, cam, dL, bg)
-        except Exception as ex:   # a diagnostic leg must never take the line down
-            math_legs["fast_vs_strict_full_size"] = {"error": str(ex)[:200]}
-        _lib.set_math_mode(strict_mode)
-    if args.mode == "train" and not args.no_extras and not args.graph:
-        out["math_modes"] = math_legs
-        _trace("other_host_path")
-        host["mode"] = "dropin" if args.host == "fused" else "fused"
-        sec = timed_loop(step, n_extra)
-        other = {"host": host["mode"], "value": round(n_extra * world / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3),
-                 "steps": n_extra}
-        if host["mode"] == "dropin":
-            # the number above is the reference's host lines on the DROP-IN renderer (render() feeds the raw parameters to one autograd node: what
-            # swapping renderer.cpp for shim/renderer.cpp gives an otherwise unmodified host); beside it the same lines on renderer.cpp as written
-            # (getOpacity / getScaling / getRotation as LibTorch ops) and with the optional one-node loss
-            other["what"] = "reference operator API + LibTorch autograd, drop-in renderer (activations inside the kernels)"
-            os.environ["GSLIC_RENDER_RAW"] = "0"
-            sec2 = timed_loop(step, n_extra)
-            os.environ.pop("GSLIC_RENDER_RAW", None)
-            other["renderer_as_written"] = {"value": round(n_extra * world / sec2, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec2 / n_extra, 3)}
-            if world == 1 and not trainer._dist_on():
-                sec3 = timed_loop(lambda: trainer.training_step(model, cam, gt, bg, one_node_loss=True), n_extra)
-                other["one_node_loss"] = {"value": round(n_extra / sec3, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec3 / n_extra, 3)}
-        host["mode"] = args.host
-        if world == 1 and not trainer._dist_on() and args.host == "fused" and not args.split_adam:
-            # the same step as ONE hipGraph replay: capacity-mode forward (no host round trip), loss, backward + Adam
-            out["other_host_path"] = other
-            _trace("graphed")
-            gs = trainer.GraphedStep(model, cam, gt, bg, check_every=0)
-            sec = timed_loop(gs.step, n_extra)
-            repeated = gs.check()
-            graphed_res = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra,
-                           "host_round_trips_per_step": 0, "steps_repeated_for_capacity": repeated, "capacity_R": gs.bufs.cap_R, "capacity_B": gs.bufs.cap_B}
-            del gs
-        if world == 1 and not trainer._dist_on() and args.host == "fused":
-            # joint map + camera-pose iteration (the "cam" of the north-star): parameter gradients and the camera gradient from ONE backward
-            # (gslic_rasterize_backward_camera), Adam as its own launch, the se(3) chain and the pose update on the host (35 floats per step)
-            out["graphed"] = graphed_res
-            _trace("joint_pose_step")
-            try:
-                pcam = synthetic_camera(W, H, 3).to_device(dev)
-                sec = timed_loop(lambda: trainer.training_step_with_pose(model, pcam, gt, bg, pose_lr=1e-6), n_extra)
-                pose_leg = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra,
-                            "what": "forward + loss + backward with camera gradient + split Adam + se(3) pose step per view (one host synchronisation per step)"}
-            except Exception as ex:
-                pose_leg = {"error": str(ex)[:200]}
-            out["joint_pose_step"] = pose_leg
-            _trace("cpp hosts")
-            cpp_host = cpp_fused_host(args, model, cam, gt, n_extra)
-            out["cpp_fused_host"] = cpp_host
-            _trace("growth_schedule")
-            torch.cuda.empty_cache()
-            growth = growth_schedule(args, dev)
+            out["rccl_microbench"] = collectives_alone(model.P, world, rank, dev, backend)
+        except Exception as ex:
+            out["rccl_microbench"] = {"error": str(ex)[:300]}
 
     if rank != 0:
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
-
-    watchdog.cancel()
     try:
         import faulthandler
         faulthandler.cancel_dump_traceback_later()
     except Exception:
         pass
-    out.update({"value_long": value_long, "views_cycle": cycle, "math_modes": math_legs, "other_host_path": other, "graphed": graphed_res,
-                "cpp_fused_host": cpp_host, "joint_pose_step": pose_leg, "growth_schedule": growth})
+    if world == 1 and not args.no_extras and not trainer._dist_on() and args.mode == "train" and args.host == "fused" and not args.graph and not args.split_adam:
+        # release the device, then the legs, each in its own process with a budget
+        try:
+            del model, gt, dL, image, visible, radii, vis
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        _trace("growth_schedule (second process)")
+        growth = run_leg_process("growth_schedule", float(os.environ.get("GSLIC_BENCH_GROWTH_BUDGET_S", "150")), args)
+        out["growth_schedule"] = growth
+        # SURVEY 8d's literal config-3 instance (1.5M -> 2.0M by five appends, the reference's learning rates) beside the stationary line
+        out["config"]["growth_schedule"] = {k: growth.get(k) for k in ("workload", "value", "unit", "ms_per_iteration", "gaussians_start", "gaussians_end",
+                                                                        "extend_ms_per_call", "error") if k in growth}
+        if args.extras:
+            _trace("extras (second process)")
+            legs = run_leg_process("extras", float(os.environ.get("GSLIC_BENCH_LEGS_BUDGET_S", "300")), args)
+            if "error" in legs:
+                out["secondary_legs"] = legs["error"]
+            out.update({k: v for k, v in legs.items() if k in ("views_cycle", "math_modes", "other_host_path", "graphed", "cpp_fused_host", "joint_pose_step", "insertion_order",
+                                                                "reference_step_in_this_process")})
     print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def collectives_alone(P, world, rank, dev, backend):
+    """The step's collectives by themselves at the step's sizes: the all-gather of the per-rank payload {dRGB [P,3] floats,
+    camera centre, visibility bytes}, the SUM all-reduces of the two small-gradient runs (xyz: 3 P floats; opacity + scaling + rotation: 8 P floats), and
+    the dense alternative (one all-reduce of the [P x 59] slab).  20 launches each after 3 warm-ups, device-synchronised wall time, MAX over ranks."""
+    dist = torch.distributed
+    pay = torch.zeros(13 * P + 12, dtype=torch.uint8, device=dev)
+    pay_all = torch.zeros(world, 13 * P + 12, dtype=torch.uint8, device=dev)
+    small_a, small_b = torch.zeros(3 * P, device=dev), torch.zeros(8 * P, device=dev)
+    slab = torch.zeros(59 * P, device=dev)
+
+    def clock(fn, n=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(); dist.barrier()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        dt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=dev)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return 1e3 * float(dt.item()) / n
+
+    def three():
+        w = [dist.all_gather_into_tensor(pay_all, pay.view(1, -1), async_op=True), dist.all_reduce(small_a, async_op=True), dist.all_reduce(small_b, async_op=True)]
+        for x in w:
+            x.wait()
+
+    res = {"backend": backend, "world": world, "gaussians": P}
+    ms = clock(lambda: dist.all_gather_into_tensor(pay_all, pay.view(1, -1)))
+    res["all_gather_payload"] = {"bytes_per_rank": int(pay.numel()), "ms": round(ms, 3), "bus_GBps": round((world - 1) * pay.numel() / (ms * 1e-3) / 1e9, 1)}
+    for name, t in (("all_reduce_xyz", small_a), ("all_reduce_opacity_scaling_rotation", small_b), ("all_reduce_dense_slab", slab)):
+        ms = clock(lambda: dist.all_reduce(t))
+        res[name] = {"bytes": int(4 * t.numel()), "ms": round(ms, 3), "bus_GBps": round(2.0 * (world - 1) / world * 4 * t.numel() / (ms * 1e-3) / 1e9, 1)}
+    ms = clock(three)
+    res["three_collectives_of_the_step_together"] = {"ms": round(ms, 3)}
+    res["note"] = "bus_GBps = bytes a rank must move over its links (ring convention) / time; the step issues the first three asynchronously, together"
+    return res
+
+
+def secondary_legs(args, dev):
+    """`bench.py --leg extras`: the secondary measurements on the headline's workload in a process of their own — a fresh map trained for the same 25
+    steps the driver's command has behind it when its counts are taken — printed as ONE JSON dict that the parent merges into its line."""
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import _lib, trainer
+    from gaussian_lic_amd.camera import synthetic_camera
+    from gaussian_lic_amd.synthetic import gt_image, lidar_scene, pixel_grad, random_scene
+    from gaussian_lic_amd.trainer import DEFAULT_LRS
+    W, H, P = args.width, args.height, args.gaussians
+    if args.math != "default":
+        _lib.set_math_mode(args.math == "strict")
+    strict_mode = bool(_lib.set_math_mode(True)); _lib.set_math_mode(strict_mode)
+    raw = (random_scene if args.scene == "random" else lidar_scene)(P, W, H, sh_degree=3, seed=0)
+    if args.density != 1.0:
+        raw["scaling"] = (raw["scaling"] + float(np.log(args.density))).contiguous()
+    if args.opacity_shift != 0.0:
+        raw["opacity"] = (raw["opacity"] + args.opacity_shift).contiguous()
+    model = trainer.GaussianModel(raw, dev, order=args.map_order)
+    model.training_setup({k: v * args.lr_scale for k, v in DEFAULT_LRS.items()})
+    cam = synthetic_camera(W, H).to_device(dev)
+    gt, dL, bg = gt_image(H, W, seed=2).to(dev), pixel_grad(H, W, seed=1).to(dev), torch.zeros(3, device=dev)
+    host = dict(mode="fused")
+
+    def step():
+        if host["mode"] == "fused":
+            return trainer.training_step_fused(model, cam, gt, bg)[1]
+        return trainer.training_step(model, cam, gt, bg)[1]
+
+    def timed_loop(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        o0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - o0
+
+    for _ in range(25):
+        step()
+    torch.cuda.synchronize()
+    out = {}
+    n_extra = min(args.steps, 200)
+    sec = timed_loop(step, n_extra)
+    out["reference_step_in_this_process"] = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra}
+    if args.map_order == "morton":   # the same step on the map in the order the scene was generated in (rows in random order)
+        _trace("extras: insertion_order")
+        m2 = trainer.GaussianModel(raw, dev, order="insertion")
+        m2.training_setup({k: v * args.lr_scale for k, v in DEFAULT_LRS.items()})
+        for _ in range(25):
+            trainer.training_step_fused(m2, cam, gt, bg)
+        sec = timed_loop(lambda: trainer.training_step_fused(m2, cam, gt, bg), n_extra)
+        out["insertion_order"] = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra,
+                                  "what": "--map-order insertion: the synthetic scene's rows as generated (random order)"}
+        del m2
+        torch.cuda.empty_cache()
+    if args.views > 1:
+        _trace("extras: views_cycle")
+        try:
+            out["views_cycle"] = views_cycle(args, model, bg, dev, args.views, n_extra)
+        except Exception as ex:   # a secondary leg must never take the others down
+            out["views_cycle"] = {"error": str(ex)[:300]}
+    # the two arithmetic modes of the blend kernels, same workload: throughput, and what the fast mode moves element for element
+    # (the strict mode is held bit-identical to the reference's kernels by tests/test_fullsize_reference_gpu.py, so these ARE the
+    # fast mode's differences from the reference: counts of elements more than 1e-4 of the tensor's max-abs away)
+    _trace("extras: math_modes")
+    math_legs = {}
+    for name, flag in (("strict", True), ("fast", False)):
+        _lib.set_math_mode(flag)
+        sec = timed_loop(step, n_extra)
+        math_legs[name] = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra}
+    math_legs["default"] = "strict" if strict_mode else "fast"
+    try:
+        math_legs["fast_vs_strict_full_size"] = mode_differences(model, cam, dL, bg)
+    except Exception as ex:
+        math_legs["fast_vs_strict_full_size"] = {"error": str(ex)[:200]}
+    _lib.set_math_mode(strict_mode)
+    out["math_modes"] = math_legs
+    _trace("extras: other_host_path")
+    host["mode"] = "dropin"
+    sec = timed_loop(step, n_extra)
+    # the reference's host lines on the DROP-IN renderer (render() feeds the raw parameters to one autograd node: what swapping renderer.cpp for
+    # shim/renderer.cpp gives an otherwise unmodified host); beside it the same lines on renderer.cpp as written (getOpacity / getScaling /
+    # getRotation as LibTorch ops) and with the optional one-node loss
+    other = {"host": "dropin", "value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra,
+             "what": "reference operator API + LibTorch autograd, drop-in renderer (activations inside the kernels)"}
+    prev_raw = os.environ.get("GSLIC_RENDER_RAW")
+    os.environ["GSLIC_RENDER_RAW"] = "0"
+    try:
+        sec2 = timed_loop(step, n_extra)
+    finally:   # restore what the user exported (ADVICE round 4), do not clobber it
+        if prev_raw is None:
+            os.environ.pop("GSLIC_RENDER_RAW", None)
+        else:
+            os.environ["GSLIC_RENDER_RAW"] = prev_raw
+    other["renderer_as_written"] = {"value": round(n_extra / sec2, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec2 / n_extra, 3)}
+    sec3 = timed_loop(lambda: trainer.training_step(model, cam, gt, bg, one_node_loss=True), n_extra)
+    other["one_node_loss"] = {"value": round(n_extra / sec3, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec3 / n_extra, 3)}
+    host["mode"] = "fused"
+    out["other_host_path"] = other
+    # the same step as ONE hipGraph replay: capacity-mode forward (no host round trip), loss, backward + Adam
+    _trace("extras: graphed")
+    try:
+        gs = trainer.GraphedStep(model, cam, gt, bg, check_every=0)
+        sec = timed_loop(gs.step, n_extra)
+        repeated = gs.check()
+        out["graphed"] = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra,
+                          "host_round_trips_per_step": 0, "steps_repeated_for_capacity": repeated, "capacity_R": gs.bufs.cap_R, "capacity_B": gs.bufs.cap_B}
+        del gs
+    except Exception as ex:
+        out["graphed"] = {"error": str(ex)[:200]}
+    # joint map + camera-pose iteration (the "cam" of the north-star): parameter gradients and the camera gradient from ONE backward
+    # (gslic_rasterize_backward_camera), Adam as its own launch, the se(3) chain and the pose update on the host (35 floats per step)
+    _trace("extras: joint_pose_step")
+    try:
+        pcam = synthetic_camera(W, H, 3).to_device(dev)
+        sec = timed_loop(lambda: trainer.training_step_with_pose(model, pcam, gt, bg, pose_lr=1e-6), n_extra)
+        out["joint_pose_step"] = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra,
+                                  "what": "forward + loss + backward with camera gradient + split Adam + se(3) pose step per view (one host synchronisation per step)"}
+    except Exception as ex:
+        out["joint_pose_step"] = {"error": str(ex)[:200]}
+    _trace("extras: cpp hosts")
+    try:
+        out["cpp_fused_host"] = cpp_fused_host(args, model, cam, gt, n_extra)
+    except Exception as ex:
+        out["cpp_fused_host"] = {"error": str(ex)[:200]}
+    return out
 
 
 def views_cycle(args, model, bg, dev, K, n):
@@ -770,6 +965,8 @@ def cpp_fused_host(args, model, cam, gt, n):
             w(name, t.detach().cpu().numpy())
         w("view", cam.world_view_transform); w("proj", cam.full_proj_transform); w("campos", cam.camera_center)
         w("gt", gt.cpu().numpy())
+        if getattr(model, "tie_rank", None) is not None:   # rows in Morton order: the C++ host gets their original indices (FusedStep::set_tie_rank)
+            w("tie_rank", model.tie_rank.cpu().numpy())
         w("scalars", np.array([cam.tanfovx, cam.tanfovy, cam.limx_neg, cam.limx_pos, cam.limy_neg, cam.limy_pos], np.float32))
         r = subprocess.run([exe, d, str(model.P), str(args.width), str(args.height), "3", "1", str(n), str(args.lr_scale)], capture_output=True,
                            text=True, timeout=180)
@@ -819,7 +1016,7 @@ def growth_schedule(args, dev):
     keep = torch.nonzero(u_pix < 0.7 * W).squeeze(1)[:P_start]
     assert keep.numel() == P_start, "not enough Gaussians left of the uncovered strip"
     raw = {k: (v[keep].contiguous() if torch.is_tensor(v) else v) for k, v in big.items()}
-    model = trainer.GaussianModel(raw, dev, capacity=int(1.05 * P))
+    model = trainer.GaussianModel(raw, dev, capacity=int(1.05 * P), order=args.map_order)
     model.training_setup()
     cam = synthetic_camera(W, H).to_device(dev)
     gt = gt_image(H, W, seed=2).to(dev)

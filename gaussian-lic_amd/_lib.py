@@ -20,7 +20,7 @@ class RasterParams(ctypes.Structure):
                 ("height", ctypes.c_int32), ("tan_fovx", ctypes.c_float), ("tan_fovy", ctypes.c_float),
                 ("limx_neg", ctypes.c_float), ("limx_pos", ctypes.c_float), ("limy_neg", ctypes.c_float),
                 ("limy_pos", ctypes.c_float), ("scale_modifier", ctypes.c_float), ("prefiltered", ctypes.c_int32),
-                ("debug", ctypes.c_int32), ("no_color", ctypes.c_int32), ("raw_params", ctypes.c_int32)]
+                ("debug", ctypes.c_int32), ("no_color", ctypes.c_int32), ("raw_params", ctypes.c_int32), ("tie_rank", ctypes.c_void_p)]
 
 
 class AdamGroup(ctypes.Structure):
@@ -107,7 +107,7 @@ def lib():
     L.gslic_l1_ssim_loss_forward.argtypes = [i32, i32, i32, i32, f32, f32] + [vp] * 7 + [vp]
     L.gslic_l1_ssim_loss_backward.argtypes = [i32, i32, i32, i32, f32] + [vp] * 6 + [vp]
     L.gslic_set_math_mode.argtypes = [i32]
-    if L.gslic_abi_version() != 6:
+    if L.gslic_abi_version() != 7:
         raise GslicError("libgslic_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -39,7 +39,7 @@ static bool g_prof_cur_on = false;
 static const char* const k_names[K_COUNT] = {
     "preprocess", "scan_reduce", "scan_spine", "scan_apply", "keybuild", "sort_hist", "sort_scatter", "finalize_lists",
     "bucket_count", "render_fwd", "render_bwd", "preprocess_bwd", "adam", "ssim_fwd", "ssim_bwd", "knn_minmax", "knn_morton",
-    "knn_boxes", "knn_search", "debug_export", "extend", "dsort_hist", "dsort_scatter", "sh_grad_from_rgb"};
+    "knn_boxes", "knn_search", "debug_export", "extend", "dsort_hist", "dsort_scatter", "sh_grad_from_rgb", "tie_fix"};
 uint32_t g_lds_pad[K_COUNT] = {0};
 static const bool g_lds_pad_parsed = [] {   // GSLIC_LDS_PAD="name=bytes,name=bytes"
     const char* e = getenv("GSLIC_LDS_PAD");
@@ -419,6 +419,8 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
         GS_TRY(radix_sort_u32(sb, geom.plan, geom.sort_scratch, (onesweep_mask() & 1) != 0, K_DSORT_HIST, K_DSORT_SCATTER, s));
     }
     uint32_t* const order = geom.order[geom.plan.passes & 1];
+    if (prm->tie_rank)   // rows stored in a permuted order: equal depths listed by the rows' ORIGINAL indices, as the reference's stable sort lists them
+        GS_TRY(launch_tie_fix((size_t)P, geom.depth_keys[geom.plan.passes & 1], order, prm->tie_rank, 0xffffffffu, s));
     GS_TRY(scan_u32_chained(geom.tiles_touched, order, geom.point_offsets, (size_t)P, false, geom.scan_state, s));
     uint32_t hostbuf[2] = {0, 0};
     const int end_bit = sort_end_bit(T);

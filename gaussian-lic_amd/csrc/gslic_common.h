@@ -63,6 +63,7 @@ enum KernelId {
     K_DSORT_HIST,
     K_DSORT_SCATTER,
     K_SH_REBUILD,
+    K_TIE_FIX,
     K_COUNT
 };
 void prof_begin(int id, hipStream_t s);
@@ -148,6 +149,9 @@ size_t sort_scratch_bytes(const SortPlan& plan);
 // n_dev != NULL: the real element count (<= plan.n, which is then the capacity the launches are sized for) is read on the device.
 int radix_sort_u32(const SortBuffers& b, const SortPlan& plan, void* scratch, bool onesweep, int id_hist, int id_scatter, hipStream_t s,
                    const uint32_t* n_dev = nullptr);
+// After a stable sort of (key, id) pairs: every run of EQUAL keys (other than `skip_key`) is put into ascending rank[id] order instead of
+// ascending id order (gslic_raster_params.tie_rank: a map whose rows are stored permuted lists equal depths in its ORIGINAL order).
+int launch_tie_fix(size_t n, const uint32_t* sorted_keys, uint32_t* ids, const uint32_t* rank, uint32_t skip_key, hipStream_t s);
 
 // opaque scratch layouts ----------------------------------------------------------------------------------
 struct GeomState {

@@ -146,6 +146,8 @@ template <int BS>
 __device__ __forceinline__ void sh_columns_pass(const PreprocessBwdArgs& a, const float* __restrict__ tab, float* __restrict__ sk,
                                                 const uint8_t* __restrict__ lds_vis, const int row0)
 {
+#pragma clang fp contract(off)   // q_k = (p0 + p1) + p2 of separately rounded products, here AND in the row-by-row path of a partial last block: a
+                                 // Gaussian's direction gradient must not depend on which block of the map its row happens to sit in
     constexpr int NE = BS * 45, NV = NE / 4, U = 4;
     const AdamFusedArgs& A = a.adam;
     const size_t base = (size_t)row0 * 45;
@@ -279,6 +281,7 @@ __global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
         } else {
             const size_t base = (size_t)row0 * 45;
             if ((int)threadIdx.x < rows) {
+#pragma clang fp contract(off)   // (as sh_columns_pass rounds them)
                 const float* __restrict__ sh = a.shs + base + 45 * threadIdx.x;
                 const float* __restrict__ tr = lds_tab + threadIdx.x * SHT;
 #pragma unroll
@@ -825,8 +828,12 @@ __global__ __launch_bounds__(64) void sh_grad_from_rgb_kernel(ShGradFromRgbArgs 
         __builtin_amdgcn_wave_barrier();
         const AdamFusedArgs& A = a.adam;
         auto update = [&](int grp, int width, const float* rows_lds, size_t base) {
-            // region of this block: rows * width floats at param + base, 16-byte aligned (row0 is a multiple of 32)
-            if (rows == SGR) {
+            // region of this block: rows * width floats at param + base.  The float4 path needs 16-byte alignment of the gradient rows, the
+            // parameter and both moments: row0 is a multiple of 32, so that holds whenever the BASE pointers are 16-byte aligned — which a gradient
+            // slab with P % 4 != 0 does not give the opacity / rotation runs: checked here (wave-uniform), scalar path otherwise
+            const bool aligned16 = ((reinterpret_cast<uintptr_t>(rows_lds) | reinterpret_cast<uintptr_t>(A.p[grp] + base) |
+                                     reinterpret_cast<uintptr_t>(A.m[grp] + base) | reinterpret_cast<uintptr_t>(A.v[grp] + base)) & 15) == 0;
+            if (rows == SGR && aligned16) {
                 const int nv = SGR * width / 4;
                 const float4* s4 = reinterpret_cast<const float4*>(rows_lds);
                 constexpr int U = 4;

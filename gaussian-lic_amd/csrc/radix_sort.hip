@@ -345,6 +345,34 @@ static int sort_impl(const SortBuffers& b, const SortPlan& plan, const uint32_t*
     return GSLIC_OK;
 }
 
+// Runs of equal keys in a sorted (key, id) sequence re-ordered by rank[id] (launch_tie_fix).  One thread per element; the thread at the head
+// of a run (its left neighbour differs, its right neighbour is equal) owns the run: runs are disjoint, so the in-place insertion sort needs no
+// synchronisation.  Equal depth bits are rare (a few 1e4 pairs among 1e6 visible Gaussians) and runs short (2, seldom 3): the kernel is one
+// coalesced read of the keys.
+__global__ __launch_bounds__(256) void tie_fix_kernel(size_t n, const uint32_t* __restrict__ keys, uint32_t* ids, const uint32_t* __restrict__ rank,
+                                                      uint32_t skip_key)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i + 1 >= n) return;
+    const uint32_t k = keys[i];
+    if (k == skip_key || keys[i + 1] != k || (i > 0 && keys[i - 1] == k)) return;
+    size_t j = i + 1;
+    while (j + 1 < n && keys[j + 1] == k) j++;          // run = [i, j]
+    for (size_t a = i + 1; a <= j; a++) {                // insertion sort by rank
+        const uint32_t id = ids[a], r = rank[id];
+        size_t b = a;
+        while (b > i && rank[ids[b - 1]] > r) { ids[b] = ids[b - 1]; b--; }
+        ids[b] = id;
+    }
+}
+
+int launch_tie_fix(size_t n, const uint32_t* sorted_keys, uint32_t* ids, const uint32_t* rank, uint32_t skip_key, hipStream_t s)
+{
+    if (n < 2) return GSLIC_OK;
+    GS_LAUNCH(K_TIE_FIX, tie_fix_kernel, dim3((unsigned)div_up_sz(n, 256)), dim3(256), 0, s, n, sorted_keys, ids, rank, skip_key);
+    return GSLIC_OK;
+}
+
 int radix_sort_u32(const SortBuffers& b, const SortPlan& plan, void* scratch, bool onesweep, int id_hist, int id_scatter, hipStream_t s,
                    const uint32_t* n_dev)
 {

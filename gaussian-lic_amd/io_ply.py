@@ -16,7 +16,8 @@ def _props(M):
 def save_map(model, path, skybox_points_num=0):
     """model: anything with xyz, features_dc [P,1,3], features_rest [P,M,3], opacity [P,1], scaling [P,3], rotation [P,4]."""
     s = int(skybox_points_num)
-    g = lambda t: t.detach()[s:].float().cpu()
+    order = model.original_order() if callable(getattr(model, "original_order", None)) else None   # a model that stores its rows permuted
+    g = lambda t: (t.detach() if order is None else t.detach()[order])[s:].float().cpu()
     xyz, dc, rest = g(model.xyz), g(model.features_dc), g(model.features_rest)
     M = rest.shape[1]
     cols = [xyz, dc.transpose(1, 2).flatten(1), rest.transpose(1, 2).flatten(1), g(model.opacity), g(model.scaling), g(model.rotation)]

@@ -36,12 +36,17 @@ class GaussianRasterizationSettings:
     debug: bool = False
     no_color: bool = False
     lambda_erank: float = 0.0
+    tie_rank: torch.Tensor = None   # not in the reference: int32 [P], set by render() for a model that keeps its rows in a permuted order (_params)
 
 
-def _params(P, D, M, H, W, tanfovx, tanfovy, lxn, lxp, lyn, lyp, scale_modifier, prefiltered, debug, no_color, raw=False):
+def _params(P, D, M, H, W, tanfovx, tanfovy, lxn, lxp, lyn, lyp, scale_modifier, prefiltered, debug, no_color, raw=False, tie_rank=None):
+    """tie_rank (forward only): device int32 [P], the rows' indices in the map's ORIGINAL order when the host stores them permuted
+    (gslic_raster_params.tie_rank); the caller keeps the tensor alive for the duration of the call."""
+    if tie_rank is not None:
+        assert tie_rank.is_contiguous() and tie_rank.dtype == torch.int32 and tie_rank.numel() >= int(P)
     return _lib.RasterParams(int(P), int(D), int(M), int(W), int(H), float(tanfovx), float(tanfovy), float(lxn), float(lxp),
                              float(lyn), float(lyp), float(scale_modifier), int(bool(prefiltered)), int(bool(debug)),
-                             int(bool(no_color)), int(bool(raw)))
+                             int(bool(no_color)), int(bool(raw)), None if tie_rank is None else ctypes.c_void_p(tie_rank.data_ptr()))
 
 
 def _f32c(t):
@@ -50,10 +55,11 @@ def _f32c(t):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                         projmatrix, tan_fovx, tan_fovy, image_height, image_width, limx_neg, limx_pos, limy_neg, limy_pos,
-                        dc, sh, degree, campos, prefiltered, debug, no_color=False, raw_params=False):
+                        dc, sh, degree, campos, prefiltered, debug, no_color=False, raw_params=False, tie_rank=None):
     """RasterizeGaussiansCUDA (rasterize_points.cu:50-149): returns
     (num_rendered, num_buckets, out_color, out_final_T, radii, geomBuffer, binningBuffer, imgBuffer, sampleBuffer).
-    raw_params=True (not in the reference): opacity / scales / rotations are the RAW parameters, activated inside the kernels."""
+    raw_params=True (not in the reference): opacity / scales / rotations are the RAW parameters, activated inside the kernels.
+    tie_rank (not in the reference): see _params — a map stored in a permuted row order renders as the unpermuted one."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise ValueError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:77-80
     L = _lib.lib()
@@ -71,7 +77,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         sh_c = _f32c(sh) if M > 0 else None
         viewmatrix, projmatrix, campos, background = map(_f32c, (viewmatrix, projmatrix, campos, background))
         prm = _params(P, degree, M, H, W, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier,
-                      prefiltered, debug, no_color, raw_params)
+                      prefiltered, debug, no_color, raw_params, tie_rank)
         p = _lib.ptr
         _lib.check(L.gslic_rasterize_forward(
             ctypes.byref(prm), allocs[0].cb, None, allocs[1].cb, None, allocs[2].cb, None, allocs[3].cb, None,
@@ -112,7 +118,7 @@ class CapacityBuffers:
 
 
 def rasterize_gaussians_capacity(bufs, background, means3D, opacity, scales, rotations, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
-                                 limx_neg, limx_pos, limy_neg, limy_pos, dc, sh, degree, campos, raw_params=False):
+                                 limx_neg, limx_pos, limy_neg, limy_pos, dc, sh, degree, campos, raw_params=False, tie_rank=None):
     """gslic_rasterize_forward_capacity: RasterizeGaussiansCUDA without a host round trip, into caller-owned buffers.  The tensors must
     already be contiguous fp32 (no copies are made: addresses have to be stable for graph capture).  Returns the same 9-tuple as
     rasterize_gaussians with (cap_R, cap_B) in place of (R, B) — pass them on to rasterize_gaussians_backward unchanged."""
@@ -123,7 +129,7 @@ def rasterize_gaussians_capacity(bufs, background, means3D, opacity, scales, rot
     for t in (means3D, dc, opacity, scales, rotations, viewmatrix, projmatrix, campos):
         assert t.is_contiguous() and t.dtype == torch.float32
     prm = _params(P, degree, M, bufs.H, bufs.W, tan_fovx, tan_fovy, limx_neg, limx_pos, limy_neg, limy_pos, scale_modifier, False, False,
-                  bufs.no_color, raw_params)
+                  bufs.no_color, raw_params, tie_rank)
     p = _lib.ptr
     cR, cB = ctypes.c_int32(0), ctypes.c_int32(0)
     bp = lambda t: ctypes.c_void_p(t.data_ptr()) if t.numel() else None
@@ -239,7 +245,7 @@ class GaussianRasterizerFunction(torch.autograd.Function):
         (R, B, color, final_T, radii, geom, binning, img, sample) = rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, rs.limx_neg, rs.limx_pos, rs.limy_neg,
-            rs.limy_pos, dc, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, rs.no_color)
+            rs.limy_pos, dc, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, rs.no_color, tie_rank=rs.tie_rank)
         ctx.rs, ctx.R, ctx.B = rs, R, B
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, dc, sh, geom, binning, img, sample)
         ctx.mark_non_differentiable(radii, final_T)
@@ -285,7 +291,7 @@ class RawGaussianRasterizerFunction(torch.autograd.Function):
         (R, B, color, final_T, radii, geom, binning, img, sample) = rasterize_gaussians(
             rs.bg, xyz, e, opacity_raw, scaling_raw, rotation_raw, rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
             rs.image_height, rs.image_width, rs.limx_neg, rs.limx_pos, rs.limy_neg, rs.limy_pos, dc, sh, rs.sh_degree, rs.campos, rs.prefiltered,
-            rs.debug, rs.no_color, raw_params=True)
+            rs.debug, rs.no_color, raw_params=True, tie_rank=rs.tie_rank)
         ctx.rs, ctx.R, ctx.B = rs, R, B
         ctx.save_for_backward(xyz, dc, sh, opacity_raw, scaling_raw, rotation_raw, radii, geom, binning, img, sample)
         ctx.mark_non_differentiable(radii, final_T)
@@ -307,8 +313,12 @@ class RawGaussianRasterizerFunction(torch.autograd.Function):
 def _raw_leaves(model):
     """The six raw parameter tensors of a GaussianModel (xyz_, features_dc_, features_rest_, opacity_, scaling_, rotation_: gaussian.h:153-158),
     or None when the model only offers the activated accessors."""
+    # An explicit marker, not duck typing (ADVICE round 4): a model whose attributes of these names hold ACTIVATED values would otherwise be
+    # activated a second time.  trainer.GaussianModel sets raw_parameter_leaves = True; any other model opts in by providing raw_leaves().
+    if callable(getattr(model, "raw_leaves", None)):
+        return tuple(model.raw_leaves())
     names = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")
-    if all(torch.is_tensor(getattr(model, n, None)) for n in names):
+    if getattr(model, "raw_parameter_leaves", False) and all(torch.is_tensor(getattr(model, n, None)) for n in names):
         return tuple(getattr(model, n) for n in names)
     return None
 
@@ -331,8 +341,11 @@ def render(camera, model, bg_color, no_color=False, scaling_modifier=1.0, raw=No
         camera.image_height, camera.image_width, float(camera.tanfovx), float(camera.tanfovy), float(camera.limx_neg),
         float(camera.limx_pos), float(camera.limy_neg), float(camera.limy_pos), bg_color, scaling_modifier,
         camera.d_world_view_transform, camera.d_full_proj_transform, model.sh_degree, camera.d_camera_center, False, False,
-        no_color, model.lambda_erank)
+        no_color, model.lambda_erank, getattr(model, "tie_rank", None))
     if raw:
+        if leaves is None:
+            raise TypeError("render(raw=True): the model does not expose its raw parameter leaves (set raw_parameter_leaves = True on a model whose "
+                            "xyz / features_dc / features_rest / opacity / scaling / rotation attributes are the PRE-activation tensors, or provide raw_leaves())")
         xyz, dc, rest, opacity, scaling, rotation = leaves
         image, radii, final_T = RawGaussianRasterizerFunction.apply(xyz, dc, rest, opacity, scaling, rotation, rs)
         screenspace_points = torch.zeros(1, 3, dtype=xyz.dtype, device=xyz.device).expand(xyz.shape[0], 3)

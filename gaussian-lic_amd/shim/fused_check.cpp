@@ -54,6 +54,10 @@ int main(int argc, char** argv)
 
     // trainingSetup (gaussian.cpp:399-418) with config/fastlivo.yaml learning rates
     gslic::FusedStep fs({xyz, dc, rest, opacity, scaling, rotation}, {1.6e-4f * ls, 2.5e-3f * ls, (float)(2.5e-3 / 20.0) * ls, 5e-2f * ls, 5e-3f * ls, 1e-3f * ls}, deg);
+    {   // optional <dir>/tie_rank.f32: the rows' original indices of a map handed over in a permuted (Morton) order
+        std::ifstream probe(d + "/tie_rank.f32", std::ios::binary);
+        if (probe.good()) fs.set_tie_rank(load(d + "/tie_rank.f32", {P}).to(torch::kInt32));
+    }
     if (std::getenv("GSLIC_CHECK_POSE")) {   // the camera-pose gradient of the initial map (before any step), six numbers
         const auto g = fs.pose_gradient(cam, gt);
         std::cout.precision(9);

@@ -65,6 +65,11 @@ public:
         prm_ = std::move(params); m_ = std::move(exp_avg); v_ = std::move(exp_avg_sq);
     }
     void set_lr(int group, float lr) { lrs_[group] = lr; }
+    // A host that keeps the map's rows in a PERMUTED order (e.g. sorted along a space-filling curve so that what a view sees is contiguous in
+    // memory) passes the rows' ORIGINAL indices (device int32 [P]): the forward then lists Gaussians of equal depth in the original order, as the
+    // reference's stable sort does (gslic_raster_params.tie_rank), and the map renders / trains bit-identically to the unpermuted one.
+    // Rows appended by extend() get their row index.
+    void set_tie_rank(torch::Tensor original_index) { tie_ = original_index.to(torch::kInt32).contiguous(); }
 
     // extend() of gaussian.cpp:499-638 for one new LiDAR frame: transmittance-only render of `cam` (no_color, :501-507), device-side
     // selection of the points that land on not-yet-opaque pixels (nearest per pixel, gslic_extend_select), append of the new Gaussians'
@@ -81,6 +86,7 @@ public:
         auto fo = prm_[0].options().requires_grad(false);
         // render(no_color) through the operator entry point with LibTorch activations, exactly as renderer.cpp:57-63 feeds it
         gslic_raster_params rp{};
+        rp.tie_rank = tie_.defined() ? reinterpret_cast<const uint32_t*>(tie_.data_ptr<int32_t>()) : nullptr;
         rp.P = (int32_t)P; rp.D = deg_; rp.M = prm_[2].numel() ? (int32_t)prm_[2].size(1) : 0; rp.width = W; rp.height = H;
         rp.tan_fovx = cam.tanfovx; rp.tan_fovy = cam.tanfovy;
         rp.limx_neg = cam.limx_neg; rp.limx_pos = cam.limx_pos; rp.limy_neg = cam.limy_neg; rp.limy_pos = cam.limy_pos;
@@ -113,6 +119,7 @@ public:
             mbuf_[g].narrow(0, P, count).zero_();
             vbuf_[g].narrow(0, P, count).zero_();
         }
+        if (tie_.defined()) tie_ = torch::cat({tie_, torch::arange(P, P + count, tie_.options())});
         bind(P + count);
         torch::cuda::synchronize();   // (the selection scratch is released on return)
         return count;
@@ -129,6 +136,7 @@ public:
         const int W = cam.image_width, H = cam.image_height;
         TORCH_CHECK(gt_image.is_contiguous() && gt_image.dim() == 3 && gt_image.size(1) == H && gt_image.size(2) == W, "gt_image must be contiguous [3,H,W]");
         gslic_raster_params rp{};
+        rp.tie_rank = tie_.defined() ? reinterpret_cast<const uint32_t*>(tie_.data_ptr<int32_t>()) : nullptr;
         rp.P = (int32_t)P; rp.D = deg_; rp.M = prm_[2].numel() ? (int32_t)prm_[2].size(1) : 0; rp.width = W; rp.height = H;
         rp.tan_fovx = cam.tanfovx; rp.tan_fovy = cam.tanfovy;
         rp.limx_neg = cam.limx_neg; rp.limx_pos = cam.limx_pos; rp.limy_neg = cam.limy_neg; rp.limy_pos = cam.limy_pos;
@@ -184,6 +192,7 @@ public:
         const int64_t P = prm_[0].size(0);
         const int W = cam.image_width, H = cam.image_height;
         gslic_raster_params rp{};
+        rp.tie_rank = tie_.defined() ? reinterpret_cast<const uint32_t*>(tie_.data_ptr<int32_t>()) : nullptr;
         rp.P = (int32_t)P; rp.D = deg_; rp.M = prm_[2].numel() ? (int32_t)prm_[2].size(1) : 0; rp.width = W; rp.height = H;
         rp.tan_fovx = cam.tanfovx; rp.tan_fovy = cam.tanfovy;
         rp.limx_neg = cam.limx_neg; rp.limx_pos = cam.limx_pos; rp.limy_neg = cam.limy_neg; rp.limy_pos = cam.limy_pos;
@@ -286,7 +295,7 @@ private:
     int deg_;
     float lambda_dssim_, lambda_erank_, b1_, b2_, eps_;
     torch::Tensor scratch_[4];   // geom, binning, img, sample — order of the C-ABI's allocator arguments
-    torch::Tensor bg_, image_, final_T_, radii_, dm_[3], dL_dimage_, partials_;
+    torch::Tensor bg_, image_, final_T_, radii_, dm_[3], dL_dimage_, partials_, tie_;
 };
 
 }  // namespace gslic

@@ -19,15 +19,49 @@ DEFAULT_LRS = dict(position_lr=1.6e-4, feature_lr=2.5e-3, opacity_lr=5e-2, scali
 LAMBDA_DSSIM = 0.2
 
 
+def morton_order(xyz, bits=10):
+    """Permutation (LongTensor [P], CPU) that sorts the rows by the Morton code of their position: `bits` per axis over the robust bounding box
+    (0.1 .. 99.9 percentile per axis, outliers clamped), ties in row order (stable).  View-independent: spatial neighbours become memory
+    neighbours, which is what a SLAM map's insertion order gives frame by frame and a synthetic scene in random order does not."""
+    import numpy as np
+    q = xyz.detach().cpu().double().numpy()
+    lo, hi = np.percentile(q, 0.1, axis=0), np.percentile(q, 99.9, axis=0)
+    u = (np.clip((q - lo) / np.maximum(hi - lo, 1e-30), 0.0, 1.0) * ((1 << bits) - 1)).astype(np.uint64)
+
+    def spread(v):   # 10 bits -> every third bit
+        v = (v | (v << np.uint64(16))) & np.uint64(0x030000FF)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x0300F00F)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x030C30C3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x09249249)
+        return v
+    assert bits <= 10
+    code = spread(u[:, 0]) | (spread(u[:, 1]) << np.uint64(1)) | (spread(u[:, 2]) << np.uint64(2))
+    return torch.from_numpy(np.argsort(code, kind="stable").astype(np.int64))
+
+
 class GaussianModel:
     """Parameters + activations of src/gaussian.{h,cpp} that the hot path touches, with capacity-doubling storage so that
     extend() appends rows in place instead of six torch::cat reallocations of every parameter and Adam moment per keyframe
     (densificationPostfix, gaussian.cpp:426-497)."""
 
     NAMES = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")   # group order of gaussian.cpp:399-418
+    raw_parameter_leaves = True   # the attributes of those names are the PRE-activation leaves: rasterizer.render() may feed them to the raw-parameter node
 
-    def __init__(self, raw, device, lambda_erank=0.0, capacity=None, scaling_scale=1.0):
+    def __init__(self, raw, device, lambda_erank=0.0, capacity=None, scaling_scale=1.0, order="insertion"):
+        """order = "insertion": rows in the order given (the reference's: initialize() then extend() appends).
+        order = "morton": the rows are stored sorted by the Morton code of their position (morton_order): what a camera sees is then contiguous
+        in memory, whole waves of the per-Gaussian kernels are invisible and skip, and the 128-byte lines of parameters and Adam moments are
+        no longer shared between visible and invisible rows.  self.tie_rank[s] = original index of storage row s: the forward breaks depth
+        ties by it (gslic_raster_params.tie_rank), so rendering and training are bit-identical to the insertion order; original_order() /
+        io_ply.save_map() give the rows back in the original order.  Rows appended by extend() keep their insertion order behind the sorted block."""
         self.sh_degree = int(raw["sh_degree"])
+        self._tie = None
+        if order == "morton":
+            perm = morton_order(raw["xyz"])
+            raw = {k: (v[perm].contiguous() if (torch.is_tensor(v) and k in self.NAMES) else v) for k, v in raw.items()}
+        else:
+            assert order == "insertion", order
+            perm = None
         self.lambda_erank = float(lambda_erank)
         self.scaling_scale = float(scaling_scale)
         self.device = device
@@ -40,8 +74,20 @@ class GaussianModel:
             self._buf[n][:self.P].copy_(src)
             self._m[n] = torch.zeros_like(self._buf[n])
             self._v[n] = torch.zeros_like(self._buf[n])
+        if perm is not None:
+            self._tie = torch.empty(cap, dtype=torch.int32, device=device)
+            self._tie[:self.P].copy_(perm.to(torch.int32))
         self.optimizer = None
         self._rebind()
+
+    @property
+    def tie_rank(self):
+        """int32 [P] original index of every storage row, or None when the rows are in their original order."""
+        return None if self._tie is None else self._tie[:self.P]
+
+    def original_order(self):
+        """LongTensor [P]: storage rows listed in the ORIGINAL order (x[model.original_order()] un-permutes a per-row tensor x); None = identity."""
+        return None if self._tie is None else torch.argsort(self._tie[:self.P].long())
 
     @property
     def capacity(self):
@@ -64,6 +110,10 @@ class GaussianModel:
                     torch.empty((cap,) + tuple(old.shape[1:]), device=self.device)
                 new[:self.P].copy_(old[:self.P])
                 d[n] = new
+        if self._tie is not None:
+            tie = torch.empty(cap, dtype=torch.int32, device=self.device)
+            tie[:self.P].copy_(self._tie[:self.P])
+            self._tie = tie
 
     # gaussian.cpp:147-175
     def get_xyz(self): return self.xyz
@@ -122,6 +172,8 @@ class GaussianModel:
         for d in (self._m, self._v):       # new rows start with zero moments (gaussian.cpp:458-459)
             for name in self.NAMES:
                 d[name][P0:P0 + k].zero_()
+        if self._tie is not None:          # appended rows are in insertion order behind the sorted block: their original index is their row
+            self._tie[P0:P0 + k].copy_(torch.arange(P0, P0 + k, dtype=torch.int32, device=dev))
         self.P = P0 + k
         self._rebind()
         torch.cuda.current_stream().synchronize()  # scratch (flags/pos) is released on return
@@ -271,7 +323,11 @@ def exchange_rank1(slab, rgb_local, visible, model, campos):
     visibility bytes} (the rebuild kernel reads the gathered blocks in place through a view stride; the masks are OR-ed locally, so no
     separate MAX-reduce blocks the step), and the all-reduces of the two contiguous runs of the gradient slab that hold the 11 small
     floats (xyz | ... | opacity, scaling, rotation).  Returns (OR-ed visibility, works) like allreduce_slab_async: wait on a work, then run
-    Adam on its groups; the rebuild of the SH rows runs behind the all-gather while the all-reduces are still on the links."""
+    Adam on its groups; the rebuild of the SH rows runs behind the all-gather while the all-reduces are still on the links.
+
+    ALIASING (folded path, the default): the returned mask is a bool VIEW of the persistent buffer slab.vis_or.  It is filled by the launch
+    inside the returned work's wait() — not before — and overwritten by the next step: a caller that keeps `visible` across steps
+    (densification statistics, logging) must clone it after wait()."""
     from . import rasterizer as rz
     dist = torch.distributed
     n = dist.get_world_size()
@@ -450,7 +506,7 @@ def pose_gradient(model, camera, gt_image, bg, fused_loss=None):
         (R, B, image, _final_T, radii, geom, binning, img, sample) = rz.rasterize_gaussians(
             bg, xyz, e, op, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
             cam.image_height, cam.image_width, float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dc, rest,
-            model.sh_degree, cam.d_camera_center, False, False, False, raw_params=True)
+            model.sh_degree, cam.d_camera_center, False, False, False, raw_params=True, tie_rank=getattr(model, "tie_rank", None))
         dL_dimage, terms = fl.forward_backward(image, gt_image)
         out = rz.rasterize_gaussians_backward(
             bg, xyz, radii, e, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
@@ -474,7 +530,7 @@ def training_step_with_pose(model, camera, gt_image, bg, pose_lr=0.0, fused_loss
         (R, B, image, _final_T, radii, geom, binning, img, sample) = rz.rasterize_gaussians(
             bg, xyz, e, op, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
             cam.image_height, cam.image_width, float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dc, rest,
-            model.sh_degree, cam.d_camera_center, False, False, False, raw_params=True)
+            model.sh_degree, cam.d_camera_center, False, False, False, raw_params=True, tie_rank=getattr(model, "tie_rank", None))
         dL_dimage, terms = fl.forward_backward(image, gt_image)
         slab = getattr(model, "_grad_slab", None)
         if slab is None or slab.P != model.P:
@@ -510,7 +566,7 @@ def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=Tr
         (R, B, image, _final_T, radii, geom, binning, img, sample) = rz.rasterize_gaussians(
             bg, xyz, e, op, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy),
             cam.image_height, cam.image_width, float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dc, rest,
-            model.sh_degree, cam.d_camera_center, False, False, False, raw_params=True)
+            model.sh_degree, cam.d_camera_center, False, False, False, raw_params=True, tie_rank=getattr(model, "tie_rank", None))
         dL_dimage, terms = fl.forward_backward(image, gt_image)
         if do_step and adam_in_backward and not _dist_on():
             # single GPU: nothing to exchange, so the Adam update runs inside the per-Gaussian backward kernel while the
@@ -624,7 +680,7 @@ class GraphedStep:
                                           1.0, self.e, self.view, self.proj, float(camera.tanfovx), float(camera.tanfovy), self.H, self.W,
                                           float(camera.limx_neg), float(camera.limx_pos), float(camera.limy_neg), float(camera.limy_pos),
                                           model.features_dc.detach(), model.features_rest.detach(), model.sh_degree, self.campos, False, False,
-                                          False, raw_params=True)[:2]
+                                          False, raw_params=True, tie_rank=getattr(model, "tie_rank", None))[:2]
         self.cap_R, self.cap_B = int(R * self.headroom) + 65536, int(B * self.headroom) + 1024
         if cap_R is not None:
             self.cap_R = int(cap_R)
@@ -644,7 +700,8 @@ class GraphedStep:
         op, sc, rot = m.opacity.detach(), m.scaling.detach(), m.rotation.detach()
         scal = (float(c.tanfovx), float(c.tanfovy), float(c.limx_neg), float(c.limx_pos), float(c.limy_neg), float(c.limy_pos))
         (R, B, image, _T, radii, geom, binning, img, sample) = rz.rasterize_gaussians_capacity(
-            self.bufs, self.bg, xyz, op, sc, rot, 1.0, self.view, self.proj, *scal, dc, rest, m.sh_degree, self.campos, raw_params=True)
+            self.bufs, self.bg, xyz, op, sc, rot, 1.0, self.view, self.proj, *scal, dc, rest, m.sh_degree, self.campos, raw_params=True,
+            tie_rank=getattr(m, "tie_rank", None))
         dL_dimage, self.terms = self.fl.forward_backward(image, self.gt)
         rz.rasterize_gaussians_backward(self.bg, xyz, radii, self.e, sc, rot, 1.0, self.e, self.view, self.proj, scal[0], scal[1], *scal[2:],
                                         dL_dimage, dc, rest, m.sh_degree, self.campos, geom, R, binning, img, B, sample, m.lambda_erank, False,

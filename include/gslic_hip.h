@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSLIC_ABI_VERSION 6
+#define GSLIC_ABI_VERSION 7
 
 typedef enum gslic_status {
     GSLIC_OK = 0,
@@ -66,6 +66,13 @@ typedef struct gslic_raster_params {
                                RAW parameters (logit, log, unnormalised quaternion); sigmoid / exp / normalize of
                                renderer.cpp:57-63 + gaussian.cpp:147-175 run inside the kernels, and the backward returns
                                dL/d(raw) in dL_dopacity / dL_dscale / dL_drot (the chain LibTorch autograd would apply). */
+    const uint32_t* tie_rank; /* NULL for the drop-in shim (ABI 7).  DEVICE uint32[P], optional: for a host that keeps the map's rows in a
+                               PERMUTED order (trainer.GaussianModel(order="morton"): rows sorted along a space-filling curve so that what a
+                               view sees is contiguous in memory), tie_rank[i] = index of row i in the ORIGINAL (insertion) order.  The
+                               reference lists Gaussians of equal (tile, depth bits) by ascending index (stable 64-bit sort of the
+                               index-ordered emission, rasterizer_impl.cu:395-424); with tie_rank set, equal depths are listed by ascending
+                               tie_rank instead of by row index, so a permuted map renders and trains bit-identically to the unpermuted
+                               one.  Read by the forward only. */
 } gslic_raster_params;
 
 /* ------------------------------------------------------------------------------------------------

@@ -100,7 +100,7 @@ def compare(kind, P, W, H, deg, seed, modes=("fast", "strict"), backward=True, v
                 for k in GRADS:
                     scale = None
                     if k == "dL_drot":   # unnormalised-quaternion gradient: scale of the chain it belongs to (as test_vs_reference_kernels_gpu.py)
-                        scale = max(float(np.abs(ref["dL_drot"]).max()), float(np.abs(ref["dL_dscale"]).max() * sc["scales"].max()))
+                        scale = max(float(np.abs(ref["dL_drot"]).max()), float(np.abs(ref["dL_dscale"]).max() * sc["scales"].max()), 1e-30)   # (a view that sees nothing: all zeros)
                     st[k] = _err_stats(g[k], ref[k], scale, keep_over=(mode == "strict" and P <= PROBE_MAX_P))
                 if mode == "strict" and P <= PROBE_MAX_P:
                     conditioning_probe(st, sc, camd, dL.numpy(), scale_modifier)

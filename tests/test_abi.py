@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in gslic_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names
-    assert _lib.lib().gslic_abi_version() == 6
+    assert _lib.lib().gslic_abi_version() == 7
 
 
 def test_scratch_sizes_and_errors_without_gpu():

@@ -78,6 +78,34 @@ def test_bench_under_torchrun_one_rank():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_gpus_2_launches_itself():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE — the shape of the driver's N = 1 command — spawns its two ranks itself and prints
+    ONE JSON line from rank 0 carrying the N > 1 fields.  On a one-GPU box the two ranks share the device (RCCL refuses that: the collectives go
+    through gloo on device tensors and the line says so); on a box with two GPUs the same command runs over RCCL and `rccl_ranks` is 2."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GSLIC_FORCE_DIST")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", GSLIC_DIST_PRIME_STEPS="3")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--gaussians", "100000",
+           "--width", "640", "--height", "360", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["launch"]["ranks"] == 2 and d["launch"]["ranks_reached_by_all_reduce"] == 2 and d["launch"]["self_launched"] is True
+    assert len(d["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in d["per_rank_ms_per_step"])
+    assert d["exchange"]["world"] == 2 and d["exchange"]["collectives_per_step"] == 3
+    mb = d["rccl_microbench"]
+    for k in ("all_gather_payload", "all_reduce_xyz", "all_reduce_opacity_scaling_rotation", "all_reduce_dense_slab", "three_collectives_of_the_step_together"):
+        assert mb[k]["ms"] > 0, (k, mb)
+    if torch.cuda.device_count() >= 2:
+        assert d["rccl_ranks"] == 2 and d["launch"]["backend"].startswith("nccl")
+    else:
+        assert d["rccl_ranks"] is None and d["launch"]["backend"].startswith("gloo")
+
+
 TWO_RANK_SNIPPET = r"""
 import os, sys, hashlib, torch
 sys.path.insert(0, {root!r})

@@ -234,3 +234,26 @@ def test_view_sharding_rule():
     assert np.allclose(cens[:, 0], (np.arange(8) - 3.5) * 0.25, atol=1e-6) and np.allclose(cens[:, 1:], 0, atol=1e-6)
     for v in views:   # full_proj = view x proj, stored transposed (camera.h:60,86,109)
         assert np.allclose(v.full_proj_transform, v.world_view_transform @ v.projection_matrix, atol=1e-6)
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """bench.py --gpus N without WORLD_SIZE re-launches itself under torch.distributed.run on 127.0.0.1 with N ranks and its own flags (the GPU
+    run of it is tests/test_dist_gpu.py::test_bench_gpus_2_launches_itself)."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    assert bench.self_launch(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["GSLIC_BENCH_SELF_LAUNCHED"] == "1"

@@ -72,3 +72,21 @@ def test_ply_equals_reference_tinyply_golden(tmp_path):
         back = io_ply.load_map(os.path.join(gdir, name + ".ply"))   # and the loader reads the reference-written file
         for k in ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation"):
             assert torch.equal(back[k], raw[k][sky:]), (name, k)
+
+
+def test_save_map_of_a_permuted_model_writes_the_original_order(tmp_path):
+    """A model that stores its rows permuted (trainer.GaussianModel(order="morton")) exposes original_order(); saveMap then writes the rows in the
+    map's ORIGINAL order, byte for byte the file of the unpermuted model (CPU stand-in models; the device model: tests/test_morton_order_gpu.py)."""
+    import types
+    import torch
+    from gaussian_lic_amd import io_ply, trainer
+    from gaussian_lic_amd.synthetic import random_scene
+    raw = random_scene(500, 64, 48, sh_degree=3, seed=3)
+    perm = trainer.morton_order(raw["xyz"])
+    assert sorted(perm.tolist()) == list(range(500))
+    a = types.SimpleNamespace(**{k: v for k, v in raw.items() if torch.is_tensor(v)})
+    b = types.SimpleNamespace(**{k: v[perm] for k, v in raw.items() if torch.is_tensor(v)})
+    b.original_order = lambda: torch.argsort(perm)
+    pa, pb = str(tmp_path / "a.ply"), str(tmp_path / "b.ply")
+    io_ply.save_map(a, pa, skybox_points_num=7); io_ply.save_map(b, pb, skybox_points_num=7)
+    assert open(pa, "rb").read() == open(pb, "rb").read()
