@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd $R
-timeout 420 python -m pytest tests -x -q -m gpu > $OUT/${TAG}_gpu_suite.log 2>&1; echo "pytest rc $?" >> $OUT/${TAG}_gpu_suite.log
+timeout 900 python -m pytest tests -x -q -m gpu > $OUT/${TAG}_gpu_suite.log 2>&1; echo "pytest rc $?" >> $OUT/${TAG}_gpu_suite.log
 tail -3 $OUT/${TAG}_gpu_suite.log
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.log 2>&1; echo "smoke rc $?" >> $OUT/${TAG}_smoke.log
 tail -2 $OUT/${TAG}_smoke.log

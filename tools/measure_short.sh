@@ -10,7 +10,8 @@ cd /tmp && export TMPDIR=/tmp
 B="timeout 300 python $R/bench.py"
 X="--no-cpu-baseline --no-extras --steps 100"
 {
-  $B 2>/dev/null | tail -1                                                   # the default line (config 3, strict arithmetic), every secondary leg
+  $B --extras 2>/dev/null | tail -1                                          # the default line (config 3, strict arithmetic, Morton row order) + every secondary leg (second process)
+  $B $X --map-order insertion 2>/dev/null | tail -1                          # the same step on the rows as generated (random order)
   GSLIC_FAST_MATH=1 $B $X 2>/dev/null | tail -1                              # the opt-in fast arithmetic (pipeline backward)
   GSLIC_BWD_SCAN=0 $B $X 2>/dev/null | tail -1                               # strict arithmetic on round 3's pipeline backward
   $B --scene lidar --gaussians 500000 $X 2>/dev/null | tail -1               # config 2 at its own size

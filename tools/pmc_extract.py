@@ -37,6 +37,7 @@ def main(fetch_db, write_db, out, tag="untagged", units_file=None):
         u = json.load(open(units_file))
         res["units"] = {k: u[k] for k in ("P", "V", "R", "B", "R_live", "B_live", "steps_before")}
         res["strict"] = bool(u.get("strict", True))
+        res["map_order"] = u.get("map_order", "insertion")   # row order of the map the counters were collected on (bench.py --map-order)
     for k in sorted(set(f) | set(w)):
         if "gslic::" not in k:
             continue

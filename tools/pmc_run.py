@@ -17,7 +17,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 del a, b
 W, H, P = 1920, 1080, 2_000_000
-model = trainer.GaussianModel(random_scene(P, W, H, 3, 0), dev); model.training_setup({k: v * 0.01 for k, v in trainer.DEFAULT_LRS.items()})  # stationary scene, as bench.py
+MAP_ORDER = os.environ.get("PMC_MAP_ORDER", "morton")   # bench.py's default row order
+model = trainer.GaussianModel(random_scene(P, W, H, 3, 0), dev, order=MAP_ORDER); model.training_setup({k: v * 0.01 for k, v in trainer.DEFAULT_LRS.items()})  # stationary scene, as bench.py
 cam = synthetic_camera(W, H).to_device(dev)
 gt = gt_image(H, W).to(dev); bg = torch.zeros(3, device=dev)
 fused = os.environ.get("PMC_HOST", "fused") == "fused"   # the default bench path; PMC_HOST=dropin for the per-op path
@@ -43,6 +44,6 @@ if os.environ.get("PMC_UNITS"):
     live_b = (dbg["max_contrib"].long() + 63) // 64
     strict = bool(_lib.set_math_mode(True)); _lib.set_math_mode(strict)
     json.dump({"P": P, "V": int(vis.sum().item()), "R": int(fwd[0]), "B": int(fwd[1]), "B_live": int(live_b.sum().item()),
-               "R_live": int(torch.minimum(n_t, 64 * live_b).sum().item()), "steps_before": int(os.environ.get("PMC_STEPS", "25")), "strict": strict},
+               "R_live": int(torch.minimum(n_t, 64 * live_b).sum().item()), "steps_before": int(os.environ.get("PMC_STEPS", "25")), "strict": strict, "map_order": MAP_ORDER},
               open(os.environ["PMC_UNITS"], "w"))
 print("pmc workload done")
