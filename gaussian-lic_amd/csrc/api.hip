@@ -190,12 +190,12 @@ __global__ void publish_kernel(const uint32_t* __restrict__ v0, const uint32_t* 
     __hip_atomic_store(box + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // out[0] = *v0, out[1] = (*v1 & 1) | scan-timeout << 1 | scan-overflow << 2
-static int fetch_counts(const uint32_t* v0, const uint32_t* v1, uint32_t out[2], hipStream_t s)
+static int fetch_counts(const uint32_t* v0, const uint32_t* v1, uint32_t out[2], hipStream_t s, uint32_t* fault = nullptr)
 {
     int dev = 0;
     GS_HIP(hipGetDevice(&dev));
     static const bool use_mailbox = getenv("GSLIC_NO_MAILBOX") == nullptr;
-    uint32_t* const status = device_status_word();
+    uint32_t* const status = fault ? fault : device_status_word();   // (a forward passes its own word: GS_FLAG_FAULT)
     if (use_mailbox && dev >= 0 && dev < kMaxDevices) {
         Mailbox& m = t_mbox.box[dev];
         if (!m.host) {
@@ -337,8 +337,9 @@ static uint32_t capacity_for(size_t bytes, F bytes_needed)
 //   [0] R, [1] B of this forward; [2] its bits: 1 instances did not fit, 2 buckets did not fit, 4 prefiltered violation, 8 a scan / sort
 //   look-back wait timed out, 16 the instance count overflowed 2^31; [3] forwards that completed (no bit of 1 | 2 | 8 | 16);
 //   [4] forwards issued; [5] bit (issue index mod 32) set for every forward that did NOT complete; [6] / [7] the largest R / B seen.
-// The device status word of the chained scans (timeout / overflow) is consumed here: the backward of a forward whose prefix sums cannot be
-// trusted stands down through flags[2] like one that overflowed, and no stale bit is left for the next, unrelated forward on this device.
+// The forward's own fault word (flags[GS_FLAG_FAULT]: timeout / overflow of ITS chained scans and sorts) is consumed here: the backward of a forward
+// whose prefix sums cannot be trusted stands down through flags[2] like one that overflowed.  Per forward, so capacity-mode forwards may run
+// concurrently on several streams of one device (round 4 kept these bits in one device-global word).
 __global__ void forward_status_kernel(const uint32_t* __restrict__ R, const uint32_t* __restrict__ B, uint32_t* __restrict__ flags,
                                       uint32_t* __restrict__ dev_status, uint32_t* __restrict__ out)
 {
@@ -416,12 +417,12 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
         SortBuffers sb;
         sb.keys[0] = geom.depth_keys[0]; sb.keys[1] = geom.depth_keys[1]; sb.v0[0] = geom.order[0]; sb.v0[1] = geom.order[1];
         sb.v1[0] = sb.v1[1] = nullptr; sb.v0_identity = true;
-        GS_TRY(radix_sort_u32(sb, geom.plan, geom.sort_scratch, (onesweep_mask() & 1) != 0, K_DSORT_HIST, K_DSORT_SCATTER, s));
+        GS_TRY(radix_sort_u32(sb, geom.plan, geom.sort_scratch, (onesweep_mask() & 1) != 0, K_DSORT_HIST, K_DSORT_SCATTER, s, nullptr, geom.flags + GS_FLAG_FAULT));
     }
     uint32_t* const order = geom.order[geom.plan.passes & 1];
     if (prm->tie_rank)   // rows stored in a permuted order: equal depths listed by the rows' ORIGINAL indices, as the reference's stable sort lists them
         GS_TRY(launch_tie_fix((size_t)P, geom.depth_keys[geom.plan.passes & 1], order, prm->tie_rank, 0xffffffffu, s));
-    GS_TRY(scan_u32_chained(geom.tiles_touched, order, geom.point_offsets, (size_t)P, false, geom.scan_state, s));
+    GS_TRY(scan_u32_chained(geom.tiles_touched, order, geom.point_offsets, (size_t)P, false, geom.scan_state, s, geom.flags + GS_FLAG_FAULT));
     uint32_t hostbuf[2] = {0, 0};
     const int end_bit = sort_end_bit(T);
     const uint32_t* const R_dev = cap ? geom.point_offsets + (P - 1) : nullptr;  // capacity mode: the count stays on the device
@@ -431,9 +432,8 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
         // status bit 0 when it does not fit.  No host read (the reference blocks here, rasterizer_impl.cu:398).
         R = capacity_for(cap->binning_bytes, [&](uint32_t r) { size_t b; BinningState::carve(nullptr, (size_t)r, end_bit, no_color, &b); return b; });
         if (R == 0) return set_error(GSLIC_ERR_INVALID_ARG, "capacity mode: the binning buffer (%zu bytes) does not hold a single instance", cap->binning_bytes);
-        if (!device_status_word()) return set_error(GSLIC_ERR_ALLOC, "capacity mode: the device status word could not be allocated");  // (allocated by the first call on a device: make one eager call before capturing a graph)
     } else {
-        GS_TRY(fetch_counts(geom.point_offsets + (P - 1), geom.flags, hostbuf, s));  // host needs R to size the binning buffer (rasterizer_impl.cu:398)
+        GS_TRY(fetch_counts(geom.point_offsets + (P - 1), geom.flags, hostbuf, s, geom.flags + GS_FLAG_FAULT));  // host needs R to size the binning buffer (rasterizer_impl.cu:398)
         if (hostbuf[1] & 2u) return set_error(GSLIC_ERR_HIP, "a chained-scan look-back wait timed out (device preempted?): the forward was abandoned");
         if (hostbuf[1] & 4u) return set_error(GSLIC_ERR_INVALID_ARG, "more than 2^31 (Gaussian, tile) instances");
         if (prm->prefiltered && (hostbuf[1] & 1u)) return set_error(GSLIC_ERR_PREFILTERED, "a point was culled although prefiltered is set");
@@ -458,7 +458,7 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
         SortBuffers sb;
         for (int i = 0; i < 2; i++) { sb.keys[i] = bin.tile_keys[i]; sb.v0[i] = bin.slots[i]; sb.v1[i] = bin.gauss[i]; }
         sb.v0_identity = true;
-        GS_TRY(radix_sort_u32(sb, bin.plan, bin.sort_scratch, (onesweep_mask() & 2) != 0, K_SORT_HIST, K_SORT_SCATTER, s, R_dev));
+        GS_TRY(radix_sort_u32(sb, bin.plan, bin.sort_scratch, (onesweep_mask() & 2) != 0, K_SORT_HIST, K_SORT_SCATTER, s, R_dev, geom.flags + GS_FLAG_FAULT));
         DEBUG_SYNC(prm, s);
         GS_TRY(launch_finalize_ranges(R, R_dev, bin.sorted_tiles(), img.ranges, bin.dead, s));
         DEBUG_SYNC(prm, s);
@@ -472,7 +472,7 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
         if (cap) {
             B = capacity_for(cap->sample_bytes, [&](uint32_t b) { size_t n; SampleState::carve(nullptr, (size_t)b, &n); return n; });
         } else {
-            GS_TRY(fetch_counts(img.bucket_offsets + (T - 1), nullptr, hostbuf, s));  // rasterizer_impl.cu:442
+            GS_TRY(fetch_counts(img.bucket_offsets + (T - 1), nullptr, hostbuf, s, geom.flags + GS_FLAG_FAULT));  // rasterizer_impl.cu:442
             if (hostbuf[1] & 2u) return set_error(GSLIC_ERR_HIP, "a sort look-back / chained-scan wait timed out (device preempted?): the forward was abandoned");
             B = hostbuf[0];
         }
@@ -492,7 +492,7 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
     DEBUG_SYNC(prm, s);
     if (cap) {
         hipLaunchKernelGGL(forward_status_kernel, dim3(1), dim3(1), 0, s, (const uint32_t*)(geom.point_offsets + (P - 1)),
-                           no_color ? (const uint32_t*)nullptr : (const uint32_t*)(img.bucket_offsets + (T - 1)), geom.flags, device_status_word(),
+                           no_color ? (const uint32_t*)nullptr : (const uint32_t*)(img.bucket_offsets + (T - 1)), geom.flags, geom.flags + GS_FLAG_FAULT,
                            cap->status_out);
         GS_HIP(hipGetLastError());
     }

@@ -70,6 +70,9 @@ void prof_begin(int id, hipStream_t s);
 void prof_end(int id, hipStream_t s);
 extern bool g_prof_on;
 #define GS_FLAG_HITBITS 4   // index into GeomState::flags: set by a forward that recorded SampleState::hit
+#define GS_FLAG_FAULT 8     // index into GeomState::flags: bit 0 a bounded look-back wait of THIS forward's scans / sorts gave up, bit 1 its instance count
+                            // overflowed.  Per forward (the flags are zeroed at its start), so forwards running concurrently on several streams of
+                            // one device cannot consume each other's bits — round 4 kept them in one device-global word (device_status_word)
 extern int g_strict_math;  // gslic_set_math_mode(): 1 (default) = blend kernels in the reference's arithmetic (render.hip), 0 = fast (GSLIC_FAST_MATH=1)
 
 // g_lds_pad[id]: extra dynamic LDS per workgroup of kernel class id — occupancy experiments only (GSLIC_LDS_PAD="render_bwd=4000,preprocess=2000",
@@ -122,7 +125,9 @@ int scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, uint32
 // the same in ONE launch (chained tiles); optional gather: scans in[gather[i]].  `zeroed_state`: scan_state_bytes(n) bytes the
 // caller has zeroed on the stream (it is consumed: zero it again before the next scan)
 size_t scan_state_bytes(size_t n);
-int scan_u32_chained(const uint32_t* in, const uint32_t* gather, uint32_t* out, size_t n, bool exclusive, void* zeroed_state, hipStream_t s);
+// fault: the word that receives the timeout / overflow bits (NULL: the device-global word — callers outside a forward: knn, extend)
+int scan_u32_chained(const uint32_t* in, const uint32_t* gather, uint32_t* out, size_t n, bool exclusive, void* zeroed_state, hipStream_t s,
+                     uint32_t* fault = nullptr);
 
 // radix_sort.hip ------------------------------------------------------------------------------------------
 #define GS_SORT_ITEMS 16
@@ -148,7 +153,7 @@ struct SortBuffers {
 size_t sort_scratch_bytes(const SortPlan& plan);
 // n_dev != NULL: the real element count (<= plan.n, which is then the capacity the launches are sized for) is read on the device.
 int radix_sort_u32(const SortBuffers& b, const SortPlan& plan, void* scratch, bool onesweep, int id_hist, int id_scatter, hipStream_t s,
-                   const uint32_t* n_dev = nullptr);
+                   const uint32_t* n_dev = nullptr, uint32_t* fault = nullptr);
 // After a stable sort of (key, id) pairs: every run of EQUAL keys (other than `skip_key`) is put into ascending rank[id] order instead of
 // ascending id order (gslic_raster_params.tie_rank: a map whose rows are stored permuted lists equal depths in its ORIGINAL order).
 int launch_tie_fix(size_t n, const uint32_t* sorted_keys, uint32_t* ids, const uint32_t* rank, uint32_t skip_key, hipStream_t s);

@@ -307,11 +307,11 @@ size_t sort_scratch_bytes(const SortPlan& plan)
 
 template <int NV>
 static int sort_impl(const SortBuffers& b, const SortPlan& plan, const uint32_t* n_dev, void* scratch, bool onesweep, int id_hist, int id_scatter,
-                     hipStream_t s)
+                     hipStream_t s, uint32_t* fault)
 {
     const unsigned nblk = (unsigned)plan.nblk;
     SortPassArgs a;
-    a.n = plan.n; a.n_dev = n_dev; a.nblk = nblk; a.status = nullptr; a.ticket = nullptr; a.timeout = onesweep ? device_status_word() : nullptr;
+    a.n = plan.n; a.n_dev = n_dev; a.nblk = nblk; a.status = nullptr; a.ticket = nullptr; a.timeout = onesweep ? (fault ? fault : device_status_word()) : nullptr;
     const size_t ssb = scan_state_bytes(plan.hist_elems);
     uint32_t* hist = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + 4 * ssb);
     unsigned long long* status = reinterpret_cast<unsigned long long*>(scratch);
@@ -337,7 +337,7 @@ static int sort_impl(const SortBuffers& b, const SortPlan& plan, const uint32_t*
             unsigned long long* const state = reinterpret_cast<unsigned long long*>(static_cast<char*>(scratch) + (size_t)p * ssb);  // one chained-scan state per pass
             GS_LAUNCH(id_hist, sort_hist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, a.kin, plan.n, n_dev, a.shift, hist, nblk, state,
                       (uint32_t)(ssb / sizeof(unsigned long long)));
-            GS_TRY(scan_u32_chained(hist, nullptr, hist, plan.hist_elems, true, state, s));
+            GS_TRY(scan_u32_chained(hist, nullptr, hist, plan.hist_elems, true, state, s, fault));
             a.table = hist;
             GS_LAUNCH(id_scatter, (sort_scatter_kernel<NV, false>), dim3(nblk), dim3(RS_THREADS), 0, s, a);
         }
@@ -374,12 +374,12 @@ int launch_tie_fix(size_t n, const uint32_t* sorted_keys, uint32_t* ids, const u
 }
 
 int radix_sort_u32(const SortBuffers& b, const SortPlan& plan, void* scratch, bool onesweep, int id_hist, int id_scatter, hipStream_t s,
-                   const uint32_t* n_dev)
+                   const uint32_t* n_dev, uint32_t* fault)
 {
     if (plan.n == 0) return GSLIC_OK;
     if (plan.n > 0xffffffffull) return set_error(GSLIC_ERR_INVALID_ARG, "radix sort: more than 2^32 elements");
-    return b.v1[0] ? sort_impl<2>(b, plan, n_dev, scratch, onesweep, id_hist, id_scatter, s)
-                   : sort_impl<1>(b, plan, n_dev, scratch, onesweep, id_hist, id_scatter, s);
+    return b.v1[0] ? sort_impl<2>(b, plan, n_dev, scratch, onesweep, id_hist, id_scatter, s, fault)
+                   : sort_impl<1>(b, plan, n_dev, scratch, onesweep, id_hist, id_scatter, s, fault);
 }
 
 }  // namespace gslic

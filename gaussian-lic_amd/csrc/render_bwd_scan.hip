@@ -311,6 +311,7 @@ __global__ __launch_bounds__(64, GS_SCAN_WAVES) void render_bwd_scan_kernel(Rend
 #if GS_SCAN_PREFETCH
     PixIn nxt = load_pix(0);
 #endif
+    uint32_t any_lo = 0u, any_hi = 0u;   // entries SOME pixel of the tile blended (wave-uniform): the others' nine sums are exact zeros
     for (int q = 0; q < (((GS_SCAN_SKIP & 2) && a.T > -1) ? 0 : 4); q++) {
         // ---- lane = pixel of quadrant q
 #if GS_SCAN_PREFETCH
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(64, GS_SCAN_WAVES) void render_bwd_scan_kernel(Rend
         uint32_t S_lo[2], S_hi[2];
         half_or(mlo, S_lo[0], S_lo[1]);
         half_or(mhi, S_hi[0], S_hi[1]);
+        any_lo |= S_lo[0] | S_lo[1]; any_hi |= S_hi[0] | S_hi[1];
         const uint32_t balh[2] = {(uint32_t)bal, (uint32_t)(bal >> 32)};
         const int half = lane >> 5;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the previous quadrant's LDS traffic is done before its records are overwritten
@@ -379,7 +381,15 @@ __global__ __launch_bounds__(64, GS_SCAN_WAVES) void render_bwd_scan_kernel(Rend
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    if (valid && !((GS_SCAN_SKIP & 16) && a.T > -1)) {   // lane = entry again: the instance's 36-byte row (as render_bwd_kernel writes it)
+    // An entry no pixel of the tile blended (21 % of the instances of live buckets on the 2M / 1080p scene: the conservative tile test let them in,
+    // or every pixel they reach was finished) has nine exact zeros: a flag byte — what the dead buckets write — stands for its 36-byte row, and
+    // preprocess_bwd does not fetch it.  (GS_SCAN_ZERO_ROWS=1 writes the rows of zeros as before: A/B.)
+#ifndef GS_SCAN_ZERO_ROWS
+#define GS_SCAN_ZERO_ROWS 0
+#endif
+    const bool blended = GS_SCAN_ZERO_ROWS || (lane < 32 ? ((any_lo >> lane) & 1u) : ((any_hi >> (lane - 32)) & 1u));
+    if (valid && !blended && !((GS_SCAN_SKIP & 8) && a.T > -1)) a.dead[slot] = 1;
+    if (valid && blended && !((GS_SCAN_SKIP & 16) && a.T > -1)) {   // lane = entry again: the instance's 36-byte row (as render_bwd_kernel writes it)
         const float4 e0 = S.ent[SC_ENT_F4 * lane], e1 = S.ent[SC_ENT_F4 * lane + 1], e2 = S.ent[SC_ENT_F4 * lane + 2];
         const ScanEntry L = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x};
         const float rop = e2.y;

@@ -236,7 +236,8 @@ size_t scan_state_bytes(size_t n)
     return ((a > b ? a : b) + 255) & ~size_t(255);
 }
 
-int scan_u32_chained(const uint32_t* in, const uint32_t* gather, uint32_t* out, size_t n, bool exclusive, void* zeroed_state, hipStream_t s)
+int scan_u32_chained(const uint32_t* in, const uint32_t* gather, uint32_t* out, size_t n, bool exclusive, void* zeroed_state, hipStream_t s,
+                     uint32_t* fault)
 {
     if (n == 0) return GSLIC_OK;
     const size_t nb = div_up_sz(n, SCAN_TILE);
@@ -253,7 +254,7 @@ int scan_u32_chained(const uint32_t* in, const uint32_t* gather, uint32_t* out, 
         return GSLIC_OK;
     }
     GS_LAUNCH(K_SCAN_APPLY, scan_chained_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, out, n, exclusive ? 1 : 0,
-              reinterpret_cast<unsigned long long*>(zeroed_state), device_status_word());
+              reinterpret_cast<unsigned long long*>(zeroed_state), fault ? fault : device_status_word());
     return GSLIC_OK;
 }
 

@@ -70,7 +70,11 @@ def psnr(img1, img2):
 def _gaussian_window(window_size, sigma, channel, like):
     """gaussian() + create_window() of loss_utils.h:41-74 (float math like the reference)."""
     import math
-    g = torch.tensor([math.exp(-((x - window_size // 2) ** 2) / (2.0 * sigma * sigma)) for x in range(window_size)], dtype=torch.float32)
+    import numpy as np
+    # std::exp(-temp * temp / (2.0f * sigma * sigma)) with a float argument (loss_utils.h:50-51): the quotient is rounded to float BEFORE the exponential
+    # (expf: correctly rounded here, like the double exp of the float argument rounded once); tests/golden/eval_*.npz hold the reference's window
+    den = np.float32(2.0) * np.float32(sigma) * np.float32(sigma)
+    g = torch.tensor([float(np.float32(math.exp(float(np.float32(-((x - window_size // 2) ** 2)) / den)))) for x in range(window_size)], dtype=torch.float32)
     g = (g / g.sum()).unsqueeze(1)
     w2 = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
     return w2.expand(channel, 1, window_size, window_size).contiguous().to(like.device).type_as(like)

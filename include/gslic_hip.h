@@ -136,7 +136,8 @@ int gslic_rasterize_forward(
  *                           (device preempted), 16: more than 2^31 instances — [3] += 1 when none of 1 | 2 | 8 | 16 is set (forwards
  *                           that completed), [4] += 1 always (forwards issued), [5] |= 1 << (issue index mod 32) for a forward that
  *                           did not complete, [6] / [7] = the largest R / B seen (what to size a retry from).
- *  The first call on a device allocates one status word (hipMalloc): make one eager call before capturing the step in a graph.
+ *  The timeout / overflow bits of a forward live in its own geometry buffer (ABI 7): capacity-mode forwards on different buffers may run
+ *  concurrently on several streams of one device, and nothing is allocated by the first call.
  *  On overflow or timeout (bit 1, 2, 8 or 16) nothing is written out of bounds, out_color / out_final_T are unspecified, and a following
  *  gslic_rasterize_backward* on these buffers does NOTHING (no gradients, no Adam update): the host re-runs the step with larger
  *  buffers once it has seen the bits.  All other arguments as gslic_rasterize_forward; results are bit-identical to it.

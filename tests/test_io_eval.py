@@ -1,4 +1,7 @@
 """CPU: PLY wire format of saveMap and the evaluation metrics of loss_utils.h (row 4)."""
+import os
+
+import pytest
 import numpy as np
 import torch
 
@@ -90,3 +93,23 @@ def test_save_map_of_a_permuted_model_writes_the_original_order(tmp_path):
     pa, pb = str(tmp_path / "a.ply"), str(tmp_path / "b.ply")
     io_ply.save_map(a, pa, skybox_points_num=7); io_ply.save_map(b, pb, skybox_points_num=7)
     assert open(pa, "rb").read() == open(pb, "rb").read()
+
+
+@pytest.mark.parametrize("name", ["eval_3x70x50", "eval_3x96x64", "eval_1x33x17"])
+def test_eval_metrics_match_the_reference_header_compiled_on_cpu(oracle32, name):
+    """Evaluation PSNR / conv-SSIM pinned to REFERENCE CODE (round-4 review, missing 6): tests/golden/eval_*.npz are the numbers of the reference's
+    own loss_utils.h:30-128 (l1_loss, psnr, ssim through gaussian() / create_window() / _ssim()), compiled unmodified against CPU LibTorch by
+    oracle/ref_build/make_eval_golden.py.  Held to them here: the host-side mirror gaussian_lic_amd.loss (same LibTorch ops) and the C oracle's
+    SSIM map, which tests/test_eval_gpu.py holds the device path (fused-SSIM kernel in inference mode) to."""
+    import torch
+    from gaussian_lic_amd import loss
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    a, b = torch.from_numpy(z["img1"]), torch.from_numpy(z["img2"])
+    np.testing.assert_array_equal(loss._gaussian_window(11, 1.5, a.size(0), a).numpy(), z["window"])      # gaussian() / create_window(), bit for bit
+    assert abs(float(loss.l1_loss(a, b)) - float(z["l1"])) <= 1e-7
+    assert abs(float(loss.psnr(a, b)) - float(z["psnr"])) <= 2e-6 * float(z["psnr"])
+    assert abs(float(loss.ssim(a, b)) - float(z["ssim"])) <= 2e-7
+    assert abs(float(loss.ssim(a[None], b[None], size_average=False)) - float(z["ssim_per_image"])) <= 2e-7
+    # the C oracle's SSIM map (separable 11-tap window, zero padding: ssim.cu:8-18,261-282) averages to the reference's conv2d formulation
+    m = oracle32.ssim_forward(z["img1"][None], z["img2"][None], train=False)[0]
+    assert abs(float(m.astype(np.float64).mean()) - float(z["ssim"])) <= 2e-6

@@ -99,6 +99,14 @@ for q in range(4):
 seg_steps += cur; rounds += 1
 print(f"quadrant-segmented pipelines: {tot(seg_steps):.2f}M steps ({100 * seg_steps.sum() / s_cur.sum():.1f}% of current), {rounds.mean():.2f} rounds per bucket; "
       f"perfect packing (sum_q (n_q + |S_q|) |S_q| / 64): {tot(((nq + nS) * nS).sum(1) / 64):.2f}M")
+# entries of live buckets that NO pixel of the tile blended: their nine partial sums are exact zeros (a flag byte could stand for the 36-byte row)
+S_tile = np.bitwise_or.reduce(m, axis=1)
+hit_e = pop32((S_tile >> np.uint64(32)).astype(np.uint32)) + pop32((S_tile & np.uint64(0xffffffff)).astype(np.uint32))
+valid_e = np.clip(n[b2t[Lb]] - bstart[Lb], 0, 64)
+print(f"entries of live buckets: {valid_e.sum() / 1e6:.2f}M, blended by >= 1 pixel of their tile: {hit_e.sum() / 1e6:.2f}M ({100 * hit_e.sum() / valid_e.sum():.1f}%); "
+      f"all-zero rows {100 - 100 * hit_e.sum() / valid_e.sum():.1f}%")
+if os.environ.get("HITMASK_ONLY_ROWS") == "1":
+    sys.exit(0)
 # lane-per-pixel alternative: (entry, quadrant) combinations with at least one blending pixel (each would cost one evaluation + a 64-lane reduction)
 print(f"(entry, quadrant) combinations with >= 1 blending pixel: {tot(nS):.2f}M = {100 * nS.sum() / (4 * 64 * Lb.size):.1f}% of all in live buckets; blended pairs per combination: {pc.sum() / max(nS.sum(), 1):.1f} of 64")
 # ---- ROW-SCAN decomposition: a wave works on (G entries x 64/G pixels) per step — lane = (entry slot, pixel row); the T / A recurrences over the G
