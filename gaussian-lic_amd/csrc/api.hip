@@ -39,7 +39,7 @@ static bool g_prof_cur_on = false;
 static const char* const k_names[K_COUNT] = {
     "preprocess", "scan_reduce", "scan_spine", "scan_apply", "keybuild", "sort_hist", "sort_scatter", "finalize_lists",
     "bucket_count", "render_fwd", "render_bwd", "preprocess_bwd", "adam", "ssim_fwd", "ssim_bwd", "knn_minmax", "knn_morton",
-    "knn_boxes", "knn_search", "debug_export", "extend", "dsort_hist", "dsort_scatter", "sh_grad_from_rgb", "tie_fix"};
+    "knn_boxes", "knn_search", "debug_export", "extend", "dsort_hist", "dsort_scatter", "sh_grad_from_rgb", "tile_lsort"};
 uint32_t g_lds_pad[K_COUNT] = {0};
 static const bool g_lds_pad_parsed = [] {   // GSLIC_LDS_PAD="name=bytes,name=bytes"
     const char* e = getenv("GSLIC_LDS_PAD");
@@ -128,6 +128,8 @@ BinningState BinningState::carve(const void* base, size_t R, int end_bit, bool n
     g.sort_scratch = c.take<char>(sort_scratch_bytes(g.plan));
     g.partials = no_color ? nullptr : c.take<float>((size_t)GS_PROW * R);
     g.dead = no_color ? nullptr : c.take<uint8_t>(R);
+    for (int i = 0; i < 4; i++)   // (36 R bytes of partial rows, unused until the backward: room for the four 4 R arrays)
+        g.lsort[i] = no_color ? c.take<uint32_t>(R) : reinterpret_cast<uint32_t*>(g.partials) + (size_t)i * R;
     if (bytes) *bytes = c.used(base) + 256;
     return g;
 }
@@ -407,22 +409,13 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
     pa.scale_modifier = prm->scale_modifier; pa.prefiltered = prm->prefiltered; pa.no_color = prm->no_color; pa.raw = prm->raw_params;
     pa.means = means3D; pa.scales = scales; pa.rots = rotations; pa.opac = opacities; pa.dc = dc; pa.shs = shs;
     pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = cam_pos;
-    pa.radii = radii; pa.rec = geom.rec; pa.tiles_touched = geom.tiles_touched; pa.depth_keys = geom.depth_keys[0]; pa.flags = geom.flags; pa.ranges = img.ranges;
+    pa.radii = radii; pa.rec = geom.rec; pa.tiles_touched = geom.tiles_touched; pa.depth_keys = nullptr; pa.flags = geom.flags; pa.ranges = img.ranges;
     GS_TRY(launch_preprocess(pa, s));
     DEBUG_SYNC(prm, s);
 
-    // Level 1: order the GAUSSIANS by (depth bits, id) — 4 digit passes over P 8-byte pairs instead of over R 12-byte ones —
-    // and hand out emission slots in that order (rasterizer_impl.cu:395 scans in id order; the slot numbering is internal).
-    {
-        SortBuffers sb;
-        sb.keys[0] = geom.depth_keys[0]; sb.keys[1] = geom.depth_keys[1]; sb.v0[0] = geom.order[0]; sb.v0[1] = geom.order[1];
-        sb.v1[0] = sb.v1[1] = nullptr; sb.v0_identity = true;
-        GS_TRY(radix_sort_u32(sb, geom.plan, geom.sort_scratch, (onesweep_mask() & 1) != 0, K_DSORT_HIST, K_DSORT_SCATTER, s, nullptr, geom.flags + GS_FLAG_FAULT));
-    }
-    uint32_t* const order = geom.order[geom.plan.passes & 1];
-    if (prm->tie_rank)   // rows stored in a permuted order: equal depths listed by the rows' ORIGINAL indices, as the reference's stable sort lists them
-        GS_TRY(launch_tie_fix((size_t)P, geom.depth_keys[geom.plan.passes & 1], order, prm->tie_rank, 0xffffffffu, s));
-    GS_TRY(scan_u32_chained(geom.tiles_touched, order, geom.point_offsets, (size_t)P, false, geom.scan_state, s, geom.flags + GS_FLAG_FAULT));
+    // Emission slots in INDEX order, as the reference hands them out (rasterizer_impl.cu:395): one plain scan.  (Rounds 2-4 sorted the Gaussians
+    // by depth first and emitted in that order; the per-tile depth sort below replaced that: DESIGN.md section 3.)
+    GS_TRY(scan_u32_chained(geom.tiles_touched, nullptr, geom.point_offsets, (size_t)P, false, geom.scan_state, s, geom.flags + GS_FLAG_FAULT));
     uint32_t hostbuf[2] = {0, 0};
     const int end_bit = sort_end_bit(T);
     const uint32_t* const R_dev = cap ? geom.point_offsets + (P - 1) : nullptr;  // capacity mode: the count stays on the device
@@ -449,18 +442,26 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
 
     if (R > 0) {
         KeybuildArgs ka;
-        ka.P = P; ka.gx = gx; ka.gy = gy; ka.rec = geom.rec; ka.order = order; ka.offsets = geom.point_offsets;
-        ka.tile_keys = bin.tile_keys[0]; ka.gauss = bin.gauss[0]; ka.gauss_start = geom.gauss_start; ka.cap = R; ka.status = geom.flags;
+        ka.P = P; ka.gx = gx; ka.gy = gy; ka.rec = geom.rec; ka.order = nullptr; ka.offsets = geom.point_offsets;
+        ka.tile_keys = bin.tile_keys[0]; ka.gauss = bin.gauss[0]; ka.depth = bin.lsort[0]; ka.gauss_start = geom.gauss_start; ka.cap = R; ka.status = geom.flags;
         GS_TRY(launch_keybuild(ka, s));
         DEBUG_SYNC(prm, s);
-        // Level 2: stable sort of the instances on the tile id alone (ceil(log2(tiles)/8) digit passes, 2 at 1080p), carrying the
-        // emission slot (identity at the start) and the Gaussian id; the sorted Gaussian-id payload IS the point list.
+        // Level 1: stable sort of the instances on the tile id alone (ceil(log2(tiles)/8) digit passes, 2 at 1080p), carrying the emission
+        // slot (identity at the start), the Gaussian id and the depth bits: instances grouped by tile, in index order inside a tile.
         SortBuffers sb;
-        for (int i = 0; i < 2; i++) { sb.keys[i] = bin.tile_keys[i]; sb.v0[i] = bin.slots[i]; sb.v1[i] = bin.gauss[i]; }
+        for (int i = 0; i < 2; i++) { sb.keys[i] = bin.tile_keys[i]; sb.v0[i] = bin.slots[i]; sb.v1[i] = bin.gauss[i]; sb.v2[i] = bin.lsort[i]; }
         sb.v0_identity = true;
         GS_TRY(radix_sort_u32(sb, bin.plan, bin.sort_scratch, (onesweep_mask() & 2) != 0, K_SORT_HIST, K_SORT_SCATTER, s, R_dev, geom.flags + GS_FLAG_FAULT));
         DEBUG_SYNC(prm, s);
         GS_TRY(launch_finalize_ranges(R, R_dev, bin.sorted_tiles(), img.ranges, bin.dead, s));
+        DEBUG_SYNC(prm, s);
+        // Level 2: every tile's segment by depth (stable: equal depths stay in index order, or in tie_rank order) — one workgroup per tile
+        const int pp = bin.plan.passes & 1;
+        TileDepthSortArgs ts;
+        ts.T = T; ts.ranges = img.ranges; ts.depth = bin.lsort[pp]; ts.depth_alt = bin.lsort[pp ^ 1]; ts.idx_a = bin.lsort[2]; ts.idx_b = bin.lsort[3];
+        ts.gauss_in = bin.gauss[pp]; ts.slot_in = bin.slots[pp]; ts.gauss_out = bin.gauss[pp ^ 1]; ts.slot_out = bin.slots[pp ^ 1];
+        ts.tie_rank = prm->tie_rank; ts.status = geom.flags; ts.long_tiles = img.bucket_offsets;
+        GS_TRY(launch_tile_depth_sort(ts, s));
         DEBUG_SYNC(prm, s);
     }
 

@@ -63,13 +63,14 @@ enum KernelId {
     K_DSORT_HIST,
     K_DSORT_SCATTER,
     K_SH_REBUILD,
-    K_TIE_FIX,
+    K_TILE_LSORT,
     K_COUNT
 };
 void prof_begin(int id, hipStream_t s);
 void prof_end(int id, hipStream_t s);
 extern bool g_prof_on;
 #define GS_FLAG_HITBITS 4   // index into GeomState::flags: set by a forward that recorded SampleState::hit
+#define GS_FLAG_LONG 9      // index into GeomState::flags: number of tiles whose instance list is longer than the one-wave depth sort takes (radix_sort.hip)
 #define GS_FLAG_FAULT 8     // index into GeomState::flags: bit 0 a bounded look-back wait of THIS forward's scans / sorts gave up, bit 1 its instance count
                             // overflowed.  Per forward (the flags are zeroed at its start), so forwards running concurrently on several streams of
                             // one device cannot consume each other's bits — round 4 kept them in one device-global word (device_status_word)
@@ -147,16 +148,36 @@ SortPlan sort_plan(size_t n, int end_bit);
 struct SortBuffers {
     uint32_t* keys[2];
     uint32_t* v0[2];
-    uint32_t* v1[2];
+    uint32_t* v1[2];   // NULL: one payload
+    uint32_t* v2[2];   // NULL: at most two payloads
     bool v0_identity;
 };
 size_t sort_scratch_bytes(const SortPlan& plan);
 // n_dev != NULL: the real element count (<= plan.n, which is then the capacity the launches are sized for) is read on the device.
 int radix_sort_u32(const SortBuffers& b, const SortPlan& plan, void* scratch, bool onesweep, int id_hist, int id_scatter, hipStream_t s,
                    const uint32_t* n_dev = nullptr, uint32_t* fault = nullptr);
-// After a stable sort of (key, id) pairs: every run of EQUAL keys (other than `skip_key`) is put into ascending rank[id] order instead of
-// ascending id order (gslic_raster_params.tie_rank: a map whose rows are stored permuted lists equal depths in its ORIGINAL order).
-int launch_tie_fix(size_t n, const uint32_t* sorted_keys, uint32_t* ids, const uint32_t* rank, uint32_t skip_key, hipStream_t s);
+// Level 2 of the binning (round 5): every tile's segment [ranges[t].x, ranges[t].y) of the tile-sorted instance list, which is in emission
+// (= Gaussian index) order inside a tile, is sorted by depth bits — stable, so equal depths stay in index order, or in tie_rank order when the
+// map's rows are stored permuted — by ONE workgroup per tile: an LSD radix sort of (depth, local index) pairs in LDS for segments of up to
+// LS_CAP instances, through the four scratch arrays for longer ones.  gauss_out / slot_out receive the tile's Gaussian ids / emission slots in
+// the reference's list order (rasterizer_impl.cu:419-424: stable 64-bit sort of tile << 32 | depth over the index-ordered emission).
+struct TileDepthSortArgs {
+    int T;
+    const uint2* ranges;
+    uint32_t* depth;            // [R] sorted by tile (the third payload of the tile sort); scratch for segments longer than LS_CAP
+    uint32_t* depth_alt;        // [R] scratch
+    uint32_t* idx_a;            // [R] scratch
+    uint32_t* idx_b;            // [R] scratch
+    const uint32_t* gauss_in;   // [R] sorted by tile
+    const uint32_t* slot_in;    // [R] sorted by tile
+    uint32_t* gauss_out;        // [R] the point list
+    uint32_t* slot_out;         // [R] emission slot of every list entry
+    const uint32_t* tie_rank;   // optional [P]: gslic_raster_params.tie_rank
+    uint32_t* status;           // device status words (GeomState::flags): a non-zero [2] (capacity overflow) makes the kernels return;
+                                // [GS_FLAG_LONG] counts the tiles whose list is longer than one wave sorts (zero at the start of a forward)
+    uint32_t* long_tiles;       // [T] scratch: ids of those tiles (ImageState::bucket_offsets, rewritten by the bucket scan afterwards)
+};
+int launch_tile_depth_sort(const TileDepthSortArgs& a, hipStream_t s);
 
 // opaque scratch layouts ----------------------------------------------------------------------------------
 struct GeomState {
@@ -183,14 +204,18 @@ struct ImageState {
 struct BinningState {
     uint32_t* tile_keys[2];   // [R] ping-pong: tile id of the instance
     uint32_t* slots[2];       // [R] ping-pong payload: emission slot u (where the backward writes the instance's partials)
-    uint32_t* gauss[2];       // [R] ping-pong payload: Gaussian id; gauss[passes & 1] after the sort IS the point list
+    uint32_t* gauss[2];       // [R] ping-pong payload: Gaussian id; after the tile sort gauss[passes & 1] holds the ids by tile, in index order inside
+                              // a tile; the per-tile depth sort writes the point list into the OTHER side
+    uint32_t* lsort[4];       // [R] each: depth bits of the instance (third payload of the tile sort, ping-pong [0] / [1]) and the index scratch of
+                              // the per-tile depth sort ([2] / [3]).  They alias the first 16 R bytes of `partials` (dead during the forward) when
+                              // there is a backward (!no_color); a transmittance-only forward carves them
     void* sort_scratch;
     float* partials;          // [9R] per emission slot: the instance's 9 partial gradients (36-byte rows), only when !no_color
     uint8_t* dead;            // [R] per emission slot: 1 = the instance lies in a bucket behind its tile's last contributor (its partial row is
                               // NOT written and must not be read: all nine gradients are exactly zero); zeroed by finalize_ranges_kernel
     SortPlan plan;
-    uint32_t* point_list() const { return gauss[plan.passes & 1]; }
-    uint32_t* inst_slot() const { return slots[plan.passes & 1]; }
+    uint32_t* point_list() const { return gauss[(plan.passes & 1) ^ 1]; }    // (written by the per-tile depth sort)
+    uint32_t* inst_slot() const { return slots[(plan.passes & 1) ^ 1]; }
     uint32_t* sorted_tiles() const { return tile_keys[plan.passes & 1]; }
     static BinningState carve(const void* base, size_t R, int end_bit, bool no_color, size_t* bytes);
 };

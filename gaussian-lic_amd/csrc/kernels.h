@@ -13,7 +13,7 @@ struct PreprocessArgs {
     int32_t* radii;
     float4* rec;
     uint32_t* tiles_touched;
-    uint32_t* depth_keys;  // [P] depth bits, 0xffffffff when culled
+    uint32_t* depth_keys;  // optional [P] depth bits, 0xffffffff when culled (round 5: the forward no longer sorts the Gaussians by depth; NULL)
     uint2* ranges;         // [gx*gy] zeroed here (rasterizer_impl.cu:426) to save a memset launch
     uint32_t* flags;
 };
@@ -22,10 +22,11 @@ int launch_preprocess(const PreprocessArgs& a, hipStream_t s);
 struct KeybuildArgs {
     int P, gx, gy;
     const float4* rec;
-    const uint32_t* order;     // [P] Gaussian ids by ascending (depth, id)
-    const uint32_t* offsets;   // [P] inclusive scan of tiles_touched[order[i]]
+    const uint32_t* order;     // NULL (round 5): thread i emits Gaussian i; else [P] Gaussian ids in emission order
+    const uint32_t* offsets;   // [P] inclusive scan of tiles_touched in emission order
     uint32_t* tile_keys;       // [R] out: tile id per emission slot
     uint32_t* gauss;           // [R] out: Gaussian id per emission slot
+    uint32_t* depth;           // [R] out: depth bits per emission slot (sort key of the per-tile depth sort)
     uint32_t* gauss_start;     // [P] out: first emission slot of each visible Gaussian
     uint32_t cap;              // slots available in tile_keys / gauss (capacity mode; the exact R otherwise)
     uint32_t* status;          // device status words: [2] |= 1 when an instance did not fit (nothing is written past cap)

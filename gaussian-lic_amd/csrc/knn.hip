@@ -168,7 +168,7 @@ int knn_mean_dist2(int P, const float* points, float* mean_dists, gslic_alloc_fn
     GS_LAUNCH(K_KNN_MINMAX, knn_minmax_kernel, dim3(mblocks), dim3(256), 0, s, P, points, mm);
     GS_LAUNCH(K_KNN_MORTON, knn_morton_kernel, dim3(div_up(P, 256)), dim3(256), 0, s, P, points, (const float*)mm, keys[0], vals[0]);
     SortBuffers sb;
-    sb.keys[0] = keys[0]; sb.keys[1] = keys[1]; sb.v0[0] = vals[0]; sb.v0[1] = vals[1]; sb.v1[0] = sb.v1[1] = nullptr; sb.v0_identity = false;
+    sb.keys[0] = keys[0]; sb.keys[1] = keys[1]; sb.v0[0] = vals[0]; sb.v0[1] = vals[1]; sb.v1[0] = sb.v1[1] = nullptr; sb.v2[0] = sb.v2[1] = nullptr; sb.v0_identity = false;
     GS_TRY(radix_sort_u32(sb, plan, sort_scratch, false, K_SORT_HIST, K_SORT_SCATTER, s));
     const uint32_t* order = vals[plan.passes & 1];
     GS_LAUNCH(K_KNN_BOXES, knn_boxes_kernel, dim3(nb), dim3(BOX), 0, s, P, points, order, sorted, boxes);

@@ -169,13 +169,16 @@ __global__ __launch_bounds__(BS) void preprocess_kernel(PreprocessArgs a)
     const int rw = x1 - x0;
     const int ntiles = active ? rw * (y1 - y0) : 0;
     uint32_t cnt = 0;
+    uint32_t seqmask = 0;   // bit t = tile t of the rectangle (row-major) passed the test, t < SEQ_TILES: keybuild_kernel emits from it instead of testing again
     float rcpx = 0.f, rcpy = 0.f;
     if (active) tile_power_prep(cA, cC, rcpx, rcpy);
     {
         int tx = x0, ty = y0;
         const int nseq = ntiles < SEQ_TILES ? ntiles : SEQ_TILES;
         for (int t = 0; t < nseq; t++) {
-            cnt += (tile_min_power_p(cA, cB, cC, mx, my, rcpx, rcpy, tx, ty) <= thr) ? 1u : 0u;
+            const uint32_t hit = (tile_min_power_p(cA, cB, cC, mx, my, rcpx, rcpy, tx, ty) <= thr) ? 1u : 0u;
+            cnt += hit;
+            seqmask |= hit << t;
             if (++tx == x1) { tx = x0; ++ty; }
         }
     }
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(BS) void preprocess_kernel(PreprocessArgs a)
     if (idx < a.P) {
         a.radii[idx] = visible ? radius : 0;
         a.tiles_touched[idx] = visible ? cnt : 0u;
-        a.depth_keys[idx] = visible ? __float_as_uint(depth) : 0xffffffffu;  // low half of the reference's sort key (forward.cu:254)
+        if (a.depth_keys) a.depth_keys[idx] = visible ? __float_as_uint(depth) : 0xffffffffu;  // low half of the reference's sort key (forward.cu:254)
     }
     // ---- SH -> RGB (forward.cu:29-77) ----
     float rgb[3] = {0.f, 0.f, 0.f};
@@ -258,21 +261,24 @@ __global__ __launch_bounds__(BS) void preprocess_kernel(PreprocessArgs a)
     float4* rec = a.rec + GS_REC_F4 * (size_t)idx;
     rec[0] = make_float4(mx, my, cA, cB);
     rec[1] = make_float4(cC, op, rgb[0], rgb[1]);
-    rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), __int_as_float(radius));
+    rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits | (seqmask << 16)), __int_as_float(radius));   // (.z: clamp bits 0-2, tile mask 16-31)
 }
 
-// Thread i emits the instances of Gaussian g = order[i] (the i-th in ascending (depth, id) order) into the emission slots
-// u in [offsets[i-1], offsets[i]), tiles in row-major order: tile_keys[u] = tile, gauss[u] = g.  Emitting in depth order
-// makes the list "sorted by depth, ties by id" already, so a STABLE sort on the tile id alone yields exactly the order the
-// reference's 64-bit (tile << 32 | depth) sort produces (rasterizer_impl.cu:86-128, 419-424).  The slot u is also where the
-// backward writes the instance's partial gradients: contiguous per Gaussian, starting at gauss_start[g].
+// Thread i emits the instances of Gaussian g = i (index order, as duplicateWithKeys does: rasterizer_impl.cu:59-193) into the emission
+// slots u in [offsets[i-1], offsets[i]), tiles in row-major order: tile_keys[u] = tile, gauss[u] = g, depth[u] = the Gaussian's depth bits.
+// A STABLE sort on the tile id (radix_sort.hip) then groups the instances by tile, in index order inside a tile, and the per-tile depth
+// sort (tile_depth_sort_kernel, stable as well) puts every tile's segment into the order the reference's 64-bit (tile << 32 | depth) sort of
+// the same index-ordered emission produces (rasterizer_impl.cu:86-128, 419-424).  The slot u is also where the backward writes the
+// instance's partial gradients: contiguous per Gaussian, starting at gauss_start[g].
+// (Rounds 2-4 sorted the GAUSSIANS by depth first — four passes over P, a gather scan, a depth-ordered gather of the records here — and
+// emitted in that order; the per-tile sort replaces all of it: every read of this kernel is coalesced now.)
 static constexpr int KB_CAP = 1024;  // instances a wave stages in LDS (64 Gaussians x 4.3 tiles on average; larger waves store directly)
 __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
 {
     // A wave's 64 Gaussians own one contiguous range of emission slots.  Their (tile, id) pairs are staged in LDS and leave as
     // contiguous 256-byte stores: per-lane runs of ~4 four-byte stores at a stride of ~17 B were measured at 4.6x write amplification.
     __shared__ uint32_t s_tile[4][KB_CAP];
-    __shared__ uint32_t s_gid[4][KB_CAP];
+    __shared__ uint8_t s_gid[4][KB_CAP];   // owner lane of every staged instance
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -288,29 +294,32 @@ __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
     const uint32_t wcount = last >= 0 ? readlane_u(end, last) - wbase : 0u;
     const bool staged = wcount <= (uint32_t)KB_CAP;
     uint32_t* const st = s_tile[wave];
-    uint32_t* const sg = s_gid[wave];
-    const int idx = active ? (int)a.order[i] : 0;
+    uint8_t* const sg = s_gid[wave];
+    const int idx = active ? (a.order ? (int)a.order[i] : i) : 0;
     float mx = 0, my = 0, cA = 0, cB = 0, cC = 0, thr = 0;
+    uint32_t dbits = 0, seqmask = 0;
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     if (active) {
         const float4 r0 = a.rec[GS_REC_F4 * (size_t)idx], r1 = a.rec[GS_REC_F4 * (size_t)idx + 1], r2 = a.rec[GS_REC_F4 * (size_t)idx + 2];
         mx = r0.x; my = r0.y; cA = r0.z; cB = r0.w; cC = r1.x;
-        thr = cull_threshold(r1.y);
+        dbits = __float_as_uint(r2.y);   // depth (forward.cu:254: the low half of the reference's key)
+        seqmask = __float_as_uint(r2.z) >> 16;   // the preprocess kernel's test results of the rectangle's first SEQ_TILES tiles
         a.gauss_start[idx] = off;
         get_rect(mx, my, __float_as_int(r2.w) /* radius, parked in the record's spare word */, a.gx, a.gy, x0, y0, x1, y1);
+        if ((x1 - x0) * (y1 - y0) > SEQ_TILES) thr = cull_threshold(r1.y);   // (only rectangles of more than SEQ_TILES tiles are tested here)
     }
     const int rw = x1 - x0;
     const int ntiles = active ? rw * (y1 - y0) : 0;
     float rcpx = 0.f, rcpy = 0.f;
-    if (active) tile_power_prep(cA, cC, rcpx, rcpy);
+    if (active && ntiles > SEQ_TILES) tile_power_prep(cA, cC, rcpx, rcpy);
     {
         int tx = x0, ty = y0;
         const int nseq = ntiles < SEQ_TILES ? ntiles : SEQ_TILES;
         for (int t = 0; t < nseq; t++) {
-            if (tile_min_power_p(cA, cB, cC, mx, my, rcpx, rcpy, tx, ty) <= thr) {
+            if ((seqmask >> t) & 1u) {   // (the exact test of forward.cu:151-230 ran in preprocess_kernel: same rectangle, same order)
                 const uint32_t key = (uint32_t)(ty * a.gx + tx);
-                if (staged) { st[off - wbase] = key; sg[off - wbase] = (uint32_t)idx; }
-                else if (off < a.cap) { a.tile_keys[off] = key; a.gauss[off] = (uint32_t)idx; }
+                if (staged) { st[off - wbase] = key; sg[off - wbase] = (uint8_t)lane; }
+                else if (off < a.cap) { a.tile_keys[off] = key; a.gauss[off] = (uint32_t)idx; a.depth[off] = dbits; }
                 off++;
             }
             if (++tx == x1) { tx = x0; ++ty; }
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
         const float srx = readlane_f(rcpx, src), sry = readlane_f(rcpy, src);
         const int sx0 = __builtin_amdgcn_readlane(x0, src), sy0 = __builtin_amdgcn_readlane(y0, src);
         const int srw = __builtin_amdgcn_readlane(rw, src), sn = __builtin_amdgcn_readlane(ntiles, src);
-        const uint32_t sidx = (uint32_t)__builtin_amdgcn_readlane(idx, src);
+        const uint32_t sidx = (uint32_t)__builtin_amdgcn_readlane(idx, src), sdep = readlane_u(dbits, src);
         uint32_t soff = readlane_u(off, src);
         for (int base = SEQ_TILES; base < sn; base += 64) {
             const int t = base + lane;
@@ -336,8 +345,8 @@ __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
             if (ok) {
                 const uint32_t o = soff + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 const uint32_t key = (uint32_t)(ty * a.gx + tx);
-                if (staged) { st[o - wbase] = key; sg[o - wbase] = sidx; }
-                else if (o < a.cap) { a.tile_keys[o] = key; a.gauss[o] = sidx; }
+                if (staged) { st[o - wbase] = key; sg[o - wbase] = (uint8_t)src; }
+                else if (o < a.cap) { a.tile_keys[o] = key; a.gauss[o] = sidx; a.depth[o] = sdep; }
             }
             soff += (uint32_t)__popcll(m);
         }
@@ -345,10 +354,17 @@ __global__ __launch_bounds__(256) void keybuild_kernel(KeybuildArgs a)
     if (staged) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t k = (uint32_t)lane; k < wcount; k += 64u) {
-            if (wbase + k < a.cap) {
+        // the staged pairs are (tile, OWNER LANE): the owner's Gaussian id and depth bits come by a lane permute (no third staging array: LDS
+        // is this kernel's occupancy)
+        for (uint32_t k0 = 0; k0 < wcount; k0 += 64u) {
+            const uint32_t k = k0 + (uint32_t)lane;
+            const bool in = k < wcount;
+            const int owner = in ? (int)sg[k] : 0;
+            const uint32_t gid = (uint32_t)__shfl(idx, owner, 64), dep = (uint32_t)__shfl((int)dbits, owner, 64);
+            if (in && wbase + k < a.cap) {
                 a.tile_keys[wbase + k] = st[k];
-                a.gauss[wbase + k] = sg[k];
+                a.gauss[wbase + k] = gid;
+                a.depth[wbase + k] = dep;
             }
         }
     }

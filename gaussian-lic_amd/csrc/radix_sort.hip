@@ -134,9 +134,9 @@ static constexpr int OS_WINDOW = 8;
 
 struct SortPassArgs {
     const uint32_t* kin;
-    const uint32_t* vin[2];  // vin[0] == NULL: the first payload is the key's own index (first pass of an argsort)
+    const uint32_t* vin[3];  // vin[0] == NULL: the first payload is the key's own index (first pass of an argsort)
     uint32_t* kout;
-    uint32_t* vout[2];
+    uint32_t* vout[3];
     size_t n;
     const uint32_t* n_dev;       // capacity mode: the real count (<= n) on the device, NULL otherwise
     int shift;
@@ -178,7 +178,8 @@ __global__ __launch_bounds__(RS_THREADS) void sort_scatter_kernel(const SortPass
         const bool valid = idx < n;
         key[i] = valid ? a.kin[idx] : 0u;
         val[0][i] = valid ? (a.vin[0] ? a.vin[0][idx] : (uint32_t)idx) : 0u;
-        if (NV > 1) val[NV - 1][i] = valid ? a.vin[NV - 1][idx] : 0u;
+#pragma unroll
+        for (int v = 1; v < NV; v++) val[v][i] = valid ? a.vin[v][idx] : 0u;
     }
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
@@ -330,6 +331,8 @@ static int sort_impl(const SortBuffers& b, const SortPlan& plan, const uint32_t*
         a.vout[0] = b.v0[dst];
         a.vin[1] = NV > 1 ? b.v1[src] : nullptr;
         a.vout[1] = NV > 1 ? b.v1[dst] : nullptr;
+        a.vin[2] = NV > 2 ? b.v2[src] : nullptr;
+        a.vout[2] = NV > 2 ? b.v2[dst] : nullptr;
         if (onesweep) {
             a.table = gbase + p * 256; a.status = status + (size_t)p * plan.nblk * 256; a.ticket = tickets + p;
             GS_LAUNCH(id_scatter, (sort_scatter_kernel<NV, true>), dim3(nblk), dim3(RS_THREADS), 0, s, a);
@@ -345,31 +348,322 @@ static int sort_impl(const SortBuffers& b, const SortPlan& plan, const uint32_t*
     return GSLIC_OK;
 }
 
-// Runs of equal keys in a sorted (key, id) sequence re-ordered by rank[id] (launch_tie_fix).  One thread per element; the thread at the head
-// of a run (its left neighbour differs, its right neighbour is equal) owns the run: runs are disjoint, so the in-place insertion sort needs no
-// synchronisation.  Equal depth bits are rare (a few 1e4 pairs among 1e6 visible Gaussians) and runs short (2, seldom 3): the kernel is one
-// coalesced read of the keys.
-__global__ __launch_bounds__(256) void tie_fix_kernel(size_t n, const uint32_t* __restrict__ keys, uint32_t* ids, const uint32_t* __restrict__ rank,
-                                                      uint32_t skip_key)
+// ---------------------------------------------------------------------------------------------------------
+// Per-tile depth sort (TileDepthSortArgs, gslic_common.h).  One workgroup of 256 threads per tile.  The sort is an LSD radix sort on the
+// four bytes of the depth bits of (depth, local index) pairs; a pass whose digit is the same for the whole segment is skipped.  A pass
+// ranks the segment in order, LS_CHUNK = 1024 elements at a time — wave w of the chunk owns 256 contiguous elements as four 64-lane
+// items; match-any gives an element's rank among the equal digits of its item, per-wave LDS counters carry it across the wave's items,
+// thread d folds the four waves of digit d and bumps the segment's running offset of digit d — so equal digits keep their order: stable.
+// This is the path of the LONG lists (more than LW_CAP instances in a tile: tile_depth_sort_wave_kernel below does the others): keys and
+// 16-bit indices ping-pong in LDS (LDS = true: up to LS_CAP instances) or in the four global scratch arrays (LDS = false: any length).
+static constexpr int LS_THREADS = 256;
+static constexpr int LS_CHUNK = 1024;
+
+template <bool LDS>
+__device__ __forceinline__ void tile_depth_sort_body(const TileDepthSortArgs& a, const uint32_t x, const uint32_t n, uint32_t* const kL0, uint32_t* const kL1,
+                                                     uint16_t* const iL0, uint16_t* const iL1, uint32_t* const hist, uint32_t* const run,
+                                                     uint32_t (*cnt)[256], uint32_t* const red)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i + 1 >= n) return;
-    const uint32_t k = keys[i];
-    if (k == skip_key || keys[i + 1] != k || (i > 0 && keys[i - 1] == k)) return;
-    size_t j = i + 1;
-    while (j + 1 < n && keys[j + 1] == k) j++;          // run = [i, j]
-    for (size_t a = i + 1; a <= j; a++) {                // insertion sort by rank
-        const uint32_t id = ids[a], r = rank[id];
-        size_t b = a;
-        while (b > i && rank[ids[b - 1]] > r) { ids[b] = ids[b - 1]; b--; }
-        ids[b] = id;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ping-pong sides: side 0 = {kL0, iL0} or {depth, idx_a}; side 1 = {kL1, iL1} or {depth_alt, idx_b}
+    uint32_t* const kG0 = a.depth + x;
+    uint32_t* const kG1 = a.depth_alt + x;
+    uint32_t* const iG0 = a.idx_a + x;
+    uint32_t* const iG1 = a.idx_b + x;
+    auto rdk = [&](int side, uint32_t e) -> uint32_t { return LDS ? (side ? kL1[e] : kL0[e]) : (side ? kG1[e] : kG0[e]); };
+    auto rdi = [&](int side, uint32_t e) -> uint32_t { return LDS ? (uint32_t)(side ? iL1[e] : iL0[e]) : (side ? iG1[e] : iG0[e]); };
+    auto wr = [&](int side, uint32_t e, uint32_t k, uint32_t i) {
+        if (LDS) { if (side) { kL1[e] = k; iL1[e] = (uint16_t)i; } else { kL0[e] = k; iL0[e] = (uint16_t)i; } }
+        else { if (side) { kG1[e] = k; iG1[e] = i; } else { kG0[e] = k; iG0[e] = i; } }
+    };
+    for (uint32_t e = tid; e < n; e += LS_THREADS) {
+        if (LDS) { kL0[e] = a.depth[x + e]; iL0[e] = (uint16_t)e; }
+        else iG0[e] = e;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int shift = 0; shift < 32; shift += 8) {
+        // ---- digit histogram of the segment (one LDS atomic per distinct digit of a 64-lane item)
+        hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t e0 = 0; e0 < n; e0 += LS_THREADS) {
+            const uint32_t e = e0 + tid;
+            const bool valid = e < n;
+            const uint32_t d = valid ? ((rdk(cur, e) >> shift) & 0xffu) : 0u;
+            const uint64_t peers = match_digit(d, valid);
+            if (valid && popc_below(peers) == 0) atomicAdd(&hist[d], (uint32_t)__popcll(peers));
+        }
+        __syncthreads();
+        const uint32_t d_first = (rdk(cur, 0) >> shift) & 0xffu;
+        const bool uniform = hist[d_first] == n;   // (the same for every thread: LDS values behind a barrier)
+        uint32_t total;
+        const uint32_t ex = block256_exclusive_prefix(hist[tid], total, red);   // (two barriers inside)
+        if (uniform) continue;                     // every key has this digit: the pass would be the identity
+        run[tid] = ex;
+        // ---- stable scatter, LS_CHUNK elements at a time
+        for (uint32_t c0 = 0; c0 < n; c0 += LS_CHUNK) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
+            __syncthreads();
+            uint32_t rk[4], dg[4], kk[4], ii[4];
+            bool vl[4];
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const uint32_t e = c0 + (uint32_t)wave * 256u + (uint32_t)it * 64u + (uint32_t)lane;
+                vl[it] = e < n;
+                kk[it] = vl[it] ? rdk(cur, e) : 0u;
+                ii[it] = vl[it] ? rdi(cur, e) : 0u;
+                dg[it] = (kk[it] >> shift) & 0xffu;
+                const uint64_t peers = match_digit(dg[it], vl[it]);
+                const uint32_t lower = popc_below(peers);
+                uint32_t old = 0;
+                if (vl[it]) old = cnt[wave][dg[it]];
+                __builtin_amdgcn_wave_barrier();
+                if (vl[it] && lower == 0) cnt[wave][dg[it]] = old + (uint32_t)__popcll(peers);
+                __builtin_amdgcn_wave_barrier();
+                rk[it] = old + lower;
+            }
+            __syncthreads();
+            {   // thread d: where each wave's run of digit d starts in the output, and the segment's running offset behind this chunk
+                uint32_t o = run[tid];
+#pragma unroll
+                for (int w = 0; w < 4; w++) { const uint32_t c = cnt[w][tid]; cnt[w][tid] = o; o += c; }
+                run[tid] = o;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 4; it++)
+                if (vl[it]) wr(cur ^ 1, cnt[wave][dg[it]] + rk[it], kk[it], ii[it]);
+            __syncthreads();
+        }
+        cur ^= 1;
+    }
+    // ---- a map stored in a permuted row order: runs of equal depth in ascending tie_rank (= original index) instead of ascending row index
+    if (a.tie_rank) {
+        for (uint32_t j = tid; j + 1 < n; j += LS_THREADS) {
+            const uint32_t k = rdk(cur, j);
+            if (rdk(cur, j + 1) != k || (j > 0 && rdk(cur, j - 1) == k)) continue;
+            uint32_t e = j + 1;
+            while (e + 1 < n && rdk(cur, e + 1) == k) e++;          // run = [j, e]: this thread owns it (runs are disjoint)
+            for (uint32_t p = j + 1; p <= e; p++) {                    // insertion sort of the run's indices by rank
+                const uint32_t ip = rdi(cur, p), rp = a.tie_rank[a.gauss_in[x + ip]];
+                uint32_t q = p;
+                while (q > j) {
+                    const uint32_t iq = rdi(cur, q - 1);
+                    if (a.tie_rank[a.gauss_in[x + iq]] <= rp) break;
+                    wr(cur, q, k, iq);
+                    q--;
+                }
+                wr(cur, q, k, ip);
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t j = tid; j < n; j += LS_THREADS) {
+        const uint32_t src = x + rdi(cur, j);
+        a.gauss_out[x + j] = a.gauss_in[src];
+        a.slot_out[x + j] = a.slot_in[src];
     }
 }
 
-int launch_tie_fix(size_t n, const uint32_t* sorted_keys, uint32_t* ids, const uint32_t* rank, uint32_t skip_key, hipStream_t s)
+// ONE WAVE per tile for segments of up to LW_CAP instances (the common case): no workgroup barrier anywhere, and no match-any either.
+// The pairs ping-pong between two LDS buffers in a BLOCKED layout: lane l owns the E = ceil(n / 64) consecutive elements [l E, (l + 1) E) —
+// order = (lane, position in the lane's run).  A pass takes FOUR bits: every lane counts the sixteen digits of its run into its own column of a
+// 16 x 64 counter matrix (no conflicts, no atomics between lanes), the matrix is scanned in (digit, lane) order — which IS the stable order —
+// and every lane walks its run once more, taking each element's position from its column's counter.  Eight passes of ~25 instructions per
+// element and lane against four of ~70 per element and WAVE-WIDE ITEM for match-any ranking (8 ballots per item): 3x fewer instructions.
+// Element p of the sorted order lives at word phys(p) = (p / E) * (E | 1) + p % E: an odd stride per lane keeps the lanes' runs on distinct banks.
+static constexpr int LW_CAP = 1024;
+static constexpr int LW_PHYS = 64 * 17;
+#define GS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+// LDS accesses of ONE wave execute in program order, an instruction at a time for all its lanes: lane A's write is seen by lane B's later read
+// without a wait of its own.  GS_WAVE_ORDER() only keeps the COMPILER from moving accesses across it.
+#define GS_WAVE_ORDER() __builtin_amdgcn_wave_barrier()
+
+__global__ __launch_bounds__(64) void tile_depth_sort_wave_kernel(const TileDepthSortArgs a)
 {
-    if (n < 2) return GSLIC_OK;
-    GS_LAUNCH(K_TIE_FIX, tie_fix_kernel, dim3((unsigned)div_up_sz(n, 256)), dim3(256), 0, s, n, sorted_keys, ids, rank, skip_key);
+    __shared__ uint32_t sk[2][LW_PHYS];
+    __shared__ uint16_t si[2][LW_PHYS];
+    __shared__ uint32_t C[16 * 64 + 64];   // counter (digit d, lane l) = word 64 d + l of the matrix, stored at f + (f >> 4): see the scan
+    if (a.status[2] != 0u) return;   // capacity mode: the instance lists did not fit
+    const uint2 range = a.ranges[blockIdx.x];
+    const uint32_t x = range.x, n = range.y - range.x;
+    const uint32_t lane = threadIdx.x;
+    if (n > (uint32_t)LW_CAP) {   // a long list: queued for tile_depth_sort_kernel, launched behind this one
+        if (lane == 0) a.long_tiles[atomicAdd(a.status + GS_FLAG_LONG, 1u)] = blockIdx.x;
+        return;
+    }
+    if (n == 0) return;
+    if (n <= 2) {
+        if (lane == 0) {
+            bool swap = false;
+            if (n == 2) {
+                const uint32_t k0 = a.depth[x], k1 = a.depth[x + 1];
+                swap = k1 < k0 || (k1 == k0 && a.tie_rank && a.tie_rank[a.gauss_in[x + 1]] < a.tie_rank[a.gauss_in[x]]);
+            }
+            const uint32_t s0 = swap ? x + 1 : x;
+            a.gauss_out[x] = a.gauss_in[s0]; a.slot_out[x] = a.slot_in[s0];
+            if (n == 2) { const uint32_t s1 = swap ? x : x + 1; a.gauss_out[x + 1] = a.gauss_in[s1]; a.slot_out[x + 1] = a.slot_in[s1]; }
+        }
+        return;
+    }
+    const uint32_t E = (n + 63u) >> 6;     // elements per lane (1 .. 16)
+    const uint32_t Eo = E | 1u;            // odd word stride of a lane's run
+    const float rE = 1.0f / (float)E;
+    // (p + 1/2) / E is at least 1 / (2 E) >= 1/32 away from every integer: the float quotient truncates to p / E exactly for p < 2^20
+    auto phys = [&](uint32_t p) { const uint32_t q = (uint32_t)(((float)p + 0.5f) * rE); return q * Eo + (p - q * E); };
+    uint32_t krange = 0xffffffffu;   // largest key of the tile relative to its smallest (wave-uniform)
+    {   // all of the wave's global loads in flight at once (a load -> LDS store loop pays one HBM round trip per 64 elements, and there are only two
+        // or three waves per SIMD to hide it: that, not the sort, was 80 % of this kernel's first version)
+        uint32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t e = 64u * (uint32_t)j + lane;
+            v[j] = ((uint32_t)j < E && e < n) ? __builtin_nontemporal_load(a.depth + x + e) : 0u;
+        }
+        // keys relative to the tile's smallest depth (order and ties unchanged): the digits above the tile's depth RANGE are zero for every
+        // key and their passes are skipped (26-27 significant bits on the 2M / 1080p scene: seven passes instead of eight)
+        uint32_t kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t e = 64u * (uint32_t)j + lane;
+            if ((uint32_t)j < E && e < n) { kmin = v[j] < kmin ? v[j] : kmin; kmax = v[j] > kmax ? v[j] : kmax; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t a0 = (uint32_t)__shfl_xor((int)kmin, d, 64), a1 = (uint32_t)__shfl_xor((int)kmax, d, 64);
+            kmin = a0 < kmin ? a0 : kmin; kmax = a1 > kmax ? a1 : kmax;
+        }
+        krange = kmax - kmin;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t e = 64u * (uint32_t)j + lane;
+            if ((uint32_t)j < E && e < n) { const uint32_t ph = phys(e); sk[0][ph] = v[j] - kmin; si[0][ph] = (uint16_t)e; }
+        }
+    }
+    const uint32_t lo = lane * E;
+    const uint32_t mine = lo < n ? (n - lo < E ? n - lo : E) : 0u;   // elements of this lane's run
+    const uint32_t run0 = lane * Eo;
+    uint32_t* const col = C + lane + (lane >> 4);                      // this lane's counter column: col[68 d] (64 d + l + its pad words)
+    GS_WAVE_ORDER();
+    int cur = 0;
+#pragma unroll 1
+    for (int shift = 0; shift < 32; shift += 4) {
+        if ((krange >> shift) == 0u) break;   // every remaining digit of every key is zero
+        // The lane's run in registers: sixteen independent LDS reads in flight at once (a runtime loop over the run pays one LDS round trip per
+        // element and step — 36 per pass — with two waves per SIMD to hide them: measured 187 us for the 2M / 1080p scene).
+        uint32_t k[16], ix[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            k[j] = 0u; ix[j] = 0u;
+            if ((uint32_t)j < E && (uint32_t)j < mine) { k[j] = sk[cur][run0 + j]; ix[j] = si[cur][run0 + j]; }
+        }
+#pragma unroll
+        for (int d = 0; d < 16; d++) col[68 * d] = 0u;
+        GS_WAVE_ORDER();
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if ((uint32_t)j < E && (uint32_t)j < mine) atomicAdd(&col[68 * ((k[j] >> shift) & 15u)], 1u);
+        GS_WAVE_ORDER();
+        {   // exclusive scan of the matrix in (digit, lane) order: lane l takes the sixteen words [16 l, 16 l + 16).  One pad word per sixteen
+            // (word f at f + (f >> 4)) puts lane l's run at 17 l: distinct banks for the 32 lanes of a half wave — unpadded, sixteen lanes hit the same
+            // bank with every access and the scan alone kept the LDS busy for longer than the rest of the kernel (69 % conflict cycles)
+            uint32_t* const cs = C + 17 * lane;
+            uint32_t w[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) w[i] = cs[i];
+            uint32_t tot = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) { const uint32_t t = w[i]; w[i] = tot; tot += t; }
+            const uint32_t base = wave_inclusive_scan(tot) - tot;
+            GS_WAVE_ORDER();
+#pragma unroll
+            for (int i = 0; i < 16; i++) cs[i] = w[i] + base;
+        }
+        GS_WAVE_ORDER();
+        uint32_t pos[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {   // (this lane's own counters, in run order: no other lane touches them)
+            pos[j] = 0u;
+            if ((uint32_t)j < E && (uint32_t)j < mine) pos[j] = atomicAdd(&col[68 * ((k[j] >> shift) & 15u)], 1u);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if ((uint32_t)j < E && (uint32_t)j < mine) {
+                const uint32_t ph = phys(pos[j]);
+                sk[cur ^ 1][ph] = k[j];
+                si[cur ^ 1][ph] = (uint16_t)ix[j];
+            }
+        }
+        GS_WAVE_ORDER();
+        cur ^= 1;
+    }
+    GS_WAVE_SYNC();
+    if (a.tie_rank) {   // runs of equal depth in ascending tie_rank (= original index of a permuted map's row) instead of ascending row index
+        for (uint32_t j = lane; j + 1 < n; j += 64u) {
+            const uint32_t k = sk[cur][phys(j)];
+            if (sk[cur][phys(j + 1)] != k || (j > 0 && sk[cur][phys(j - 1)] == k)) continue;
+            uint32_t e = j + 1;
+            while (e + 1 < n && sk[cur][phys(e + 1)] == k) e++;      // run = [j, e]: this lane owns it (runs are disjoint)
+            for (uint32_t p = j + 1; p <= e; p++) {
+                const uint16_t ip = si[cur][phys(p)];
+                const uint32_t rp = a.tie_rank[a.gauss_in[x + ip]];
+                uint32_t q = p;
+                while (q > j) {
+                    const uint16_t iq = si[cur][phys(q - 1)];
+                    if (a.tie_rank[a.gauss_in[x + iq]] <= rp) break;
+                    si[cur][phys(q)] = iq;
+                    q--;
+                }
+                si[cur][phys(q)] = ip;
+            }
+        }
+        GS_WAVE_SYNC();
+    }
+    {   // the tile's Gaussian ids and emission slots in list order: every gather of the wave in flight before the first store
+        uint32_t g[16], sl[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t p = 64u * (uint32_t)j + lane;
+            g[j] = sl[j] = 0u;
+            if ((uint32_t)j < E && p < n) {
+                const uint32_t src = x + si[cur][phys(p)];
+                g[j] = a.gauss_in[src];
+                sl[j] = a.slot_in[src];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t p = 64u * (uint32_t)j + lane;
+            if ((uint32_t)j < E && p < n) { a.gauss_out[x + p] = g[j]; a.slot_out[x + p] = sl[j]; }
+        }
+    }
+}
+
+// Longer segments: one workgroup of 256 threads; pairs in LDS up to LS_CAP instances, in the global scratch arrays beyond.
+static constexpr int LS_CAP = 4096;
+__global__ __launch_bounds__(LS_THREADS) void tile_depth_sort_kernel(const TileDepthSortArgs a)
+{
+    __shared__ uint32_t kL0[LS_CAP], kL1[LS_CAP];
+    __shared__ uint16_t iL0[LS_CAP], iL1[LS_CAP];
+    __shared__ uint32_t hist[256], run[256], cnt[4][256], red[8];
+    if (a.status[2] != 0u) return;   // capacity mode: the instance lists did not fit
+    const uint32_t n_long = a.status[GS_FLAG_LONG];   // (the queue's order depends on the run; what is written for a tile does not)
+    for (uint32_t q = blockIdx.x; q < n_long; q += gridDim.x) {
+        const uint2 range = a.ranges[a.long_tiles[q]];
+        const uint32_t x = range.x, n = range.y - range.x;
+        if (n <= (uint32_t)LS_CAP) tile_depth_sort_body<true>(a, x, n, kL0, kL1, iL0, iL1, hist, run, cnt, red);
+        else tile_depth_sort_body<false>(a, x, n, kL0, kL1, iL0, iL1, hist, run, cnt, red);
+        __syncthreads();
+    }
+}
+
+int launch_tile_depth_sort(const TileDepthSortArgs& a, hipStream_t s)
+{
+    if (a.T <= 0) return GSLIC_OK;
+    GS_LAUNCH(K_TILE_LSORT, tile_depth_sort_wave_kernel, dim3((unsigned)a.T), dim3(64), 0, s, a);
+    // a fixed grid walks the queue of long lists (usually empty: its workgroups read one word and leave)
+    GS_LAUNCH(K_TILE_LSORT, tile_depth_sort_kernel, dim3((unsigned)(a.T < 512 ? a.T : 512)), dim3(LS_THREADS), 0, s, a);
     return GSLIC_OK;
 }
 
@@ -378,6 +672,7 @@ int radix_sort_u32(const SortBuffers& b, const SortPlan& plan, void* scratch, bo
 {
     if (plan.n == 0) return GSLIC_OK;
     if (plan.n > 0xffffffffull) return set_error(GSLIC_ERR_INVALID_ARG, "radix sort: more than 2^32 elements");
+    if (b.v1[0] && b.v2[0]) return sort_impl<3>(b, plan, n_dev, scratch, onesweep, id_hist, id_scatter, s, fault);
     return b.v1[0] ? sort_impl<2>(b, plan, n_dev, scratch, onesweep, id_hist, id_scatter, s, fault)
                    : sort_impl<1>(b, plan, n_dev, scratch, onesweep, id_hist, id_scatter, s, fault);
 }
