@@ -49,14 +49,12 @@ def algorithmic_bytes(kernel, s):
     table = {
         # in: xyz 12 + scale 12 + rot 16 + opacity 4 per P; out: radii 4 + tiles 4 per P; per visible: SH 12K in, 48 B record out
         "preprocess": 52 * P + V * (12 * K + 48),
-        # depth sort of the Gaussians: 4-byte key (+ 4-byte id after the first pass) per pass
-        "dsort_hist": 4 * P,
-        "dsort_scatter": 16 * P,
-        "depth_gather": 12 * P,
-        # per Gaussian: order 4 + radius 4; per visible: record 32 + offset 4 in, start 4 out; per instance: tile 4 + gaussian id 4 out
-        "keybuild": 8 * P + 52 * V + 8 * R,
+        # per Gaussian: offset 4; per visible: record 48 in, start 4 out; per instance: tile 4 + gaussian id 4 + depth bits 4 out
+        "keybuild": 4 * P + 52 * V + 12 * R,
         "sort_hist": 4 * R,                       # tile keys once per pass
-        "sort_scatter": 24 * R,                   # key + slot + gaussian id in and out, per pass (the first pass reads no slot: 20)
+        "sort_scatter": 32 * R,                   # key + slot + gaussian id + depth bits in and out, per pass (the first pass reads no slot: 28)
+        # per-tile depth sort: depth 4 + gaussian id 4 + slot 4 in, gaussian id 4 + slot 4 out per instance; ranges 8 per tile
+        "tile_lsort": 20 * R + 8 * T,
         "finalize_lists": 4 * R + 8 * T,          # sorted tile ids in, ranges out
         # list 4 + record 48 per instance of a live bucket; checkpoints 4096 (+ decision masks) per live bucket; pix_final 16/px(padded), image 16/px
         "render_fwd": 52 * Rl + (4096 + hb) * Bl + 16 * Np + 16 * N,

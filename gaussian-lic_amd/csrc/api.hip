@@ -88,16 +88,11 @@ GeomState GeomState::carve(const void* base, size_t P, size_t* bytes)
 {
     Carver c(base);
     GeomState g;
-    g.plan = sort_plan(P, 32);
     g.rec = c.take<float4>(GS_REC_F4 * P);
     g.tiles_touched = c.take<uint32_t>(P);
-    g.depth_keys[0] = c.take<uint32_t>(P);
-    g.depth_keys[1] = c.take<uint32_t>(P);
-    g.order[0] = c.take<uint32_t>(P);
-    g.order[1] = c.take<uint32_t>(P);
+    g.cam_scratch = c.take<float>(128 * ((P + 255) / 256) + 64);   // 32 floats per wave of 4 ceil(P / 256) waves + the 35 results (rounds 2-4 kept the Gaussians' depth-sort arrays here: 16 P bytes)
     g.point_offsets = c.take<uint32_t>(P);
     g.gauss_start = c.take<uint32_t>(P);
-    g.sort_scratch = c.take<char>(sort_scratch_bytes(g.plan));
     g.flags = c.take<uint32_t>(64);  // 256 B, so that scan_state follows directly
     g.scan_state = c.take<char>(scan_state_bytes(P));
     g.zero_bytes = 64 * sizeof(uint32_t) + scan_state_bytes(P);
@@ -607,11 +602,10 @@ static int rasterize_backward_impl(const gslic_raster_params* prm, int32_t R, in
     pb.cam_partials = nullptr; pb.cam_out = nullptr;
     pb.vis_out = vis_out; pb.campos_out = campos_out;
     if (dL_dcam) {
-        // scratch: the depth-sort ping-pong arrays of the geometry buffer are dead after the forward.  The per-wave partial rows
-        // (128 B per wave; the generic 256-thread path writes 4 rows per block even when P < 256, i.e. up to 512 * ceil(P / 256) B)
-        // take the two key arrays, which are contiguous and hold max(512, 8 P) bytes; the 35 reduced terms go behind them
-        pb.cam_partials = reinterpret_cast<float*>(geom.depth_keys[0]);
-        pb.cam_out = reinterpret_cast<float*>(geom.order[0]);
+        // scratch of the geometry buffer: the per-wave partial rows (128 B per wave; the generic 256-thread path writes 4 rows per block even
+        // when P < 256, i.e. up to 4 ceil(P / 256) rows), the 35 reduced terms behind them
+        pb.cam_partials = geom.cam_scratch;
+        pb.cam_out = geom.cam_scratch + 128 * (((size_t)P + 255) / 256);
     }
     GS_TRY(launch_preprocess_bwd(pb, s));
     if (dL_dcam) {

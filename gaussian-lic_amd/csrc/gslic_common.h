@@ -181,17 +181,14 @@ int launch_tile_depth_sort(const TileDepthSortArgs& a, hipStream_t s);
 
 // opaque scratch layouts ----------------------------------------------------------------------------------
 struct GeomState {
-    float4* rec;             // [3P] per Gaussian: {mx,my,conic.x,conic.y} {conic.z,opacity,r,g} {b,depth,clamped-bits,radius}
+    float4* rec;             // [3P] per Gaussian: {mx,my,conic.x,conic.y} {conic.z,opacity,r,g} {b,depth,clamp bits 0-2 | tile-test mask 16-31,radius}
     uint32_t* tiles_touched; // [P]
-    uint32_t* depth_keys[2]; // [P] ping-pong: depth bits (0xffffffff when culled)
-    uint32_t* order[2];      // [P] ping-pong: Gaussian ids; after the depth sort order[0] = ids by ascending (depth, id)
-    uint32_t* point_offsets; // [P] inclusive scan of tiles_touched in DEPTH order: emission slots of order[0][i] end here
+    float* cam_scratch;      // [128 ceil(P / 256) + 64] the camera-gradient backward's per-wave partial rows and its 35 results (gslic_rasterize_backward_camera)
+    uint32_t* point_offsets; // [P] inclusive scan of tiles_touched in index order: the emission slots of Gaussian i end here
     uint32_t* gauss_start;   // [P] first emission slot of Gaussian g (written for visible Gaussians only)
-    void* sort_scratch;
     uint32_t* flags;         // [64] device-side status words ([0] = prefiltered violation), zeroed together with scan_state
     void* scan_state;        // chained-scan state of the emission-slot scan (directly behind flags)
     size_t zero_bytes;       // flags + scan_state
-    SortPlan plan;
     static GeomState carve(const void* base, size_t P, size_t* bytes);
 };
 struct ImageState {
