@@ -341,7 +341,7 @@ def main():
     _lib.profile_enable(False)
     dominant = max(breakdown, key=lambda k: breakdown[k][0]) if breakdown else "render_bwd"
     if args.graph:   # the timed region replays the captured step; per-kernel HIP events cannot be recorded inside a replay
-        graphed["gs"] = trainer.GraphedStep(model, cam, gt, bg, check_every=0)
+        graphed["gs"] = trainer.GraphedStep(model, cam, gt, bg, check_every=0, use_graph=True)
         for _ in range(3):
             step()
 
@@ -645,7 +645,7 @@ def main():
             if "error" in legs:
                 out["secondary_legs"] = legs["error"]
             out.update({k: v for k, v in legs.items() if k in ("views_cycle", "math_modes", "other_host_path", "graphed", "cpp_fused_host", "joint_pose_step", "insertion_order",
-                                                                "reference_step_in_this_process")})
+                                                                "reference_step_in_this_process", "capacity_eager")})
     print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
@@ -793,12 +793,19 @@ def secondary_legs(args, dev):
     # the same step as ONE hipGraph replay: capacity-mode forward (no host round trip), loss, backward + Adam
     _trace("extras: graphed")
     try:
-        gs = trainer.GraphedStep(model, cam, gt, bg, check_every=0)
+        gs = trainer.GraphedStep(model, cam, gt, bg, check_every=0, use_graph=True)
         sec = timed_loop(gs.step, n_extra)
         repeated = gs.check()
         out["graphed"] = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra,
                           "host_round_trips_per_step": 0, "steps_repeated_for_capacity": repeated, "capacity_R": gs.bufs.cap_R, "capacity_B": gs.bufs.cap_B}
         del gs
+        # ... and the same capacity-mode step as eager launches (no graph, no host round trip)
+        ge = trainer.GraphedStep(model, cam, gt, bg, check_every=16, use_graph=False)
+        sec = timed_loop(ge.step, n_extra)
+        repeated = ge.check()
+        out["capacity_eager"] = {"value": round(n_extra / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / n_extra, 3), "steps": n_extra,
+                                 "host_round_trips_per_step": 0, "overflow_check_every": 16, "steps_repeated_for_capacity": repeated}
+        del ge
     except Exception as ex:
         out["graphed"] = {"error": str(ex)[:200]}
     # joint map + camera-pose iteration (the "cam" of the north-star): parameter gradients and the camera gradient from ONE backward

@@ -661,9 +661,16 @@ class GraphedStep:
     replaced while steps were issued with gt_image=None, makes the repeat fail loudly instead of training on the wrong data), after the
     ones that did.  extend() changes P: build a new GraphedStep afterwards."""
 
-    def __init__(self, model, camera, gt_image, bg, headroom=1.25, check_every=16, cap_R=None, cap_B=None):
+    def __init__(self, model, camera, gt_image, bg, headroom=1.25, check_every=16, cap_R=None, cap_B=None, use_graph=False):
+        """use_graph=False (default since round 5): the capacity-mode step (caller-owned scratch, no host round trip, overflow checks and repeats as
+        below) issued as eager launches; use_graph=True: captured in a hipGraph and replayed with one launch per step.  The two are equally fast at
+        2M Gaussians (bench.py: `capacity_eager` / `graphed`; the host runs ahead of the device either way), and the eager form has no hazard:
+        on ROCm 7.2 a replay FAULTS (GPU memory access fault) when the host has called torch.cuda.synchronize() and then enqueued ANY other device
+        work — a copy, a fill — before it (tools/experiments/graph_check_repro.py, modes B / C / E; a synchronise alone, or a blocking .cpu() copy
+        alone, is harmless: modes A / D / F).  A host that uses the graph must keep its own device work off that pattern."""
         from . import rasterizer as rz
         assert not _dist_on(), "GraphedStep is the single-GPU path"
+        self.use_graph = bool(use_graph)
         self.model, self.bg, self.headroom, self.check_every = model, bg, float(headroom), int(check_every)
         dev = model.device
         self.H, self.W = int(camera.image_height), int(camera.image_width)
@@ -723,10 +730,12 @@ class GraphedStep:
             self._eager()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g), torch.no_grad():
-            self._eager()
-        torch.cuda.synchronize()
+        g = None
+        if self.use_graph:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g), torch.no_grad():
+                self._eager()
+            torch.cuda.synchronize()
         for n, (p, m1, m2) in zip(names, saved):
             self.model._buf[n][:self.model.P].copy_(p); self.model._m[n][:self.model.P].copy_(m1); self.model._v[n][:self.model.P].copy_(m2)
         self.bufs.status.zero_()
@@ -780,10 +789,17 @@ class GraphedStep:
                 self.gt.copy_(gt)
                 self._gt_serial = getattr(self, "_gt_serial", 0) + 1
 
+    def _issue(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            with torch.no_grad():
+                self._eager()
+
     def step(self, camera=None, gt_image=None):
         """One optimiser step (replay).  Returns the device tensor [mean L1, mean SSIM] of this step's loss terms."""
         self._load(camera, gt_image)
-        self.graph.replay()
+        self._issue()
         self.steps_issued += 1
         if len(self.window) < 32:
             self.window.append(self._snapshot(gt_image))
@@ -814,7 +830,7 @@ class GraphedStep:
             self._capture()                     # (zeroes the status words, empties the window)
             for snap in todo:
                 self._load_snapshot(snap)
-                self.graph.replay()
+                self._issue()
                 self.steps_issued += 1
                 self.window.append(snap)
             repeated += len(todo)

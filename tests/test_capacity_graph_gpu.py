@@ -74,7 +74,8 @@ def test_capacity_overflow_turns_the_step_into_a_noop():
             assert bool((t == 7.0).all()), f"{k} was written although the forward had overflowed"
 
 
-def test_graphed_step_equals_eager_steps():
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_graphed_step_equals_eager_steps(use_graph):
     import gaussian_lic_amd  # noqa: F401
     from gaussian_lic_amd import trainer
     from gaussian_lic_amd.synthetic import gt_image
@@ -94,7 +95,7 @@ def test_graphed_step_equals_eager_steps():
         terms_e, _vis = trainer.training_step_fused(eager, cam, gt, bg)
     for headroom, expect_recapture in ((1.25, False), (0.9, True)):   # 0.9: the first capture is too small on purpose
         model = fresh()
-        gs = trainer.GraphedStep(model, cam, gt, bg, headroom=headroom, check_every=5)
+        gs = trainer.GraphedStep(model, cam, gt, bg, headroom=headroom, check_every=5, use_graph=use_graph)
         if expect_recapture:
             gs.cap_R, gs.cap_B = int(gs.cap_R * 0.5), int(gs.cap_B * 0.5)
             gs._capture()
@@ -108,7 +109,8 @@ def test_graphed_step_equals_eager_steps():
         assert torch.equal(terms_g, terms_e)
 
 
-def test_graphed_step_repeats_overflowed_steps_with_their_own_views():
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_graphed_step_repeats_overflowed_steps_with_their_own_views(use_graph):
     """A different camera and target every step, capacity buffers sized so that SOME views overflow: every view must be trained exactly
     once — the views that fitted in issue order, then the ones that did not (each with ITS camera and ground truth, not the last one's)
     — i.e. the parameters equal an eager run over that order bit for bit.  Also: the status words report the did-not-fit steps."""
@@ -144,7 +146,7 @@ def test_graphed_step_repeats_overflowed_steps_with_their_own_views():
     assert any(fits) and not all(fits)
     model = fresh()
     first_fit = fits.index(True)
-    gs = trainer.GraphedStep(model, cams[first_fit], gts[first_fit], bg, check_every=0, cap_R=cap_R)
+    gs = trainer.GraphedStep(model, cams[first_fit], gts[first_fit], bg, check_every=0, cap_R=cap_R, use_graph=use_graph)
     order = list(range(8))
     for k in order:
         gs.step(cams[k], gts[k])
@@ -195,7 +197,7 @@ def test_graphed_step_repeats_with_the_pose_of_the_step_when_one_camera_object_m
     assert any(fits) and not all(fits)
     moving = synthetic_camera(W, H, fits.index(True)).to_device(dev)       # the one object the host moves around
     model = fresh()
-    gs = trainer.GraphedStep(model, moving, gts[fits.index(True)], bg, check_every=0, cap_R=cap_R)
+    gs = trainer.GraphedStep(model, moving, gts[fits.index(True)], bg, check_every=0, cap_R=cap_R, use_graph=True)
     for k in range(6):
         moving.set_pose(poses[k].R_wc, poses[k].t_wc)
         moving.to_device(dev)
@@ -212,7 +214,7 @@ def test_graphed_step_repeats_with_the_pose_of_the_step_when_one_camera_object_m
         assert torch.equal(getattr(model, n).detach(), getattr(eager, n).detach()), n
     # a target modified in place after its step was issued: the repeat refuses
     model2 = fresh()
-    gs2 = trainer.GraphedStep(model2, poses[fits.index(True)], gts[fits.index(True)], bg, check_every=0, cap_R=cap_R)
+    gs2 = trainer.GraphedStep(model2, poses[fits.index(True)], gts[fits.index(True)], bg, check_every=0, cap_R=cap_R, use_graph=True)
     k_bad = fits.index(False)
     staging = gts[k_bad].clone()
     gs2.step(poses[k_bad], staging)

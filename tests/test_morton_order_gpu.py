@@ -91,7 +91,7 @@ def test_morton_model_graphed_step_and_extend_and_save_map(tmp_path):
     a, b = _models(raw, dev, capacity=2 * P)
     cam = synthetic_camera(W, H).to_device(dev)
     gt, bg = gt_image(H, W).to(dev), torch.zeros(3, device=dev)
-    ga, gb = trainer.GraphedStep(a, cam, gt, bg, check_every=0), trainer.GraphedStep(b, cam, gt, bg, check_every=0)
+    ga, gb = trainer.GraphedStep(a, cam, gt, bg, check_every=0, use_graph=True), trainer.GraphedStep(b, cam, gt, bg, check_every=0, use_graph=True)
     for _ in range(3):
         ga.step(); gb.step()
     assert ga.check() == 0 and gb.check() == 0
