@@ -217,6 +217,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    json_out = sys.stdout
+    if world > 1 or os.environ.get("GSLIC_FORCE_DIST") == "1":
+        # ONE JSON line on stdout is the contract, and the collective libraries talk on stdout from C++ (gloo: "[Gloo] Rank 1 is connected to ..."):
+        # keep the real stdout for the line, send everything else that is written to file descriptor 1 to stderr
+        json_out = os.fdopen(os.dup(1), "w")
+        sys.stdout.flush()
+        os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run (or let bench.py spawn the ranks: unset WORLD_SIZE)"
     ndev = torch.cuda.device_count()
@@ -646,7 +653,7 @@ def main():
                 out["secondary_legs"] = legs["error"]
             out.update({k: v for k, v in legs.items() if k in ("views_cycle", "math_modes", "other_host_path", "graphed", "cpp_fused_host", "joint_pose_step", "insertion_order",
                                                                 "reference_step_in_this_process", "capacity_eager")})
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out), file=json_out, flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

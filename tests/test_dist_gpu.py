@@ -90,9 +90,8 @@ def test_bench_gpus_2_launches_itself():
            "--width", "640", "--height", "360", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    assert r.stdout.count("\n") == 1 and r.stdout.startswith("{"), "stdout must hold the ONE JSON line and nothing else: " + r.stdout[:400]
+    d = json.loads(r.stdout)
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["launch"]["ranks"] == 2 and d["launch"]["ranks_reached_by_all_reduce"] == 2 and d["launch"]["self_launched"] is True
     assert len(d["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in d["per_rank_ms_per_step"])
