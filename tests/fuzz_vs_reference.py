@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Ad-hoc fuzz (not collected by pytest): random small scenes, HIP path vs the reference's own kernels, strict and fast arithmetic.
-    python tests/fuzz_vs_reference.py [n_cases] [seed0]
+    python tests/fuzz_vs_reference.py [n_cases] [seed0] [only]
+    python tests/fuzz_vs_reference.py --poses [n_cases] [seed0]     # round 5: every scene at a random SE(3) pose (some with a scale_modifier / extent scale)
 Prints one line per case and a summary; exits non-zero when a strict run is not bit-identical (radii / tile counts / lists / image /
 final_T / n_contrib) or a gradient element is beyond 1e-4.  Test infrastructure (uses oracle/_ref); needs the MI355X."""
 import os
@@ -11,7 +12,35 @@ sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
 import numpy as np
 
 
+def main_poses(argv):
+    """The generator of tests/test_pose_reference_gpu.py (fuzz_cases) with more cases: the strict bars, plus the conditioning probe's verdict on any
+    gradient element beyond 1e-4."""
+    n = int(argv[0]) if argv else 200
+    seed0 = int(argv[1]) if len(argv) > 1 else 555
+    from refcompare import GRADS, compare
+    from test_pose_reference_gpu import fuzz_cases
+    bad = 0
+    over_ill = 0
+    for i, (kind, P, W, H, deg, seed, view, sigma_scale, scale_modifier) in enumerate(fuzz_cases(n, seed0)):
+        res = compare(kind, P, W, H, deg, seed, view=view, sigma_scale=sigma_scale, scale_modifier=scale_modifier)
+        st = res["strict"]
+        exact = (st["radii_mismatch"] == 0 and st["tiles_touched_mismatch"] == 0 and st["point_list_equal"] and st["color"]["bit_equal"] and
+                 st["final_T"]["bit_equal"] and st["n_contrib_mismatch"] == 0 and all(st[k + "_bit_equal"] for k in ("means2D", "depths", "conic_opacity", "rgb")))
+        over = sum(st[k]["over"] for k in GRADS)
+        ill = sum(st[k].get("over_ill_conditioned", 0) for k in GRADS)
+        ok = exact and over == ill
+        over_ill += ill
+        print(f"{i:3d} {kind:6s} P={P:6d} {W}x{H} deg{deg} ypr={view['ypr']} place={view['place']} mod={scale_modifier} sigma={sigma_scale}: R={res['ref']['R']} "
+              f"clamp-masked={res['ref']['clamp_masked_visible']} strict {'OK' if ok else 'MISMATCH'} (max grad err {max(st[k]['max_rel'] for k in GRADS):.1e}"
+              + (f"; {over} element(s) over 1e-4, {ill} of them ill-conditioned in fp32" if over else "") + ")", flush=True)
+        bad += 0 if ok else 1
+    print(f"{n} posed cases, {bad} strict mismatches, {over_ill} gradient elements over 1e-4 that fp32 cannot resolve (conditioning probe)")
+    sys.exit(1 if bad else 0)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--poses":
+        return main_poses(sys.argv[2:])
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     only = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # run just this case of the sequence

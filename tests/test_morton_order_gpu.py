@@ -10,9 +10,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _scene(P, W, H, seed, quantum=0.5):
+def _scene(P, W, H, seed, quantum=0.5, sigma=1.0):
+    import math
     from gaussian_lic_amd.synthetic import random_scene
     raw = random_scene(P, W, H, sh_degree=3, seed=seed)
+    if sigma != 1.0:   # larger Gaussians: longer per-tile lists (the per-tile depth sort's long-list paths: LDS workgroup kernel, global scratch)
+        raw["scaling"] = (raw["scaling"] + math.log(sigma)).contiguous()
     z = raw["xyz"][:, 2]
     zq = torch.where(z > 0.3, (z / quantum).round().clamp_min(1.0) * quantum, z)   # identity camera: depth = z -> many exact depth ties
     raw["xyz"] = torch.stack([raw["xyz"][:, 0] * zq / z, raw["xyz"][:, 1] * zq / z, zq], 1).contiguous()
@@ -45,16 +48,25 @@ def test_morton_order_is_a_nontrivial_permutation_with_ties_in_the_scene():
     assert (z > 0.3).sum() - torch.unique(z[z > 0.3]).numel() > 20000     # (the depths tie)
 
 
-@pytest.mark.parametrize("P,W,H,seed", [(30000, 320, 192, 5), (200192, 960, 540, 6)])
-def test_morton_model_renders_and_trains_bit_identically(P, W, H, seed):
+@pytest.mark.parametrize("P,W,H,seed,sigma", [(30000, 320, 192, 5, 1.0), (200192, 960, 540, 6, 1.0), (60000, 160, 96, 7, 3.0)])
+def test_morton_model_renders_and_trains_bit_identically(P, W, H, seed, sigma):
     from gaussian_lic_amd import trainer
     from gaussian_lic_amd.camera import synthetic_camera
     from gaussian_lic_amd.rasterizer import render
     from gaussian_lic_amd.synthetic import gt_image
     dev = torch.device("cuda:0")
-    a, b = _models(_scene(P, W, H, seed), dev)
+    a, b = _models(_scene(P, W, H, seed, sigma=sigma), dev)
     cam = synthetic_camera(W, H).to_device(dev)
     gt, bg = gt_image(H, W).to(dev), torch.zeros(3, device=dev)
+    if sigma != 1.0:   # (the case is there for its long lists: 60 tiles, thousands of instances each — beyond what one wave and what LDS sorts)
+        from gaussian_lic_amd import rasterizer as rz
+        e = torch.empty(0, device=dev)
+        with torch.no_grad():
+            R = rz.rasterize_gaussians(bg, a.xyz.detach(), e, a.opacity.detach(), a.scaling.detach(), a.rotation.detach(), 1.0, e, cam.d_world_view_transform,
+                                       cam.d_full_proj_transform, float(cam.tanfovx), float(cam.tanfovy), H, W, float(cam.limx_neg), float(cam.limx_pos),
+                                       float(cam.limy_neg), float(cam.limy_pos), a.features_dc.detach(), a.features_rest.detach(), 3, cam.d_camera_center,
+                                       False, False, False, raw_params=True)[0]
+        assert R > 4096 * 1.5 * ((W + 15) // 16) * ((H + 15) // 16), R
     with torch.no_grad():
         ia, Ta, _, va, ra = render(cam, a, bg)
         ib, Tb, _, vb, rb = render(cam, b, bg)
