@@ -30,7 +30,7 @@ class AdamGroup(ctypes.Structure):
 
 class AdamFused(ctypes.Structure):
     _fields_ = [("param", ctypes.c_void_p * 6), ("exp_avg", ctypes.c_void_p * 6), ("exp_avg_sq", ctypes.c_void_p * 6),
-                ("lr", ctypes.c_float * 6), ("b1", ctypes.c_float), ("b2", ctypes.c_float), ("eps", ctypes.c_float)]
+                ("lr", ctypes.c_float * 6), ("b1", ctypes.c_float), ("b2", ctypes.c_float), ("eps", ctypes.c_float), ("visible_out", ctypes.c_void_p)]
 
 
 EXPORTS = [

@@ -756,7 +756,7 @@ int gslic_rasterize_backward_adam(const gslic_raster_params* prm, int32_t R, int
     return rasterize_backward_impl(prm, R, B, background, means3D, dc, shs, colors_precomp, scales, rotations, cov3D_precomp, viewmatrix,
                                    projmatrix, cam_pos, radii, geom_buffer, binning_buffer, img_buffer, sample_buffer, dL_dpix, nullptr,
                                    nullptr, dL_dopacity, nullptr, dL_dmean3D, nullptr, dL_ddc, dL_dsh, dL_dscale, dL_drot, lambda_erank,
-                                   adam, nullptr, stream);
+                                   adam, nullptr, stream, nullptr, 0, -1, false, adam->visible_out);
 }
 
 int gslic_rasterize_backward_camera(const gslic_raster_params* prm, int32_t R, int32_t B, const float* background, const float* means3D,

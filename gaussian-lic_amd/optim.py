@@ -83,9 +83,11 @@ class SparseGaussianAdam:
         _lib.check(_lib.lib().gslic_adam_update_groups(arr, len(groups), ctypes.c_void_p(vis.data_ptr() + p0), self.betas[0], self.betas[1], self.eps,
                                                        p1 - p0, _lib.current_stream_ptr()))
 
-    def fused_descriptor(self):
-        """gslic_adam_fused for gslic_rasterize_backward_adam: the six groups' parameters and moments, learning rates, betas, eps."""
+    def fused_descriptor(self, visible_out=None):
+        """gslic_adam_fused for gslic_rasterize_backward_adam: the six groups' parameters and moments, learning rates, betas, eps.
+        visible_out: optional uint8 [P] device tensor the backward also fills with `radii > 0` (kept alive by the caller)."""
         d = _lib.AdamFused()
+        d.visible_out = None if visible_out is None else visible_out.data_ptr()
         for i, prm in enumerate(self.params):
             st = self._ensure_state(i)
             d.param[i] = prm.data_ptr() if prm.numel() else None

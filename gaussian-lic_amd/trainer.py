@@ -571,13 +571,14 @@ def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=Tr
         if do_step and adam_in_backward and not _dist_on():
             # single GPU: nothing to exchange, so the Adam update runs inside the per-Gaussian backward kernel while the
             # gradients are still in registers / LDS (bit-identical to backward + SparseGaussianAdam.step, ~2 GB less HBM traffic)
+            vis_u8 = torch.empty(model.P, dtype=torch.uint8, device=dev)
             rz.rasterize_gaussians_backward(
                 bg, xyz, radii, e, sc, rot, 1.0, e, cam.d_world_view_transform, cam.d_full_proj_transform, float(cam.tanfovx),
                 float(cam.tanfovy), float(cam.limx_neg), float(cam.limx_pos), float(cam.limy_neg), float(cam.limy_pos), dL_dimage, dc, rest,
                 model.sh_degree, cam.d_camera_center, geom, R, binning, img, B, sample, model.lambda_erank, False, raw_params=True,
-                adam=model.optimizer.fused_descriptor())
+                adam=model.optimizer.fused_descriptor(visible_out=vis_u8))
             model.optimizer.count_step()
-            return terms, radii > 0
+            return terms, vis_u8.view(torch.bool)   # `radii > 0` (renderer.cpp:85), written by the backward kernel: no compare launch
         slab = getattr(model, "_grad_slab", None)
         if slab is None or slab.P != model.P:
             slab = model._grad_slab = GradSlab(model)

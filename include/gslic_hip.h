@@ -220,6 +220,9 @@ typedef struct gslic_adam_fused {
     float* exp_avg_sq[6];
     float lr[6];
     float b1, b2, eps;
+    uint8_t* visible_out;   /* optional (ABI 7) DEVICE [P]: gslic_rasterize_backward_adam also writes 1 = radii > 0 per Gaussian — the `visible` mask
+                               of renderer.cpp:85 that the host reads for its statistics — so that no compare kernel has to be launched for it;
+                               ignored by the other entry points that take this descriptor */
 } gslic_adam_fused;
 int gslic_rasterize_backward_adam(
     const gslic_raster_params* prm, int32_t R, int32_t B,

@@ -120,6 +120,13 @@ def test_extreme_parameters_do_not_poison_training():
     assert bool(torch.isfinite(terms).all()) and int(vis.sum()) > 0
     for n in ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation"):
         assert bool(torch.isfinite(getattr(model, n)).all()), n
+    # the visible mask of the fused step is written by the backward kernel (gslic_adam_fused.visible_out): it is `radii > 0` of that step's forward,
+    # what the split path (Adam as its own launch) computes with a compare
+    from gaussian_lic_amd.rasterizer import render
+    with torch.no_grad():
+        vis_before = render(cam, model, bg)[3].clone()
+    _t, vis_fused = trainer.training_step_fused(model, cam, gt, bg)
+    assert vis_fused.dtype == torch.bool and torch.equal(vis_fused, vis_before)
 
 
 def test_dropin_renderer_matches_the_operator_path():

@@ -27,7 +27,7 @@ mark("warm")
 which = os.environ.get("PROBE_WHICH", "ceg")
 res = {}
 if "e" in which:
-    ge = trainer.GraphedStep(model, cam, gt, bg, check_every=int(os.environ.get("PROBE_CHECK", "16")), use_graph=False); mark("ge built")
+    ge = trainer.GraphedStep(model, cam, gt, bg, check_every=int(os.environ.get("PROBE_CHECK", "16")), use_graph=False, headroom=float(os.environ.get("PROBE_HEADROOM", "1.25"))); mark("ge built")
 if "g" in which:
     gg = trainer.GraphedStep(model, cam, gt, bg, check_every=int(os.environ.get("PROBE_CHECK", "16")), use_graph=True); mark("gg built")
 for r in range(2):
