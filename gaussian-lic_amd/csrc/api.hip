@@ -258,6 +258,7 @@ int ssim_backward(int, int, int, int, const float*, const float*, const float*, 
 int knn_mean_dist2(int, const float*, float*, gslic_alloc_fn, void*, hipStream_t);
 int loss_forward(int, int, int, int, float, float, const float*, const float*, float*, float*, float*, float*, float*, hipStream_t);
 int loss_backward(int, int, int, int, float, const float*, const float*, const float*, const float*, const float*, float*, hipStream_t);
+int loss_forward_backward(int, int, int, int, float, float, float, const float*, const float*, float*, float*, float*, float*, float*, float*, hipStream_t);
 int64_t loss_partials_count(int, int, int, int);
 int extend_select(int, const float*, const float*, const float*, const float*, float, float, float, float, int, int, const float*,
                   gslic_alloc_fn, void*, uint32_t**, uint32_t**, int32_t*, hipStream_t);
@@ -853,6 +854,17 @@ int gslic_l1_ssim_loss_backward(int32_t B, int32_t CH, int32_t H, int32_t W, flo
     if (B <= 0 || CH <= 0 || H <= 0 || W <= 0) return set_error(GSLIC_ERR_INVALID_ARG, "loss: empty image");
     if (!img || !gt || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg) return set_error(GSLIC_ERR_INVALID_ARG, "loss backward: NULL pointer");
     return loss_backward(B, CH, H, W, lambda_dssim, img, gt, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg, (hipStream_t)stream);
+}
+
+int gslic_l1_ssim_loss_forward_backward(int32_t B, int32_t CH, int32_t H, int32_t W, float C1, float C2, float lambda_dssim, const float* img,
+                                        const float* gt, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, float* partials, float* terms,
+                                        float* dL_dimg, void* stream)
+{
+    if (B <= 0 || CH <= 0 || H <= 0 || W <= 0) return set_error(GSLIC_ERR_INVALID_ARG, "loss: empty image");
+    if (!img || !gt || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !partials || !terms || !dL_dimg)
+        return set_error(GSLIC_ERR_INVALID_ARG, "loss forward_backward: NULL pointer");
+    return loss_forward_backward(B, CH, H, W, C1, C2, lambda_dssim, img, gt, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, partials, terms, dL_dimg,
+                                 (hipStream_t)stream);
 }
 
 int gslic_knn_mean_dist2(int32_t P, const float* points, float* mean_dists, gslic_alloc_fn scratch_alloc, void* scratch_ctx,

@@ -351,13 +351,24 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(size_t nblk, const flo
 __global__ __launch_bounds__(256) void loss_bwd_kernel(SsimGrid grid, int H, int W, float w_l1, float w_ssim, const float* __restrict__ img1,
                                                        const float* __restrict__ img2, const float* __restrict__ dm_dmu1,
                                                        const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12,
-                                                       float* __restrict__ dL_dimg1)
+                                                       float* __restrict__ dL_dimg1, size_t red_nblk, const float* __restrict__ red_partials,
+                                                       float red_inv_n, float* __restrict__ red_terms)
 {
     // the horizontal pass overwrites the first 32 floats of each row with that row's sums (the wave that owns a row has read all of it
     // by then: two rows per wave, lockstep): 21.2 KB instead of 37.3 — six workgroups per CU instead of four
     __shared__ float s1[SH_][SH_];
     __shared__ float s2[SH_][SH_];
     __shared__ float s3[SH_][SH_];
+    if (red_terms && blockIdx.x == 0) {
+        // gslic_l1_ssim_loss_forward_backward: the sums of the forward's per-block partials (loss_reduce_kernel's loop and order: the same bits)
+        // ride on workgroup 0 of the backward instead of being a launch of their own between the two loss kernels
+        float* const red = &s1[0][0];
+        float r0 = 0.f, r1 = 0.f;
+        for (size_t i = threadIdx.x; i < red_nblk; i += 256) { r0 += red_partials[2 * i]; r1 += red_partials[2 * i + 1]; }
+        const float t0 = block256_sum(r0, red);
+        const float t1 = block256_sum(r1, red);
+        if (threadIdx.x == 0) { red_terms[0] = t0 * red_inv_n; red_terms[1] = t1 * red_inv_n; }
+    }
     int tile_x, tile_y, plane_i;
     size_t tile_linear;
     if (!ssim_tile(grid, tile_x, tile_y, plane_i, tile_linear)) return;   // (whole workgroup: before any barrier)
@@ -447,7 +458,20 @@ int loss_backward(int B, int CH, int H, int W, float lambda_dssim, const float* 
     const SsimGrid grid = ssim_grid(W, H, B * CH, blocks);
     const float n = (float)((size_t)B * CH * H * W);
     GS_LAUNCH(K_SSIM_BWD, loss_bwd_kernel, dim3(blocks), dim3(256), 0, s, grid, H, W, (1.0f - lambda_dssim) / n, -lambda_dssim / n, img, gt, d1, d2,
-              d3, dL_dimg);
+              d3, dL_dimg, (size_t)0, (const float*)nullptr, 0.0f, (float*)nullptr);
+    return GSLIC_OK;
+}
+// forward + backward of the loss in TWO launches: the reduction of the forward's partial sums rides on workgroup 0 of the backward
+int loss_forward_backward(int B, int CH, int H, int W, float C1, float C2, float lambda_dssim, const float* img, const float* gt, float* d1,
+                          float* d2, float* d3, float* partials, float* terms, float* dL_dimg, hipStream_t s)
+{
+    unsigned blocks;
+    const SsimGrid grid = ssim_grid(W, H, B * CH, blocks);
+    const float n = (float)((size_t)B * CH * H * W);
+    GS_LAUNCH(K_SSIM_FWD, loss_fwd_kernel, dim3(blocks), dim3(256), 0, s, grid, H, W, C1, C2, img, gt, d1, d2, d3, partials);
+    const size_t nblk = (size_t)grid.gx * grid.gy * grid.planes;
+    GS_LAUNCH(K_SSIM_BWD, loss_bwd_kernel, dim3(blocks), dim3(256), 0, s, grid, H, W, (1.0f - lambda_dssim) / n, -lambda_dssim / n, img, gt,
+              (const float*)d1, (const float*)d2, (const float*)d3, dL_dimg, nblk, (const float*)partials, 1.0f / n, terms);
     return GSLIC_OK;
 }
 int64_t loss_partials_count(int B, int CH, int H, int W) { return 2 * (int64_t)div_up(W, ST) * div_up(H, ST) * B * CH + 8; }

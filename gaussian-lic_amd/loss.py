@@ -165,10 +165,9 @@ class FusedLoss:
         CH, H, W = image.shape
         d1, d2, d3, dL, partials, terms = self._scratch(image)
         p, L = _lib.ptr, _lib.lib()
-        _lib.check(L.gslic_l1_ssim_loss_forward(1, CH, H, W, C1, C2, p(image), p(gt), p(d1), p(d2), p(d3), p(partials), p(terms),
-                                                _lib.current_stream_ptr()))
-        _lib.check(L.gslic_l1_ssim_loss_backward(1, CH, H, W, self.lambda_dssim, p(image), p(gt), p(d1), p(d2), p(d3), p(dL),
-                                                 _lib.current_stream_ptr()))
+        # (two launches: the reduction of the forward's partial sums rides on the backward kernel; gslic_l1_ssim_loss_forward + _backward are three)
+        _lib.check(L.gslic_l1_ssim_loss_forward_backward(1, CH, H, W, C1, C2, self.lambda_dssim, p(image), p(gt), p(d1), p(d2), p(d3), p(partials),
+                                                         p(terms), p(dL), _lib.current_stream_ptr()))
         return dL, terms
 
     def value(self, terms):

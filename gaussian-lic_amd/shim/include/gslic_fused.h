@@ -159,12 +159,11 @@ public:
                                       radii_.data_ptr<int32_t>(), &R, &B, current_stream()),
               "gslic_rasterize_forward");
         const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;   // loss_utils.h:187-188
-        check(gslic_l1_ssim_loss_forward(1, 3, H, W, C1, C2, f(image_), f(gt_image), dm_[0].data_ptr<float>(), dm_[1].data_ptr<float>(),
-                                         dm_[2].data_ptr<float>(), partials_.data_ptr<float>(), terms.data_ptr<float>(), current_stream()),
-              "gslic_l1_ssim_loss_forward");
-        check(gslic_l1_ssim_loss_backward(1, 3, H, W, lambda_dssim_, f(image_), f(gt_image), f(dm_[0]), f(dm_[1]), f(dm_[2]),
-                                          dL_dimage_.data_ptr<float>(), current_stream()),
-              "gslic_l1_ssim_loss_backward");
+        // (forward + backward of the loss in two launches: the reduction of the partial sums rides on the backward kernel)
+        check(gslic_l1_ssim_loss_forward_backward(1, 3, H, W, C1, C2, lambda_dssim_, f(image_), f(gt_image), dm_[0].data_ptr<float>(),
+                                                  dm_[1].data_ptr<float>(), dm_[2].data_ptr<float>(), partials_.data_ptr<float>(),
+                                                  terms.data_ptr<float>(), dL_dimage_.data_ptr<float>(), current_stream()),
+              "gslic_l1_ssim_loss_forward_backward");
         gslic_adam_fused ad{};
         for (int i = 0; i < 6; i++) {
             const bool on = prm_[i].numel() != 0;   // features_rest is [P,0,3] at SH degree 0: an empty group is a no-op, as in the reference

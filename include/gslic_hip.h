@@ -383,6 +383,11 @@ int gslic_l1_ssim_loss_forward(
 int gslic_l1_ssim_loss_backward(
     int32_t B, int32_t CH, int32_t H, int32_t W, float lambda_dssim, const float* img, const float* gt,
     const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg, void* stream);
+/* Both of them as TWO launches instead of three (ABI 7): the fixed-order reduction of the forward's partial sums into `terms` rides on the
+ * first workgroup of the backward kernel.  Same bits in the maps, in terms and in dL_dimg as the two calls above. */
+int gslic_l1_ssim_loss_forward_backward(
+    int32_t B, int32_t CH, int32_t H, int32_t W, float C1, float C2, float lambda_dssim, const float* img, const float* gt,
+    float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, float* partials, float* terms /*[2] device*/, float* dL_dimg, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * gslic_knn_mean_dist2 — replaces SimpleKNN::knn (src/simple-knn/simple_knn.cu:185-221) behind distCUDA2
