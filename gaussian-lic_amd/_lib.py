@@ -39,7 +39,7 @@ EXPORTS = [
     "gslic_last_error", "gslic_geom_bytes", "gslic_img_bytes", "gslic_binning_bytes", "gslic_sample_bytes",
     "gslic_profile_enable", "gslic_profile_reset", "gslic_profile_collect", "gslic_profile_num_kernels",
     "gslic_profile_kernel_name", "gslic_profile_get", "gslic_debug_export", "gslic_extend_select", "gslic_extend_emit", "gslic_loss_partials_count", "gslic_l1_ssim_loss_forward", "gslic_l1_ssim_loss_forward_backward",
-    "gslic_l1_ssim_loss_backward", "gslic_set_math_mode", "gslic_rasterize_forward_capacity", "gslic_rasterize_backward_rgb",
+    "gslic_l1_ssim_loss_backward", "gslic_set_math_mode", "gslic_set_binning_mode", "gslic_rasterize_forward_capacity", "gslic_rasterize_backward_rgb",
     "gslic_rasterize_backward_rgb_rows", "gslic_sh_grad_from_rgb", "gslic_sh_grad_from_rgb_adam", "gslic_rasterize_backward_rgb_payload",
     "gslic_sh_grad_from_rgb_adam_all",
 ]
@@ -108,6 +108,7 @@ def lib():
     L.gslic_l1_ssim_loss_backward.argtypes = [i32, i32, i32, i32, f32] + [vp] * 6 + [vp]
     L.gslic_l1_ssim_loss_forward_backward.argtypes = [i32, i32, i32, i32, f32, f32, f32] + [vp] * 8 + [vp]
     L.gslic_set_math_mode.argtypes = [i32]
+    L.gslic_set_binning_mode.argtypes = [i32]
     if L.gslic_abi_version() != 7:
         raise GslicError("libgslic_hip.so ABI version mismatch")
     _lib = L
@@ -118,6 +119,13 @@ def set_math_mode(strict):
     """gslic_set_math_mode: True (default) = the blend kernels in the reference's arithmetic (bit-identical image), False = fast (opt-in; GSLIC_FAST_MATH=1).
     Returns the previous mode."""
     return bool(lib().gslic_set_math_mode(int(bool(strict))))
+
+
+def set_binning_mode(mode):
+    """gslic_set_binning_mode: "auto" (default), "radix" or "atomic" — how the forward groups the instances by tile (same lists bit for bit).
+    Returns the previous mode's name."""
+    names = ("auto", "radix", "atomic")
+    return names[lib().gslic_set_binning_mode(names.index(mode))]
 
 
 def check(rc):

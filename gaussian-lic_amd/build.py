@@ -22,6 +22,7 @@ SOURCES = {
     "api.hip": [],
     "scan.hip": [],
     "radix_sort.hip": [],
+    "tile_bin.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],
     "render.hip": ["-fno-slp-vectorize"],
     "render_bwd_scan.hip": ["-fno-slp-vectorize"],

@@ -39,7 +39,7 @@ static bool g_prof_cur_on = false;
 static const char* const k_names[K_COUNT] = {
     "preprocess", "scan_reduce", "scan_spine", "scan_apply", "keybuild", "sort_hist", "sort_scatter", "finalize_lists",
     "bucket_count", "render_fwd", "render_bwd", "preprocess_bwd", "adam", "ssim_fwd", "ssim_bwd", "knn_minmax", "knn_morton",
-    "knn_boxes", "knn_search", "debug_export", "extend", "dsort_hist", "dsort_scatter", "sh_grad_from_rgb", "tile_lsort"};
+    "knn_boxes", "knn_search", "debug_export", "extend", "dsort_hist", "dsort_scatter", "sh_grad_from_rgb", "tile_lsort", "tile_hist", "tile_bin"};
 uint32_t g_lds_pad[K_COUNT] = {0};
 static const bool g_lds_pad_parsed = [] {   // GSLIC_LDS_PAD="name=bytes,name=bytes"
     const char* e = getenv("GSLIC_LDS_PAD");
@@ -123,8 +123,9 @@ BinningState BinningState::carve(const void* base, size_t R, int end_bit, bool n
     g.sort_scratch = c.take<char>(sort_scratch_bytes(g.plan));
     g.partials = no_color ? nullptr : c.take<float>((size_t)GS_PROW * R);
     g.dead = no_color ? nullptr : c.take<uint8_t>(R);
-    for (int i = 0; i < 4; i++)   // (36 R bytes of partial rows, unused until the backward: room for the four 4 R arrays)
-        g.lsort[i] = no_color ? c.take<uint32_t>(R) : reinterpret_cast<uint32_t*>(g.partials) + (size_t)i * R;
+    // (36 R bytes of partial rows, unused until the backward: room for the four 4 R arrays — contiguous: they are also the 16 R bytes of binned())
+    uint32_t* const ls = no_color ? c.take<uint32_t>(4 * R) : reinterpret_cast<uint32_t*>(g.partials);
+    for (int i = 0; i < 4; i++) g.lsort[i] = ls + (size_t)i * R;
     if (bytes) *bytes = c.used(base) + 256;
     return g;
 }
@@ -179,16 +180,20 @@ uint32_t* device_status_word()
     }
     return static_cast<uint32_t*>(p);
 }
-__global__ void publish_kernel(const uint32_t* __restrict__ v0, const uint32_t* __restrict__ v1, uint32_t* status, uint32_t* box, uint32_t seq)
+__global__ void publish_kernel(const uint32_t* __restrict__ v0, const uint32_t* __restrict__ v1, const uint32_t* __restrict__ v2, uint32_t* status,
+                               uint32_t* box, uint32_t seq)
 {
     const uint32_t st = status ? atomicExch(status, 0u) : 0u;  // bit 0: a bounded spin-wait gave up somewhere upstream
     __hip_atomic_store(box + 0, v0 ? *v0 : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(box + 3, v2 ? *v2 : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(box + 1, (v1 ? (*v1 & 1u) : 0u) | ((st & 3u) << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(box + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// out[0] = *v0, out[1] = (*v1 & 1) | scan-timeout << 1 | scan-overflow << 2
-static int fetch_counts(const uint32_t* v0, const uint32_t* v1, uint32_t out[2], hipStream_t s, uint32_t* fault = nullptr)
+// out[0] = *v0, out[1] = (*v1 & 1) | scan-timeout << 1 | scan-overflow << 2; *extra_out = *extra (an optional third word riding along)
+static int fetch_counts(const uint32_t* v0, const uint32_t* v1, uint32_t out[2], hipStream_t s, uint32_t* fault = nullptr,
+                        const uint32_t* extra = nullptr, uint32_t* extra_out = nullptr)
 {
+    if (extra_out) *extra_out = 0;
     int dev = 0;
     GS_HIP(hipGetDevice(&dev));
     static const bool use_mailbox = getenv("GSLIC_NO_MAILBOX") == nullptr;
@@ -211,7 +216,7 @@ static int fetch_counts(const uint32_t* v0, const uint32_t* v1, uint32_t out[2],
         }
         if (m.host) {
             const uint32_t seq = ++m.seq ? m.seq : ++m.seq;  // never 0
-            hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, s, v0, v1, status, m.dev, seq);
+            hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, s, v0, v1, extra, status, m.dev, seq);
             GS_HIP(hipGetLastError());
             const auto t0 = std::chrono::steady_clock::now();
             uint32_t spins = 0;
@@ -225,6 +230,7 @@ static int fetch_counts(const uint32_t* v0, const uint32_t* v1, uint32_t out[2],
                 return set_error(GSLIC_ERR_HIP, "count mailbox: the publish kernel did not report");
             out[0] = m.host[0];
             out[1] = m.host[1];
+            if (extra_out) *extra_out = m.host[3];
             return GSLIC_OK;
         }
     }
@@ -233,6 +239,7 @@ static int fetch_counts(const uint32_t* v0, const uint32_t* v1, uint32_t out[2],
     if (v0) GS_HIP(hipMemcpyAsync(&out[0], v0, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (v1) GS_HIP(hipMemcpyAsync(&out[1], v1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (status) GS_HIP(hipMemcpyAsync(&st, status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (extra && extra_out) GS_HIP(hipMemcpyAsync(extra_out, extra, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     GS_HIP(hipStreamSynchronize(s));
     if (st) GS_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t), s));
     out[1] = (out[1] & 1u) | ((st & 3u) << 1);
@@ -356,6 +363,42 @@ __global__ void forward_status_kernel(const uint32_t* __restrict__ R, const uint
 }
 }  // namespace gslic
 
+// GSLIC_BINNING = auto (default) | atomic | radix.  auto: per host thread and per kind of map (rows in the caller's order / rows permuted by
+// the library: tie_rank set), the path follows what the last binned forward measured — the global atomics its tile histogram needed per
+// instance (0.08 with the rows of the 2M / 1080p scene in Morton order, 0.79 in random order; the two paths cost the same at about 0.5).  A map
+// found incoherent is probed again every 64th forward.  Capacity-mode forwards read nothing back: they follow the last measurement of the
+// thread, and before any, bin exactly when the library permuted the rows.
+struct BinningAuto { int measured = 0; bool coherent = true; uint32_t since_probe = 0; };
+static thread_local BinningAuto t_binning[2];
+static int g_binning_mode = [] {
+    const char* e = getenv("GSLIC_BINNING");
+    if (e && strcmp(e, "radix") == 0) return 1;
+    if (e && strcmp(e, "atomic") == 0) return 2;
+    return 0;
+}();
+static int binning_mode() { return g_binning_mode; }
+static bool binning_choice(int T, bool permuted, bool capacity)
+{
+    if (T > gslic::GS_TILE_BIN_MAX_T || binning_mode() == 1) return false;
+    if (binning_mode() == 2) return true;
+    // (one 4-byte LDS counter per tile and workgroup: above 64 KB a CU holds one workgroup and the path stops paying — 4K, 32 400 tiles:
+    // 164 views/s against the radix sort's 165 at the config-5 shape)
+    if (T > 16384) return false;
+    BinningAuto& st = t_binning[permuted ? 1 : 0];
+    if (!st.measured) return capacity ? permuted : true;
+    if (st.coherent) return true;
+    if (capacity) return false;
+    return ++st.since_probe >= 64u;   // (a probe: binning_feedback resets the count)
+}
+static void binning_feedback(bool permuted, bool used_bin, uint32_t atomics, uint32_t R)
+{
+    if (!used_bin || R < 4096u) return;
+    BinningAuto& st = t_binning[permuted ? 1 : 0];
+    st.measured = 1;
+    st.coherent = (double)atomics <= 0.4 * (double)R;
+    st.since_probe = 0;
+}
+
 static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn geom_alloc, void* geom_ctx, gslic_alloc_fn binning_alloc,
                             void* binning_ctx, gslic_alloc_fn img_alloc, void* img_ctx, gslic_alloc_fn sample_alloc,
                             void* sample_ctx, const ForwardCapacity* cap, const float* background, const float* means3D, const float* dc, const float* shs,
@@ -436,27 +479,44 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
     if (!bin_base) return set_error(GSLIC_ERR_ALLOC, "binning allocator returned NULL for %zu bytes", bin_bytes);
     BinningState bin = BinningState::carve(align256(bin_base), (size_t)R, end_bit, no_color, nullptr);
 
+    // How the instances get grouped by tile (same lists either way, bit for bit): block-aggregated atomics on the tiles' cursors (tile_bin.hip) when
+    // the map's row order keeps a block's instances on few tiles, the stable radix sort on the tile id otherwise (and above GS_TILE_BIN_MAX_T tiles).
+    const bool use_bin = R > 0 && binning_choice(T, prm->tie_rank != nullptr, cap != nullptr);
     if (R > 0) {
+        const int pp = bin.plan.passes & 1;   // the lists go to gauss[pp ^ 1] / slots[pp ^ 1] on either path (BinningState::point_list())
         KeybuildArgs ka;
         ka.P = P; ka.gx = gx; ka.gy = gy; ka.rec = geom.rec; ka.order = nullptr; ka.offsets = geom.point_offsets;
-        ka.tile_keys = bin.tile_keys[0]; ka.gauss = bin.gauss[0]; ka.depth = bin.lsort[0]; ka.gauss_start = geom.gauss_start; ka.cap = R; ka.status = geom.flags;
+        ka.gauss_start = geom.gauss_start; ka.cap = R; ka.status = geom.flags;
+        ka.tile_keys = bin.tile_keys[0];
+        ka.gauss = use_bin ? bin.gauss[pp] : bin.gauss[0];
+        ka.depth = use_bin ? bin.slots[pp] : bin.lsort[0];   // (binned() is the lsort arrays: the emission-order depths must not sit there)
         GS_TRY(launch_keybuild(ka, s));
         DEBUG_SYNC(prm, s);
-        // Level 1: stable sort of the instances on the tile id alone (ceil(log2(tiles)/8) digit passes, 2 at 1080p), carrying the emission
-        // slot (identity at the start), the Gaussian id and the depth bits: instances grouped by tile, in index order inside a tile.
-        SortBuffers sb;
-        for (int i = 0; i < 2; i++) { sb.keys[i] = bin.tile_keys[i]; sb.v0[i] = bin.slots[i]; sb.v1[i] = bin.gauss[i]; sb.v2[i] = bin.lsort[i]; }
-        sb.v0_identity = true;
-        GS_TRY(radix_sort_u32(sb, bin.plan, bin.sort_scratch, (onesweep_mask() & 2) != 0, K_SORT_HIST, K_SORT_SCATTER, s, R_dev, geom.flags + GS_FLAG_FAULT));
-        DEBUG_SYNC(prm, s);
-        GS_TRY(launch_finalize_ranges(R, R_dev, bin.sorted_tiles(), img.ranges, bin.dead, s));
-        DEBUG_SYNC(prm, s);
-        // Level 2: every tile's segment by depth (stable: equal depths stay in index order, or in tie_rank order) — one workgroup per tile
-        const int pp = bin.plan.passes & 1;
         TileDepthSortArgs ts;
-        ts.T = T; ts.ranges = img.ranges; ts.depth = bin.lsort[pp]; ts.depth_alt = bin.lsort[pp ^ 1]; ts.idx_a = bin.lsort[2]; ts.idx_b = bin.lsort[3];
-        ts.gauss_in = bin.gauss[pp]; ts.slot_in = bin.slots[pp]; ts.gauss_out = bin.gauss[pp ^ 1]; ts.slot_out = bin.slots[pp ^ 1];
-        ts.tie_rank = prm->tie_rank; ts.status = geom.flags; ts.long_tiles = img.bucket_offsets;
+        ts.T = T; ts.ranges = img.ranges; ts.tie_rank = prm->tie_rank; ts.status = geom.flags; ts.long_tiles = img.bucket_offsets;
+        ts.gauss_out = bin.gauss[pp ^ 1]; ts.slot_out = bin.slots[pp ^ 1];
+        if (use_bin) {
+            TileBinArgs tb;
+            tb.T = T; tb.n_cap = R; tb.n_dev = R_dev; tb.tile = ka.tile_keys; tb.gid = ka.gauss; tb.depth = ka.depth; tb.tie_rank = prm->tie_rank;
+            tb.ranges = img.ranges; tb.binned = bin.binned(); tb.dead = bin.dead; tb.status = geom.flags;
+            GS_TRY(launch_tile_bin(tb, s));
+            DEBUG_SYNC(prm, s);
+            ts.binned = bin.binned(); ts.depth = nullptr; ts.gauss_in = nullptr; ts.slot_in = nullptr;
+            ts.key_a = bin.tile_keys[0]; ts.key_b = bin.tile_keys[1]; ts.idx_a = bin.gauss[pp]; ts.idx_b = bin.slots[pp];   // (all dead by now)
+        } else {
+            // Level 1: stable sort of the instances on the tile id alone (ceil(log2(tiles)/8) digit passes, 2 at 1080p), carrying the emission
+            // slot (identity at the start), the Gaussian id and the depth bits: instances grouped by tile, in index order inside a tile.
+            SortBuffers sb;
+            for (int i = 0; i < 2; i++) { sb.keys[i] = bin.tile_keys[i]; sb.v0[i] = bin.slots[i]; sb.v1[i] = bin.gauss[i]; sb.v2[i] = bin.lsort[i]; }
+            sb.v0_identity = true;
+            GS_TRY(radix_sort_u32(sb, bin.plan, bin.sort_scratch, (onesweep_mask() & 2) != 0, K_SORT_HIST, K_SORT_SCATTER, s, R_dev, geom.flags + GS_FLAG_FAULT));
+            DEBUG_SYNC(prm, s);
+            GS_TRY(launch_finalize_ranges(R, R_dev, bin.tile_keys[pp], img.ranges, bin.dead, s));
+            DEBUG_SYNC(prm, s);
+            ts.binned = nullptr; ts.depth = bin.lsort[pp]; ts.gauss_in = bin.gauss[pp]; ts.slot_in = bin.slots[pp];
+            ts.key_a = bin.lsort[pp ^ 1]; ts.key_b = bin.tile_keys[pp ^ 1]; ts.idx_a = bin.lsort[2]; ts.idx_b = bin.lsort[3];
+        }
+        // Level 2: every tile's segment by (depth, original index) — the order of the reference's 64-bit sort of an index-ordered emission
         GS_TRY(launch_tile_depth_sort(ts, s));
         DEBUG_SYNC(prm, s);
     }
@@ -469,9 +529,12 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
         if (cap) {
             B = capacity_for(cap->sample_bytes, [&](uint32_t b) { size_t n; SampleState::carve(nullptr, (size_t)b, &n); return n; });
         } else {
-            GS_TRY(fetch_counts(img.bucket_offsets + (T - 1), nullptr, hostbuf, s, geom.flags + GS_FLAG_FAULT));  // rasterizer_impl.cu:442
+            uint32_t bin_atomics = 0;
+            GS_TRY(fetch_counts(img.bucket_offsets + (T - 1), nullptr, hostbuf, s, geom.flags + GS_FLAG_FAULT,
+                                use_bin ? geom.flags + GS_FLAG_BIN_ATOMICS : nullptr, &bin_atomics));  // rasterizer_impl.cu:442
             if (hostbuf[1] & 2u) return set_error(GSLIC_ERR_HIP, "a sort look-back / chained-scan wait timed out (device preempted?): the forward was abandoned");
             B = hostbuf[0];
+            binning_feedback(prm->tie_rank != nullptr, use_bin, bin_atomics, R);
         }
         size_t smp_bytes;
         SampleState::carve(nullptr, (size_t)B, &smp_bytes);
@@ -500,6 +563,16 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
 }
 
 extern "C" {
+int gslic_set_binning_mode(int32_t mode)
+{
+    const int old = g_binning_mode;
+    if (mode >= 0 && mode <= 2) {
+        g_binning_mode = mode;
+        t_binning[0] = BinningAuto();
+        t_binning[1] = BinningAuto();
+    }
+    return old;
+}
 int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_alloc, void* geom_ctx, gslic_alloc_fn binning_alloc,
                             void* binning_ctx, gslic_alloc_fn img_alloc, void* img_ctx, gslic_alloc_fn sample_alloc,
                             void* sample_ctx, const float* background, const float* means3D, const float* dc, const float* shs,
@@ -958,12 +1031,13 @@ __global__ __launch_bounds__(256) void export_geom_kernel(int P, const float4* _
     if (o_co) { o_co[4 * i] = r0.z; o_co[4 * i + 1] = r0.w; o_co[4 * i + 2] = r1.x; o_co[4 * i + 3] = r1.y; }
     if (o_rgb) { o_rgb[3 * i] = r1.z; o_rgb[3 * i + 1] = r1.w; o_rgb[3 * i + 2] = r2.x; }
 }
-// the reference's sorted 64-bit keys (tile << 32 | depth bits), rebuilt from the sorted tile ids and the point list
-__global__ __launch_bounds__(256) void export_keys_kernel(uint32_t R, const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ point_list,
+// the reference's sorted 64-bit keys (tile << 32 | depth bits), rebuilt from the tiles' ranges and the point list (one workgroup per tile)
+__global__ __launch_bounds__(256) void export_keys_kernel(uint32_t R, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                                                           const float4* __restrict__ rec, uint64_t* __restrict__ o)
 {
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k < R) o[k] = ((uint64_t)tiles[k] << 32) | __float_as_uint(rec[GS_REC_F4 * (size_t)point_list[k] + 2].y);
+    const uint2 r = ranges[blockIdx.x];
+    for (uint32_t k = r.x + threadIdx.x; k < r.y && k < R; k += 256u)
+        o[k] = ((uint64_t)blockIdx.x << 32) | __float_as_uint(rec[GS_REC_F4 * (size_t)point_list[k] + 2].y);
 }
 __global__ __launch_bounds__(256) void export_ncontrib_kernel(int W, int H, int gx, const float4* __restrict__ pix_final, uint32_t* o)
 {
@@ -994,8 +1068,8 @@ extern "C" int gslic_debug_export(const gslic_raster_params* prm, int32_t R, int
         GS_LAUNCH(K_DEBUG_EXPORT, export_geom_kernel, dim3(div_up(P, 256)), dim3(256), 0, s, P, (const float4*)geom.rec,
                   (const uint32_t*)geom.tiles_touched, tiles_touched, means2D, depths, conic_opacity, rgb);
     if (R > 0 && sorted_keys)
-        GS_LAUNCH(K_DEBUG_EXPORT, export_keys_kernel, dim3(((uint32_t)R + 255u) / 256u), dim3(256), 0, s, (uint32_t)R,
-                  (const uint32_t*)bin.sorted_tiles(), (const uint32_t*)bin.point_list(), (const float4*)geom.rec, sorted_keys);
+        GS_LAUNCH(K_DEBUG_EXPORT, export_keys_kernel, dim3((unsigned)T), dim3(256), 0, s, (uint32_t)R,
+                  (const uint2*)img.ranges, (const uint32_t*)bin.point_list(), (const float4*)geom.rec, sorted_keys);
     if (R > 0 && point_list)
         GS_HIP(hipMemcpyAsync(point_list, bin.point_list(), (size_t)R * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     if (ranges) GS_HIP(hipMemcpyAsync(ranges, img.ranges, (size_t)T * sizeof(uint2), hipMemcpyDeviceToDevice, s));

@@ -64,12 +64,16 @@ enum KernelId {
     K_DSORT_SCATTER,
     K_SH_REBUILD,
     K_TILE_LSORT,
+    K_TILE_HIST,
+    K_TILE_BIN,
     K_COUNT
 };
 void prof_begin(int id, hipStream_t s);
 void prof_end(int id, hipStream_t s);
 extern bool g_prof_on;
 #define GS_FLAG_HITBITS 4   // index into GeomState::flags: set by a forward that recorded SampleState::hit
+#define GS_FLAG_BIN_ATOMICS 10   // index into GeomState::flags: global atomics of the tile histogram of this forward (sum over its blocks of the distinct
+                                 // tiles of a block: what grouping by tile without a sort costs on this map's row order — api.hip picks the path by it)
 #define GS_FLAG_LONG 9      // index into GeomState::flags: number of tiles whose instance list is longer than the one-wave depth sort takes (radix_sort.hip)
 #define GS_FLAG_FAULT 8     // index into GeomState::flags: bit 0 a bounded look-back wait of THIS forward's scans / sorts gave up, bit 1 its instance count
                             // overflowed.  Per forward (the flags are zeroed at its start), so forwards running concurrently on several streams of
@@ -161,13 +165,35 @@ int radix_sort_u32(const SortBuffers& b, const SortPlan& plan, void* scratch, bo
 // map's rows are stored permuted — by ONE workgroup per tile: an LSD radix sort of (depth, local index) pairs in LDS for segments of up to
 // LS_CAP instances, through the four scratch arrays for longer ones.  gauss_out / slot_out receive the tile's Gaussian ids / emission slots in
 // the reference's list order (rasterizer_impl.cu:419-424: stable 64-bit sort of tile << 32 | depth over the index-ordered emission).
+// Grouping the instances by tile WITHOUT a sort (tile_bin.hip): block-aggregated atomics on the tiles' list cursors.  Any order inside a tile
+// will do, because the per-tile depth sort orders a tile's instances by (depth, tie key) — a total order.
+struct TileBinArgs {
+    int T;
+    uint32_t n_cap;             // instances the launch is sized for (capacity mode: the buffer's capacity; the exact R otherwise)
+    const uint32_t* n_dev;      // capacity mode: the real instance count, on the device (NULL: n_cap)
+    const uint32_t* tile;       // [R] tile id per emission slot (keybuild)
+    const uint32_t* gid;        // [R] Gaussian id per emission slot
+    const uint32_t* depth;      // [R] depth bits per emission slot
+    const uint32_t* tie_rank;   // optional [P]: gslic_raster_params.tie_rank (the tie key of an instance is tie_rank[gid], or gid without it)
+    uint2* ranges;              // [T] zero on entry (preprocess_kernel); the tiles' list ranges on exit, (0, 0) for an empty tile
+    uint4* binned;              // [R] out, grouped by tile: {depth bits, tie key, Gaussian id, emission slot}
+    uint8_t* dead;              // optional [R]: the backward's per-slot dead flags, cleared here (a coalesced byte store riding on the pass)
+    uint32_t* status;           // device status words: a non-zero [2] (capacity overflow) makes the kernels return
+};
+static constexpr int GS_TILE_BIN_MAX_T = 36864;   // tiles the block histogram of the binning kernels holds in LDS (4 bytes each, 144 of 160 KB)
+int launch_tile_bin(const TileBinArgs& a, hipStream_t s);
+
 struct TileDepthSortArgs {
     int T;
     const uint2* ranges;
-    uint32_t* depth;            // [R] sorted by tile (the third payload of the tile sort); scratch for segments longer than LS_CAP
-    uint32_t* depth_alt;        // [R] scratch
-    uint32_t* idx_a;            // [R] scratch
-    uint32_t* idx_b;            // [R] scratch
+    const uint4* binned;        // non-NULL: the instances grouped by tile in ANY order inside a tile (TileBinArgs::binned) — depth, gauss_in and
+                                // slot_in are then not read, and equal depths are put into tie-key order by a second key (no input order to keep);
+                                // NULL: depth / gauss_in / slot_in sorted by tile, in index order inside a tile (the stable tile sort's output)
+    const uint32_t* depth;      // [R] sorted by tile (the third payload of the tile sort)
+    uint32_t* key_a;            // [R] each: scratch of the segments longer than LS_CAP (keys and indices, ping-pong); they alias no input and no output
+    uint32_t* key_b;
+    uint32_t* idx_a;
+    uint32_t* idx_b;
     const uint32_t* gauss_in;   // [R] sorted by tile
     const uint32_t* slot_in;    // [R] sorted by tile
     uint32_t* gauss_out;        // [R] the point list
@@ -213,7 +239,7 @@ struct BinningState {
     SortPlan plan;
     uint32_t* point_list() const { return gauss[(plan.passes & 1) ^ 1]; }    // (written by the per-tile depth sort)
     uint32_t* inst_slot() const { return slots[(plan.passes & 1) ^ 1]; }
-    uint32_t* sorted_tiles() const { return tile_keys[plan.passes & 1]; }
+    uint4* binned() const { return reinterpret_cast<uint4*>(lsort[0]); }       // [R] 16-byte rows of the atomic binning (TileBinArgs): the four lsort arrays
     static BinningState carve(const void* base, size_t R, int end_bit, bool no_color, size_t* bytes);
 };
 struct SampleState {

@@ -359,15 +359,38 @@ static int sort_impl(const SortBuffers& b, const SortPlan& plan, const uint32_t*
 static constexpr int LS_THREADS = 256;
 static constexpr int LS_CHUNK = 1024;
 
-template <bool LDS>
+// What the two kinds of input look like to the sort (TileDepthSortArgs): BINNED = 16-byte rows {depth, tie key, Gaussian id, slot} grouped by
+// tile in any order; otherwise three arrays sorted by tile, in index order inside a tile.
+template <bool BINNED>
+struct TileIn {
+    const TileDepthSortArgs& a;
+    const uint32_t x;
+    __device__ __forceinline__ uint32_t depth(uint32_t e) const { return BINNED ? a.binned[x + e].x : __builtin_nontemporal_load(a.depth + x + e); }
+    // the second key: ascending original index among equal depths (forward.cu / rasterizer_impl.cu:419: the reference's stable sort of an
+    // index-ordered emission).  The stable tile sort's output is in row order already: without tie_rank its local index IS that key.
+    __device__ __forceinline__ uint32_t tie(uint32_t e) const
+    {
+        return BINNED ? a.binned[x + e].y : (a.tie_rank ? a.tie_rank[a.gauss_in[x + e]] : e);
+    }
+    __device__ __forceinline__ uint2 out(uint32_t e) const
+    {
+        if (BINNED) return *reinterpret_cast<const uint2*>(&a.binned[x + e].z);   // (the upper half of the row: one 8-byte load)
+        return make_uint2(a.gauss_in[x + e], a.slot_in[x + e]);
+    }
+    // equal depths need the second key unless the input is in row order and the row order is the original one
+    __device__ __forceinline__ bool two_keys() const { return BINNED || a.tie_rank != nullptr; }
+};
+
+template <bool LDS, bool BINNED>
 __device__ __forceinline__ void tile_depth_sort_body(const TileDepthSortArgs& a, const uint32_t x, const uint32_t n, uint32_t* const kL0, uint32_t* const kL1,
                                                      uint16_t* const iL0, uint16_t* const iL1, uint32_t* const hist, uint32_t* const run,
                                                      uint32_t (*cnt)[256], uint32_t* const red)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // ping-pong sides: side 0 = {kL0, iL0} or {depth, idx_a}; side 1 = {kL1, iL1} or {depth_alt, idx_b}
-    uint32_t* const kG0 = a.depth + x;
-    uint32_t* const kG1 = a.depth_alt + x;
+    const TileIn<BINNED> in{a, x};
+    // ping-pong sides: side 0 = {kL0, iL0} or {key_a, idx_a}; side 1 = {kL1, iL1} or {key_b, idx_b} (four scratch arrays that alias no input)
+    uint32_t* const kG0 = a.key_a + x;
+    uint32_t* const kG1 = a.key_b + x;
     uint32_t* const iG0 = a.idx_a + x;
     uint32_t* const iG1 = a.idx_b + x;
     auto rdk = [&](int side, uint32_t e) -> uint32_t { return LDS ? (side ? kL1[e] : kL0[e]) : (side ? kG1[e] : kG0[e]); };
@@ -376,93 +399,82 @@ __device__ __forceinline__ void tile_depth_sort_body(const TileDepthSortArgs& a,
         if (LDS) { if (side) { kL1[e] = k; iL1[e] = (uint16_t)i; } else { kL0[e] = k; iL0[e] = (uint16_t)i; } }
         else { if (side) { kG1[e] = k; iG1[e] = i; } else { kG0[e] = k; iG0[e] = i; } }
     };
-    for (uint32_t e = tid; e < n; e += LS_THREADS) {
-        if (LDS) { kL0[e] = a.depth[x + e]; iL0[e] = (uint16_t)e; }
-        else iG0[e] = e;
-    }
-    __syncthreads();
+    // A long list always takes both keys when it needs them at all (LSD: the tie key first, then the depth — both passes stable): lists this long
+    // are rare, and a run of equal depths can be as long as the list (a wall seen head-on), which rules out fixing runs up afterwards.
     int cur = 0;
-    for (int shift = 0; shift < 32; shift += 8) {
-        // ---- digit histogram of the segment (one LDS atomic per distinct digit of a 64-lane item)
-        hist[tid] = 0;
-        __syncthreads();
-        for (uint32_t e0 = 0; e0 < n; e0 += LS_THREADS) {
-            const uint32_t e = e0 + tid;
-            const bool valid = e < n;
-            const uint32_t d = valid ? ((rdk(cur, e) >> shift) & 0xffu) : 0u;
-            const uint64_t peers = match_digit(d, valid);
-            if (valid && popc_below(peers) == 0) atomicAdd(&hist[d], (uint32_t)__popcll(peers));
+#pragma unroll 1
+    for (int phase = in.two_keys() ? 0 : 1; phase < 2; phase++) {
+        if (phase == 0) {
+            for (uint32_t e = tid; e < n; e += LS_THREADS) wr(0, e, in.tie(e), e);
+        } else if (!in.two_keys()) {
+            for (uint32_t e = tid; e < n; e += LS_THREADS) wr(0, e, in.depth(e), e);
+        } else {
+            for (uint32_t p = tid; p < n; p += LS_THREADS) { const uint32_t i = rdi(cur, p); wr(cur, p, in.depth(i), i); }
         }
         __syncthreads();
-        const uint32_t d_first = (rdk(cur, 0) >> shift) & 0xffu;
-        const bool uniform = hist[d_first] == n;   // (the same for every thread: LDS values behind a barrier)
-        uint32_t total;
-        const uint32_t ex = block256_exclusive_prefix(hist[tid], total, red);   // (two barriers inside)
-        if (uniform) continue;                     // every key has this digit: the pass would be the identity
-        run[tid] = ex;
-        // ---- stable scatter, LS_CHUNK elements at a time
-        for (uint32_t c0 = 0; c0 < n; c0 += LS_CHUNK) {
-#pragma unroll
-            for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
+#pragma unroll 1
+        for (int shift = 0; shift < 32; shift += 8) {
+            // ---- digit histogram of the segment (one LDS atomic per distinct digit of a 64-lane item)
+            hist[tid] = 0;
             __syncthreads();
-            uint32_t rk[4], dg[4], kk[4], ii[4];
-            bool vl[4];
-#pragma unroll
-            for (int it = 0; it < 4; it++) {
-                const uint32_t e = c0 + (uint32_t)wave * 256u + (uint32_t)it * 64u + (uint32_t)lane;
-                vl[it] = e < n;
-                kk[it] = vl[it] ? rdk(cur, e) : 0u;
-                ii[it] = vl[it] ? rdi(cur, e) : 0u;
-                dg[it] = (kk[it] >> shift) & 0xffu;
-                const uint64_t peers = match_digit(dg[it], vl[it]);
-                const uint32_t lower = popc_below(peers);
-                uint32_t old = 0;
-                if (vl[it]) old = cnt[wave][dg[it]];
-                __builtin_amdgcn_wave_barrier();
-                if (vl[it] && lower == 0) cnt[wave][dg[it]] = old + (uint32_t)__popcll(peers);
-                __builtin_amdgcn_wave_barrier();
-                rk[it] = old + lower;
+            for (uint32_t e0 = 0; e0 < n; e0 += LS_THREADS) {
+                const uint32_t e = e0 + tid;
+                const bool valid = e < n;
+                const uint32_t d = valid ? ((rdk(cur, e) >> shift) & 0xffu) : 0u;
+                const uint64_t peers = match_digit(d, valid);
+                if (valid && popc_below(peers) == 0) atomicAdd(&hist[d], (uint32_t)__popcll(peers));
             }
             __syncthreads();
-            {   // thread d: where each wave's run of digit d starts in the output, and the segment's running offset behind this chunk
-                uint32_t o = run[tid];
+            const uint32_t d_first = (rdk(cur, 0) >> shift) & 0xffu;
+            const bool uniform = hist[d_first] == n;   // (the same for every thread: LDS values behind a barrier)
+            uint32_t total;
+            const uint32_t ex = block256_exclusive_prefix(hist[tid], total, red);   // (two barriers inside)
+            if (uniform) continue;                     // every key has this digit: the pass would be the identity
+            run[tid] = ex;
+            // ---- stable scatter, LS_CHUNK elements at a time
+            for (uint32_t c0 = 0; c0 < n; c0 += LS_CHUNK) {
 #pragma unroll
-                for (int w = 0; w < 4; w++) { const uint32_t c = cnt[w][tid]; cnt[w][tid] = o; o += c; }
-                run[tid] = o;
-            }
-            __syncthreads();
+                for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
+                __syncthreads();
+                uint32_t rk[4], dg[4], kk[4], ii[4];
+                bool vl[4];
 #pragma unroll
-            for (int it = 0; it < 4; it++)
-                if (vl[it]) wr(cur ^ 1, cnt[wave][dg[it]] + rk[it], kk[it], ii[it]);
-            __syncthreads();
-        }
-        cur ^= 1;
-    }
-    // ---- a map stored in a permuted row order: runs of equal depth in ascending tie_rank (= original index) instead of ascending row index
-    if (a.tie_rank) {
-        for (uint32_t j = tid; j + 1 < n; j += LS_THREADS) {
-            const uint32_t k = rdk(cur, j);
-            if (rdk(cur, j + 1) != k || (j > 0 && rdk(cur, j - 1) == k)) continue;
-            uint32_t e = j + 1;
-            while (e + 1 < n && rdk(cur, e + 1) == k) e++;          // run = [j, e]: this thread owns it (runs are disjoint)
-            for (uint32_t p = j + 1; p <= e; p++) {                    // insertion sort of the run's indices by rank
-                const uint32_t ip = rdi(cur, p), rp = a.tie_rank[a.gauss_in[x + ip]];
-                uint32_t q = p;
-                while (q > j) {
-                    const uint32_t iq = rdi(cur, q - 1);
-                    if (a.tie_rank[a.gauss_in[x + iq]] <= rp) break;
-                    wr(cur, q, k, iq);
-                    q--;
+                for (int it = 0; it < 4; it++) {
+                    const uint32_t e = c0 + (uint32_t)wave * 256u + (uint32_t)it * 64u + (uint32_t)lane;
+                    vl[it] = e < n;
+                    kk[it] = vl[it] ? rdk(cur, e) : 0u;
+                    ii[it] = vl[it] ? rdi(cur, e) : 0u;
+                    dg[it] = (kk[it] >> shift) & 0xffu;
+                    const uint64_t peers = match_digit(dg[it], vl[it]);
+                    const uint32_t lower = popc_below(peers);
+                    uint32_t old = 0;
+                    if (vl[it]) old = cnt[wave][dg[it]];
+                    __builtin_amdgcn_wave_barrier();
+                    if (vl[it] && lower == 0) cnt[wave][dg[it]] = old + (uint32_t)__popcll(peers);
+                    __builtin_amdgcn_wave_barrier();
+                    rk[it] = old + lower;
                 }
-                wr(cur, q, k, ip);
+                __syncthreads();
+                {   // thread d: where each wave's run of digit d starts in the output, and the segment's running offset behind this chunk
+                    uint32_t o = run[tid];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) { const uint32_t c = cnt[w][tid]; cnt[w][tid] = o; o += c; }
+                    run[tid] = o;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 4; it++)
+                    if (vl[it]) wr(cur ^ 1, cnt[wave][dg[it]] + rk[it], kk[it], ii[it]);
+                __syncthreads();
             }
+            cur ^= 1;
         }
         __syncthreads();
     }
     for (uint32_t j = tid; j < n; j += LS_THREADS) {
-        const uint32_t src = x + rdi(cur, j);
-        a.gauss_out[x + j] = a.gauss_in[src];
-        a.slot_out[x + j] = a.slot_in[src];
+        const uint2 o = in.out(rdi(cur, j));
+        a.gauss_out[x + j] = o.x;
+        a.slot_out[x + j] = o.y;
     }
 }
 
@@ -473,6 +485,11 @@ __device__ __forceinline__ void tile_depth_sort_body(const TileDepthSortArgs& a,
 // and every lane walks its run once more, taking each element's position from its column's counter.  Eight passes of ~25 instructions per
 // element and lane against four of ~70 per element and WAVE-WIDE ITEM for match-any ranking (8 ballots per item): 3x fewer instructions.
 // Element p of the sorted order lives at word phys(p) = (p / E) * (E | 1) + p % E: an odd stride per lane keeps the lanes' runs on distinct banks.
+//
+// Equal depths.  The reference's list has them in ascending original index (a stable sort of an index-ordered emission).  Input in row order
+// of a map whose row order is the original one gets that from the passes' stability; any other input (rows grouped by tile in arrival order;
+// a permuted map) gets it from a SECOND key, and only when the tile has two equal depths at all (3 % of the tiles of the 2M / 1080p scene):
+// the list is then sorted by the tie key and by the depth again — LSD over (depth, tie key), whatever the length of the runs.
 static constexpr int LW_CAP = 1024;
 static constexpr int LW_PHYS = 64 * 17;
 #define GS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
@@ -480,6 +497,7 @@ static constexpr int LW_PHYS = 64 * 17;
 // without a wait of its own.  GS_WAVE_ORDER() only keeps the COMPILER from moving accesses across it.
 #define GS_WAVE_ORDER() __builtin_amdgcn_wave_barrier()
 
+template <bool BINNED>
 __global__ __launch_bounds__(64) void tile_depth_sort_wave_kernel(const TileDepthSortArgs a)
 {
     __shared__ uint32_t sk[2][LW_PHYS];
@@ -494,16 +512,17 @@ __global__ __launch_bounds__(64) void tile_depth_sort_wave_kernel(const TileDept
         return;
     }
     if (n == 0) return;
+    const TileIn<BINNED> in{a, x};
     if (n <= 2) {
         if (lane == 0) {
             bool swap = false;
             if (n == 2) {
-                const uint32_t k0 = a.depth[x], k1 = a.depth[x + 1];
-                swap = k1 < k0 || (k1 == k0 && a.tie_rank && a.tie_rank[a.gauss_in[x + 1]] < a.tie_rank[a.gauss_in[x]]);
+                const uint32_t k0 = in.depth(0), k1 = in.depth(1);
+                swap = k1 < k0 || (k1 == k0 && in.two_keys() && in.tie(1) < in.tie(0));
             }
-            const uint32_t s0 = swap ? x + 1 : x;
-            a.gauss_out[x] = a.gauss_in[s0]; a.slot_out[x] = a.slot_in[s0];
-            if (n == 2) { const uint32_t s1 = swap ? x : x + 1; a.gauss_out[x + 1] = a.gauss_in[s1]; a.slot_out[x + 1] = a.slot_in[s1]; }
+            const uint2 o0 = in.out(swap ? 1u : 0u);
+            a.gauss_out[x] = o0.x; a.slot_out[x] = o0.y;
+            if (n == 2) { const uint2 o1 = in.out(swap ? 0u : 1u); a.gauss_out[x + 1] = o1.x; a.slot_out[x + 1] = o1.y; }
         }
         return;
     }
@@ -512,136 +531,143 @@ __global__ __launch_bounds__(64) void tile_depth_sort_wave_kernel(const TileDept
     const float rE = 1.0f / (float)E;
     // (p + 1/2) / E is at least 1 / (2 E) >= 1/32 away from every integer: the float quotient truncates to p / E exactly for p < 2^20
     auto phys = [&](uint32_t p) { const uint32_t q = (uint32_t)(((float)p + 0.5f) * rE); return q * Eo + (p - q * E); };
-    uint32_t krange = 0xffffffffu;   // largest key of the tile relative to its smallest (wave-uniform)
-    {   // all of the wave's global loads in flight at once (a load -> LDS store loop pays one HBM round trip per 64 elements, and there are only two
-        // or three waves per SIMD to hide it: that, not the sort, was 80 % of this kernel's first version)
-        uint32_t v[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const uint32_t e = 64u * (uint32_t)j + lane;
-            v[j] = ((uint32_t)j < E && e < n) ? __builtin_nontemporal_load(a.depth + x + e) : 0u;
-        }
-        // keys relative to the tile's smallest depth (order and ties unchanged): the digits above the tile's depth RANGE are zero for every
-        // key and their passes are skipped (26-27 significant bits on the 2M / 1080p scene: seven passes instead of eight)
-        uint32_t kmin = 0xffffffffu, kmax = 0u;
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const uint32_t e = 64u * (uint32_t)j + lane;
-            if ((uint32_t)j < E && e < n) { kmin = v[j] < kmin ? v[j] : kmin; kmax = v[j] > kmax ? v[j] : kmax; }
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const uint32_t a0 = (uint32_t)__shfl_xor((int)kmin, d, 64), a1 = (uint32_t)__shfl_xor((int)kmax, d, 64);
-            kmin = a0 < kmin ? a0 : kmin; kmax = a1 > kmax ? a1 : kmax;
-        }
-        krange = kmax - kmin;
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const uint32_t e = 64u * (uint32_t)j + lane;
-            if ((uint32_t)j < E && e < n) { const uint32_t ph = phys(e); sk[0][ph] = v[j] - kmin; si[0][ph] = (uint16_t)e; }
-        }
-    }
     const uint32_t lo = lane * E;
     const uint32_t mine = lo < n ? (n - lo < E ? n - lo : E) : 0u;   // elements of this lane's run
     const uint32_t run0 = lane * Eo;
     uint32_t* const col = C + lane + (lane >> 4);                      // this lane's counter column: col[68 d] (64 d + l + its pad words)
-    GS_WAVE_ORDER();
     int cur = 0;
+    // phase 0: by depth.  Only a tile with two equal depths whose order the input does not settle goes on — phase 1: by tie key (from the input
+    // order), phase 2: by depth again (from the tie-key order).
 #pragma unroll 1
-    for (int shift = 0; shift < 32; shift += 4) {
-        if ((krange >> shift) == 0u) break;   // every remaining digit of every key is zero
-        // The lane's run in registers: sixteen independent LDS reads in flight at once (a runtime loop over the run pays one LDS round trip per
-        // element and step — 36 per pass — with two waves per SIMD to hide them: measured 187 us for the 2M / 1080p scene).
-        uint32_t k[16], ix[16];
+    for (int phase = 0; phase < 3; phase++) {
+        uint32_t krange;   // largest key relative to the smallest (wave-uniform)
+        {   // all of the wave's global loads in flight at once (a load -> LDS store loop pays one HBM round trip per 64 elements, and there are only two
+            // or three waves per SIMD to hide it: that, not the sort, was 80 % of this kernel's first version)
+            uint32_t v[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            k[j] = 0u; ix[j] = 0u;
-            if ((uint32_t)j < E && (uint32_t)j < mine) { k[j] = sk[cur][run0 + j]; ix[j] = si[cur][run0 + j]; }
-        }
+            for (int j = 0; j < 16; j++) {
+                const uint32_t e = 64u * (uint32_t)j + lane;
+                const bool ok = (uint32_t)j < E && e < n;
+                const uint32_t src = (ok && phase == 2) ? (uint32_t)si[cur][phys(e)] : e;
+                v[j] = ok ? (phase == 1 ? in.tie(src) : in.depth(src)) : 0u;
+            }
+            // keys relative to the tile's smallest (order and ties unchanged): the digits above the tile's key RANGE are zero for every key and
+            // their passes are skipped (26-27 significant depth bits on the 2M / 1080p scene: seven passes instead of eight)
+            uint32_t kmin = 0xffffffffu, kmax = 0u;
 #pragma unroll
-        for (int d = 0; d < 16; d++) col[68 * d] = 0u;
-        GS_WAVE_ORDER();
+            for (int j = 0; j < 16; j++) {
+                const uint32_t e = 64u * (uint32_t)j + lane;
+                if ((uint32_t)j < E && e < n) { kmin = v[j] < kmin ? v[j] : kmin; kmax = v[j] > kmax ? v[j] : kmax; }
+            }
 #pragma unroll
-        for (int j = 0; j < 16; j++)
-            if ((uint32_t)j < E && (uint32_t)j < mine) atomicAdd(&col[68 * ((k[j] >> shift) & 15u)], 1u);
-        GS_WAVE_ORDER();
-        {   // exclusive scan of the matrix in (digit, lane) order: lane l takes the sixteen words [16 l, 16 l + 16).  One pad word per sixteen
-            // (word f at f + (f >> 4)) puts lane l's run at 17 l: distinct banks for the 32 lanes of a half wave — unpadded, sixteen lanes hit the same
-            // bank with every access and the scan alone kept the LDS busy for longer than the rest of the kernel (69 % conflict cycles)
-            uint32_t* const cs = C + 17 * lane;
-            uint32_t w[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) w[i] = cs[i];
-            uint32_t tot = 0;
-#pragma unroll
-            for (int i = 0; i < 16; i++) { const uint32_t t = w[i]; w[i] = tot; tot += t; }
-            const uint32_t base = wave_inclusive_scan(tot) - tot;
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint32_t a0 = (uint32_t)__shfl_xor((int)kmin, d, 64), a1 = (uint32_t)__shfl_xor((int)kmax, d, 64);
+                kmin = a0 < kmin ? a0 : kmin; kmax = a1 > kmax ? a1 : kmax;
+            }
+            krange = kmax - kmin;
+            const int dst = phase == 2 ? cur : 0;
             GS_WAVE_ORDER();
 #pragma unroll
-            for (int i = 0; i < 16; i++) cs[i] = w[i] + base;
-        }
-        GS_WAVE_ORDER();
-        uint32_t pos[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) {   // (this lane's own counters, in run order: no other lane touches them)
-            pos[j] = 0u;
-            if ((uint32_t)j < E && (uint32_t)j < mine) pos[j] = atomicAdd(&col[68 * ((k[j] >> shift) & 15u)], 1u);
-        }
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            if ((uint32_t)j < E && (uint32_t)j < mine) {
-                const uint32_t ph = phys(pos[j]);
-                sk[cur ^ 1][ph] = k[j];
-                si[cur ^ 1][ph] = (uint16_t)ix[j];
-            }
-        }
-        GS_WAVE_ORDER();
-        cur ^= 1;
-    }
-    GS_WAVE_SYNC();
-    if (a.tie_rank) {   // runs of equal depth in ascending tie_rank (= original index of a permuted map's row) instead of ascending row index
-        for (uint32_t j = lane; j + 1 < n; j += 64u) {
-            const uint32_t k = sk[cur][phys(j)];
-            if (sk[cur][phys(j + 1)] != k || (j > 0 && sk[cur][phys(j - 1)] == k)) continue;
-            uint32_t e = j + 1;
-            while (e + 1 < n && sk[cur][phys(e + 1)] == k) e++;      // run = [j, e]: this lane owns it (runs are disjoint)
-            for (uint32_t p = j + 1; p <= e; p++) {
-                const uint16_t ip = si[cur][phys(p)];
-                const uint32_t rp = a.tie_rank[a.gauss_in[x + ip]];
-                uint32_t q = p;
-                while (q > j) {
-                    const uint16_t iq = si[cur][phys(q - 1)];
-                    if (a.tie_rank[a.gauss_in[x + iq]] <= rp) break;
-                    si[cur][phys(q)] = iq;
-                    q--;
+            for (int j = 0; j < 16; j++) {
+                const uint32_t e = 64u * (uint32_t)j + lane;
+                if ((uint32_t)j < E && e < n) {
+                    const uint32_t ph = phys(e);
+                    sk[dst][ph] = v[j] - kmin;
+                    if (phase != 2) si[dst][ph] = (uint16_t)e;   // (phase 2 re-keys the list in place: position e keeps its index)
                 }
-                si[cur][phys(q)] = ip;
             }
+            cur = dst;
+        }
+        GS_WAVE_ORDER();
+#pragma unroll 1
+        for (int shift = 0; shift < 32; shift += 4) {
+            if ((krange >> shift) == 0u) break;   // every remaining digit of every key is zero
+            // The lane's run in registers: sixteen independent LDS reads in flight at once (a runtime loop over the run pays one LDS round trip per
+            // element and step — 36 per pass — with two waves per SIMD to hide them: measured 187 us for the 2M / 1080p scene).
+            uint32_t k[16], ix[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                k[j] = 0u; ix[j] = 0u;
+                if ((uint32_t)j < E && (uint32_t)j < mine) { k[j] = sk[cur][run0 + j]; ix[j] = si[cur][run0 + j]; }
+            }
+#pragma unroll
+            for (int d = 0; d < 16; d++) col[68 * d] = 0u;
+            GS_WAVE_ORDER();
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if ((uint32_t)j < E && (uint32_t)j < mine) atomicAdd(&col[68 * ((k[j] >> shift) & 15u)], 1u);
+            GS_WAVE_ORDER();
+            {   // exclusive scan of the matrix in (digit, lane) order: lane l takes the sixteen words [16 l, 16 l + 16).  One pad word per sixteen
+                // (word f at f + (f >> 4)) puts lane l's run at 17 l: distinct banks for the 32 lanes of a half wave — unpadded, sixteen lanes hit the same
+                // bank with every access and the scan alone kept the LDS busy for longer than the rest of the kernel (69 % conflict cycles)
+                uint32_t* const cs = C + 17 * lane;
+                uint32_t w[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) w[i] = cs[i];
+                uint32_t tot = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) { const uint32_t t = w[i]; w[i] = tot; tot += t; }
+                const uint32_t base = wave_inclusive_scan(tot) - tot;
+                GS_WAVE_ORDER();
+#pragma unroll
+                for (int i = 0; i < 16; i++) cs[i] = w[i] + base;
+            }
+            GS_WAVE_ORDER();
+            uint32_t pos[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {   // (this lane's own counters, in run order: no other lane touches them)
+                pos[j] = 0u;
+                if ((uint32_t)j < E && (uint32_t)j < mine) pos[j] = atomicAdd(&col[68 * ((k[j] >> shift) & 15u)], 1u);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                if ((uint32_t)j < E && (uint32_t)j < mine) {
+                    const uint32_t ph = phys(pos[j]);
+                    sk[cur ^ 1][ph] = k[j];
+                    si[cur ^ 1][ph] = (uint16_t)ix[j];
+                }
+            }
+            GS_WAVE_ORDER();
+            cur ^= 1;
         }
         GS_WAVE_SYNC();
+        if (phase == 0) {
+            if (!in.two_keys()) break;
+            // two equal depths anywhere in the tile?  Every lane looks at its own run of the sorted list (consecutive words: no phys() arithmetic)
+            // and at the first element of the next lane's run.
+            uint32_t kr[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) kr[j] = ((uint32_t)j < E && (uint32_t)j < mine) ? sk[cur][run0 + j] : 0u;
+            bool dup = false;
+            uint32_t last = kr[0];
+#pragma unroll
+            for (int j = 1; j < 16; j++)
+                if ((uint32_t)j < E && (uint32_t)j < mine) { dup |= kr[j] == last; last = kr[j]; }
+            const uint32_t next_first = (uint32_t)__shfl_down((int)kr[0], 1, 64);
+            const uint32_t next_mine = (uint32_t)__shfl_down((int)mine, 1, 64);
+            if (lane < 63u && mine > 0u && next_mine > 0u) dup |= last == next_first;
+            if (__ballot(dup) == 0ull) break;   // (wave-uniform)
+        }
     }
     {   // the tile's Gaussian ids and emission slots in list order: every gather of the wave in flight before the first store
-        uint32_t g[16], sl[16];
+        uint2 o[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const uint32_t p = 64u * (uint32_t)j + lane;
-            g[j] = sl[j] = 0u;
-            if ((uint32_t)j < E && p < n) {
-                const uint32_t src = x + si[cur][phys(p)];
-                g[j] = a.gauss_in[src];
-                sl[j] = a.slot_in[src];
-            }
+            o[j] = make_uint2(0u, 0u);
+            if ((uint32_t)j < E && p < n) o[j] = in.out(si[cur][phys(p)]);
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const uint32_t p = 64u * (uint32_t)j + lane;
-            if ((uint32_t)j < E && p < n) { a.gauss_out[x + p] = g[j]; a.slot_out[x + p] = sl[j]; }
+            if ((uint32_t)j < E && p < n) { a.gauss_out[x + p] = o[j].x; a.slot_out[x + p] = o[j].y; }
         }
     }
 }
 
 // Longer segments: one workgroup of 256 threads; pairs in LDS up to LS_CAP instances, in the global scratch arrays beyond.
 static constexpr int LS_CAP = 4096;
+template <bool BINNED>
 __global__ __launch_bounds__(LS_THREADS) void tile_depth_sort_kernel(const TileDepthSortArgs a)
 {
     __shared__ uint32_t kL0[LS_CAP], kL1[LS_CAP];
@@ -652,8 +678,8 @@ __global__ __launch_bounds__(LS_THREADS) void tile_depth_sort_kernel(const TileD
     for (uint32_t q = blockIdx.x; q < n_long; q += gridDim.x) {
         const uint2 range = a.ranges[a.long_tiles[q]];
         const uint32_t x = range.x, n = range.y - range.x;
-        if (n <= (uint32_t)LS_CAP) tile_depth_sort_body<true>(a, x, n, kL0, kL1, iL0, iL1, hist, run, cnt, red);
-        else tile_depth_sort_body<false>(a, x, n, kL0, kL1, iL0, iL1, hist, run, cnt, red);
+        if (n <= (uint32_t)LS_CAP) tile_depth_sort_body<true, BINNED>(a, x, n, kL0, kL1, iL0, iL1, hist, run, cnt, red);
+        else tile_depth_sort_body<false, BINNED>(a, x, n, kL0, kL1, iL0, iL1, hist, run, cnt, red);
         __syncthreads();
     }
 }
@@ -661,9 +687,15 @@ __global__ __launch_bounds__(LS_THREADS) void tile_depth_sort_kernel(const TileD
 int launch_tile_depth_sort(const TileDepthSortArgs& a, hipStream_t s)
 {
     if (a.T <= 0) return GSLIC_OK;
-    GS_LAUNCH(K_TILE_LSORT, tile_depth_sort_wave_kernel, dim3((unsigned)a.T), dim3(64), 0, s, a);
-    // a fixed grid walks the queue of long lists (usually empty: its workgroups read one word and leave)
-    GS_LAUNCH(K_TILE_LSORT, tile_depth_sort_kernel, dim3((unsigned)(a.T < 512 ? a.T : 512)), dim3(LS_THREADS), 0, s, a);
+    // a fixed grid walks the queue of long lists behind the one-wave kernel (usually empty: its workgroups read one word and leave)
+    const dim3 lgrid((unsigned)(a.T < 512 ? a.T : 512));
+    if (a.binned) {
+        GS_LAUNCH(K_TILE_LSORT, tile_depth_sort_wave_kernel<true>, dim3((unsigned)a.T), dim3(64), 0, s, a);
+        GS_LAUNCH(K_TILE_LSORT, tile_depth_sort_kernel<true>, lgrid, dim3(LS_THREADS), 0, s, a);
+    } else {
+        GS_LAUNCH(K_TILE_LSORT, tile_depth_sort_wave_kernel<false>, dim3((unsigned)a.T), dim3(64), 0, s, a);
+        GS_LAUNCH(K_TILE_LSORT, tile_depth_sort_kernel<false>, lgrid, dim3(LS_THREADS), 0, s, a);
+    }
     return GSLIC_OK;
 }
 

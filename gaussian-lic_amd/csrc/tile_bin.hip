@@ -1,0 +1,158 @@
+// tile_bin.hip — the instances grouped by tile WITHOUT a sort (round 5).
+//
+// The reference sorts (tile << 32 | depth) keys (rasterizer_impl.cu:419-424).  Since the per-tile depth sort (radix_sort.hip) orders a tile's
+// instances by (depth, tie key) — a total order — the order in which they ARRIVE in the tile's segment does not matter, and the stable two-pass
+// radix sort on the tile id (0.146 ms at 2M / 1080p, three payloads) can be any grouping.  Per-instance atomics on the tiles' cursors lose to it
+// (tools/ubench/atomic_scatter.hip: 240 us); BLOCK-aggregated ones do not, when the map's rows are stored in an order that keeps a block's
+// instances on few tiles (Morton order of the centres: 4096 consecutive instances touch 330 tiles on the 2M / 1080p scene, 3200 when the rows
+// are in random order): a block counts its tiles in an LDS histogram, the thread that drew rank 0 of a tile reserves the tile's count at the
+// global cursor, and everybody stores one 16-byte row {depth, tie key, Gaussian id, emission slot} at cursor + rank — runs of ~12 rows per tile
+// and block.  tools/ubench/tile_binning.hip on the scene's real tile stream: histogram 14 us + binning 46 us (rows in Morton order; 51 + 153
+// in random order, where api.hip keeps the radix sort).
+//
+//   tile_hist_kernel : count[tile] += the block's count (ranges[tile].y, zero on entry); status[GS_FLAG_BIN_ATOMICS] += the block's distinct tiles
+//   tile_scan_kernel : ranges[tile] = {start, start} (the cursor), {0, 0} for an empty tile (as the reference's zeroed ranges)
+//   tile_bin_kernel  : position = atomicAdd(ranges[tile].y, the block's count) + rank; on exit ranges[tile] = {start, end}
+#include "kernels.h"
+
+namespace gslic {
+
+static constexpr int TB_THREADS = 256, TB_ITEMS = 16, TB_BLOCK = TB_THREADS * TB_ITEMS;
+
+__device__ __forceinline__ uint32_t tb_count(const TileBinArgs& a)
+{
+    return a.n_dev ? (*a.n_dev < a.n_cap ? *a.n_dev : a.n_cap) : a.n_cap;
+}
+
+__global__ __launch_bounds__(TB_THREADS) void tile_hist_kernel(const TileBinArgs a)
+{
+    extern __shared__ uint32_t h[];   // [T]
+    __shared__ uint32_t red[4];
+    if (a.status[2] != 0u) return;
+    const uint32_t n = tb_count(a);
+    const uint32_t b0 = blockIdx.x * (uint32_t)TB_BLOCK;
+    if (b0 >= n) return;
+    for (int i = threadIdx.x; i < a.T; i += TB_THREADS) h[i] = 0u;
+    __syncthreads();
+    uint32_t t[TB_ITEMS];
+#pragma unroll
+    for (int j = 0; j < TB_ITEMS; j++) {
+        const uint32_t i = b0 + (uint32_t)(j * TB_THREADS) + threadIdx.x;
+        t[j] = i < n ? a.tile[i] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int j = 0; j < TB_ITEMS; j++)
+        if (t[j] < (uint32_t)a.T) atomicAdd(&h[t[j]], 1u);
+    __syncthreads();
+    uint32_t distinct = 0;
+    for (int i = threadIdx.x; i < a.T; i += TB_THREADS) {
+        const uint32_t c = h[i];
+        if (c) { atomicAdd(&a.ranges[i].y, c); distinct++; }
+    }
+    uint32_t total;
+    block256_exclusive_prefix(distinct, total, red);
+    if (threadIdx.x == 0) atomicAdd(a.status + GS_FLAG_BIN_ATOMICS, total);
+}
+
+// One workgroup: the counts reach the threads through LDS (coalesced loads; a thread scans TS_PER consecutive tiles), the ranges leave the same way.
+static constexpr int TS_THREADS = 1024;
+__global__ __launch_bounds__(TS_THREADS) void tile_scan_kernel(const TileBinArgs a)
+{
+    extern __shared__ uint32_t c[];   // [per * TS_THREADS (+ padding)]: count of tile t at c[t + t / 32] (a thread's run starts on its own bank)
+    __shared__ uint32_t wsum[TS_THREADS / 64];
+    if (a.status[2] != 0u) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (a.T + TS_THREADS - 1) / TS_THREADS;
+    auto at = [&](int t) -> uint32_t& { return c[t + (t >> 5)]; };
+    for (int t = tid; t < a.T; t += TS_THREADS) at(t) = a.ranges[t].y;
+    __syncthreads();
+    const int t0 = tid * per, t1 = (t0 + per) < a.T ? (t0 + per) : a.T;
+    uint32_t sum = 0;
+    for (int t = t0; t < t1; t++) sum += at(t);
+    const uint32_t inc = wave_inclusive_scan(sum);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t start = inc - sum;
+    for (int w = 0; w < wave; w++) start += wsum[w];
+    for (int t = t0; t < t1; t++) { const uint32_t n = at(t); at(t) = n ? start : 0xffffffffu; start += n; }
+    __syncthreads();
+    for (int t = tid; t < a.T; t += TS_THREADS) {
+        const uint32_t st = at(t);
+        a.ranges[t] = st != 0xffffffffu ? make_uint2(st, st) : make_uint2(0u, 0u);
+    }
+}
+
+__global__ __launch_bounds__(TB_THREADS) void tile_bin_kernel(const TileBinArgs a)
+{
+    extern __shared__ uint32_t h[];   // [T]: the block's count per tile, then the tile's reserved position
+    if (a.status[2] != 0u) return;
+    const uint32_t n = tb_count(a);
+    const uint32_t b0 = blockIdx.x * (uint32_t)TB_BLOCK;
+    if (b0 >= n) return;
+    for (int i = threadIdx.x; i < a.T; i += TB_THREADS) h[i] = 0u;
+    __syncthreads();
+    uint32_t t[TB_ITEMS], r[TB_ITEMS], g[TB_ITEMS], d[TB_ITEMS];
+#pragma unroll
+    for (int j = 0; j < TB_ITEMS; j++) {   // (all of a thread's loads in flight before the first use)
+        const uint32_t i = b0 + (uint32_t)(j * TB_THREADS) + threadIdx.x;
+        const bool in = i < n;
+        t[j] = in ? a.tile[i] : 0xffffffffu;
+        g[j] = in ? a.gid[i] : 0u;
+        d[j] = in ? a.depth[i] : 0u;
+        if (in && a.dead) a.dead[i] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < TB_ITEMS; j++) {
+        if (t[j] >= (uint32_t)a.T) t[j] = 0xffffffffu;
+        r[j] = t[j] != 0xffffffffu ? atomicAdd(&h[t[j]], 1u) : 1u;   // rank among the block's instances of the tile (any order will do)
+    }
+    uint32_t tie[TB_ITEMS];
+#pragma unroll
+    for (int j = 0; j < TB_ITEMS; j++) tie[j] = (a.tie_rank && t[j] != 0xffffffffu) ? a.tie_rank[g[j]] : g[j];
+    __syncthreads();
+    uint32_t c[TB_ITEMS];
+#pragma unroll
+    for (int j = 0; j < TB_ITEMS; j++) c[j] = (r[j] == 0u && t[j] != 0xffffffffu) ? h[t[j]] : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TB_ITEMS; j++)
+        if (c[j]) h[t[j]] = atomicAdd(&a.ranges[t[j]].y, c[j]);   // (one global atomic per distinct tile of the block)
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TB_ITEMS; j++) {
+        if (t[j] == 0xffffffffu) continue;
+        const uint32_t i = b0 + (uint32_t)(j * TB_THREADS) + threadIdx.x;
+        a.binned[h[t[j]] + r[j]] = make_uint4(d[j], tie[j], g[j], i);
+    }
+}
+
+int launch_tile_bin(const TileBinArgs& a, hipStream_t s)
+{
+    if (a.n_cap == 0 || a.T <= 0) return GSLIC_OK;
+    if (a.T > GS_TILE_BIN_MAX_T) return set_error(GSLIC_ERR_INVALID_ARG, "tile binning: more than %d tiles", GS_TILE_BIN_MAX_T);
+    const unsigned grid = (a.n_cap + (uint32_t)TB_BLOCK - 1u) / (uint32_t)TB_BLOCK;
+    const size_t lds = (size_t)a.T * sizeof(uint32_t);
+    // (more than 64 KB of dynamic LDS per workgroup has to be asked for, once per kernel and device)
+    static bool asked[16] = {false}, granted[16] = {false};
+    int dev = 0;
+    GS_HIP(hipGetDevice(&dev));
+    const int di = dev >= 0 && dev < 16 ? dev : 0;
+    if (!asked[di] || dev != di) {
+        const int big = 160 * 1024 - 256;
+        granted[di] = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, big) == hipSuccess &&
+                      hipFuncSetAttribute(reinterpret_cast<const void*>(tile_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, big) == hipSuccess &&
+                      hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, big) == hipSuccess;
+        asked[di] = true;
+        (void)hipGetLastError();
+    }
+    const bool lds_ok = granted[di];
+    if (!lds_ok && a.T > 15000) return set_error(GSLIC_ERR_HIP, "tile binning: the kernels' dynamic LDS limit could not be raised");
+    GS_LAUNCH(K_TILE_HIST, tile_hist_kernel, dim3(grid), dim3(TB_THREADS), lds, s, a);
+    const int per = (a.T + TS_THREADS - 1) / TS_THREADS;
+    const size_t slds = ((size_t)per * TS_THREADS + (size_t)per * TS_THREADS / 32 + 1) * sizeof(uint32_t);
+    GS_LAUNCH(K_TILE_HIST, tile_scan_kernel, dim3(1), dim3(TS_THREADS), slds, s, a);
+    GS_LAUNCH(K_TILE_BIN, tile_bin_kernel, dim3(grid), dim3(TB_THREADS), lds, s, a);
+    return GSLIC_OK;
+}
+
+}  // namespace gslic

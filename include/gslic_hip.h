@@ -441,6 +441,14 @@ const char* gslic_last_error(void);
  * and T < 1e-4 decisions of a few (pixel, Gaussian) pairs per million (counted in the same test). */
 int gslic_set_math_mode(int32_t strict);
 
+/* How the forward groups the (Gaussian, tile) instances by tile — the tile half of cub::DeviceRadixSort::SortPairs,
+ * rasterizer_impl.cu:419-424; the lists are the reference's bit for bit on either path.  Returns the previous mode.
+ * 0 = auto (default; GSLIC_BINNING=auto): block-aggregated atomics on the tiles' list cursors while the map's row order keeps consecutive
+ *     Gaussians on neighbouring tiles (measured per forward: the global atomics the tile histogram needed per instance), the stable radix sort
+ *     otherwise and above 16384 tiles;  1 = always the radix sort (GSLIC_BINNING=radix);  2 = atomics whenever the tile count allows
+ *     (GSLIC_BINNING=atomic).  Any other value only reads the mode. */
+int gslic_set_binning_mode(int32_t mode);
+
 /* Sizes the four scratch buffers would need, for hosts that prefer to pre-size (bytes incl. slack). */
 size_t gslic_geom_bytes(int32_t P);
 size_t gslic_img_bytes(int32_t width, int32_t height);
