@@ -56,6 +56,11 @@ def algorithmic_bytes(kernel, s):
         # per-tile depth sort: depth 4 + gaussian id 4 + slot 4 in, gaussian id 4 + slot 4 out per instance; ranges 8 per tile
         "tile_lsort": 20 * R + 8 * T,
         "finalize_lists": 4 * R + 8 * T,          # sorted tile ids in, ranges out
+        # grouping by tile without a sort (tile_bin.hip): the histogram reads the tile ids and the single-workgroup scan turns the counts into ranges;
+        # the binning reads tile, Gaussian id, depth bits (12) and writes one 16-byte row + the cleared dead flag (1) per instance.  The per-tile
+        # sort then reads rows (16) instead of three arrays (12): + 4 R on "tile_lsort", not itemised
+        "tile_hist": 4 * R + 24 * T,
+        "tile_bin": 29 * R,
         # list 4 + record 48 per instance of a live bucket; checkpoints 4096 (+ decision masks) per live bucket; pix_final 16/px(padded), image 16/px
         "render_fwd": 52 * Rl + (4096 + hb) * Bl + 16 * Np + 16 * N,
         # live buckets: checkpoints 4096 (+ masks), list 4 + slot 4 + record 48 in, partial row 36 out per instance; dead buckets: slot 4 in,
@@ -571,6 +576,8 @@ def main():
                                      "dense": "the [P x 59] slab all-reduced", "sparse": "the visible rows of the slab all-reduced"}[trainer.exchange_mode()] + ")"),
                    "mode": args.mode, "host": args.host if args.mode != "render" else "dropin", "parallelism": f"dp{world}" if world > 1 else "single",
                    "math": "strict" if strict_mode else "fast", "map_order": args.map_order,
+                   # how the forward grouped the instances by tile in the instrumented warm-up pass (GSLIC_BINNING / gslic_set_binning_mode; auto follows the row order)
+                   "binning": ("atomic" if "tile_bin" in breakdown else "radix") + " (" + os.environ.get("GSLIC_BINNING", "auto") + ")",
                    "visible": stats["V"], "instances_R": stats["R"], "buckets_B": stats["B"], "instances_live": stats.get("R_live"),
                    "buckets_live": stats.get("B_live")},
         "roofline": roofline,

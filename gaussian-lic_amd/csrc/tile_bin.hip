@@ -17,22 +17,26 @@
 
 namespace gslic {
 
-static constexpr int TB_THREADS = 256, TB_ITEMS = 16, TB_BLOCK = TB_THREADS * TB_ITEMS;
+// Workgroup: THREADS x TB_ITEMS instances.  256 threads while five workgroups' histograms fit a CU's LDS together (up to 8192 tiles; four waves each);
+// 1024 threads above — one histogram of up to 144 KB then serves sixteen waves, instead of four waves having the CU to themselves.
+static constexpr int TB_ITEMS = 16;
 
 __device__ __forceinline__ uint32_t tb_count(const TileBinArgs& a)
 {
     return a.n_dev ? (*a.n_dev < a.n_cap ? *a.n_dev : a.n_cap) : a.n_cap;
 }
 
+template <int TB_THREADS>
 __global__ __launch_bounds__(TB_THREADS) void tile_hist_kernel(const TileBinArgs a)
 {
     extern __shared__ uint32_t h[];   // [T]
-    __shared__ uint32_t red[4];
+    __shared__ uint32_t red;
     if (a.status[2] != 0u) return;
     const uint32_t n = tb_count(a);
-    const uint32_t b0 = blockIdx.x * (uint32_t)TB_BLOCK;
+    const uint32_t b0 = blockIdx.x * (uint32_t)(TB_THREADS * TB_ITEMS);
     if (b0 >= n) return;
     for (int i = threadIdx.x; i < a.T; i += TB_THREADS) h[i] = 0u;
+    if (threadIdx.x == 0) red = 0u;
     __syncthreads();
     uint32_t t[TB_ITEMS];
 #pragma unroll
@@ -49,9 +53,11 @@ __global__ __launch_bounds__(TB_THREADS) void tile_hist_kernel(const TileBinArgs
         const uint32_t c = h[i];
         if (c) { atomicAdd(&a.ranges[i].y, c); distinct++; }
     }
-    uint32_t total;
-    block256_exclusive_prefix(distinct, total, red);
-    if (threadIdx.x == 0) atomicAdd(a.status + GS_FLAG_BIN_ATOMICS, total);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) distinct += (uint32_t)__shfl_xor((int)distinct, d, 64);
+    if ((threadIdx.x & 63) == 0 && distinct) atomicAdd(&red, distinct);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(a.status + GS_FLAG_BIN_ATOMICS, red);
 }
 
 // One workgroup: the counts reach the threads through LDS (coalesced loads; a thread scans TS_PER consecutive tiles), the ranges leave the same way.
@@ -82,12 +88,13 @@ __global__ __launch_bounds__(TS_THREADS) void tile_scan_kernel(const TileBinArgs
     }
 }
 
+template <int TB_THREADS>
 __global__ __launch_bounds__(TB_THREADS) void tile_bin_kernel(const TileBinArgs a)
 {
     extern __shared__ uint32_t h[];   // [T]: the block's count per tile, then the tile's reserved position
     if (a.status[2] != 0u) return;
     const uint32_t n = tb_count(a);
-    const uint32_t b0 = blockIdx.x * (uint32_t)TB_BLOCK;
+    const uint32_t b0 = blockIdx.x * (uint32_t)(TB_THREADS * TB_ITEMS);
     if (b0 >= n) return;
     for (int i = threadIdx.x; i < a.T; i += TB_THREADS) h[i] = 0u;
     __syncthreads();
@@ -126,11 +133,11 @@ __global__ __launch_bounds__(TB_THREADS) void tile_bin_kernel(const TileBinArgs 
     }
 }
 
-int launch_tile_bin(const TileBinArgs& a, hipStream_t s)
+template <int TB_THREADS>
+static int launch_tile_bin_t(const TileBinArgs& a, hipStream_t s)
 {
-    if (a.n_cap == 0 || a.T <= 0) return GSLIC_OK;
-    if (a.T > GS_TILE_BIN_MAX_T) return set_error(GSLIC_ERR_INVALID_ARG, "tile binning: more than %d tiles", GS_TILE_BIN_MAX_T);
-    const unsigned grid = (a.n_cap + (uint32_t)TB_BLOCK - 1u) / (uint32_t)TB_BLOCK;
+    const unsigned block = (unsigned)(TB_THREADS * TB_ITEMS);
+    const unsigned grid = (a.n_cap + block - 1u) / block;
     const size_t lds = (size_t)a.T * sizeof(uint32_t);
     // (more than 64 KB of dynamic LDS per workgroup has to be asked for, once per kernel and device)
     static bool asked[16] = {false}, granted[16] = {false};
@@ -139,20 +146,26 @@ int launch_tile_bin(const TileBinArgs& a, hipStream_t s)
     const int di = dev >= 0 && dev < 16 ? dev : 0;
     if (!asked[di] || dev != di) {
         const int big = 160 * 1024 - 256;
-        granted[di] = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, big) == hipSuccess &&
+        granted[di] = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist_kernel<TB_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, big) == hipSuccess &&
                       hipFuncSetAttribute(reinterpret_cast<const void*>(tile_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, big) == hipSuccess &&
-                      hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, big) == hipSuccess;
+                      hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bin_kernel<TB_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, big) == hipSuccess;
         asked[di] = true;
         (void)hipGetLastError();
     }
-    const bool lds_ok = granted[di];
-    if (!lds_ok && a.T > 15000) return set_error(GSLIC_ERR_HIP, "tile binning: the kernels' dynamic LDS limit could not be raised");
-    GS_LAUNCH(K_TILE_HIST, tile_hist_kernel, dim3(grid), dim3(TB_THREADS), lds, s, a);
+    if (!granted[di] && a.T > 15000) return set_error(GSLIC_ERR_HIP, "tile binning: the kernels' dynamic LDS limit could not be raised");
+    GS_LAUNCH(K_TILE_HIST, tile_hist_kernel<TB_THREADS>, dim3(grid), dim3(TB_THREADS), lds, s, a);
     const int per = (a.T + TS_THREADS - 1) / TS_THREADS;
     const size_t slds = ((size_t)per * TS_THREADS + (size_t)per * TS_THREADS / 32 + 1) * sizeof(uint32_t);
     GS_LAUNCH(K_TILE_HIST, tile_scan_kernel, dim3(1), dim3(TS_THREADS), slds, s, a);
-    GS_LAUNCH(K_TILE_BIN, tile_bin_kernel, dim3(grid), dim3(TB_THREADS), lds, s, a);
+    GS_LAUNCH(K_TILE_BIN, tile_bin_kernel<TB_THREADS>, dim3(grid), dim3(TB_THREADS), lds, s, a);
     return GSLIC_OK;
+}
+
+int launch_tile_bin(const TileBinArgs& a, hipStream_t s)
+{
+    if (a.n_cap == 0 || a.T <= 0) return GSLIC_OK;
+    if (a.T > GS_TILE_BIN_MAX_T) return set_error(GSLIC_ERR_INVALID_ARG, "tile binning: more than %d tiles", GS_TILE_BIN_MAX_T);
+    return a.T <= 8192 ? launch_tile_bin_t<256>(a, s) : launch_tile_bin_t<1024>(a, s);
 }
 
 }  // namespace gslic
