@@ -381,9 +381,6 @@ static bool binning_choice(int T, bool permuted, bool capacity)
 {
     if (T > gslic::GS_TILE_BIN_MAX_T || binning_mode() == 1) return false;
     if (binning_mode() == 2) return true;
-    // (one 4-byte LDS counter per tile and workgroup: above 64 KB a CU holds one workgroup and the path stops paying — 4K, 32 400 tiles:
-    // 164 views/s against the radix sort's 165 at the config-5 shape)
-    if (T > 16384) return false;
     BinningAuto& st = t_binning[permuted ? 1 : 0];
     if (!st.measured) return capacity ? permuted : true;
     if (st.coherent) return true;

@@ -14,11 +14,11 @@
 //   tile_scan_kernel : ranges[tile] = {start, start} (the cursor), {0, 0} for an empty tile (as the reference's zeroed ranges)
 //   tile_bin_kernel  : position = atomicAdd(ranges[tile].y, the block's count) + rank; on exit ranges[tile] = {start, end}
 #include "kernels.h"
+#include <cstdlib>
 
 namespace gslic {
 
-// Workgroup: THREADS x TB_ITEMS instances.  256 threads while five workgroups' histograms fit a CU's LDS together (up to 8192 tiles; four waves each);
-// 1024 threads above — one histogram of up to 144 KB then serves sixteen waves, instead of four waves having the CU to themselves.
+// Workgroup: THREADS x TB_ITEMS instances (launch_tile_bin picks THREADS: one histogram of up to 144 KB serves sixteen waves or four).
 static constexpr int TB_ITEMS = 16;
 
 __device__ __forceinline__ uint32_t tb_count(const TileBinArgs& a)
@@ -133,31 +133,36 @@ __global__ __launch_bounds__(TB_THREADS) void tile_bin_kernel(const TileBinArgs 
     }
 }
 
-template <int TB_THREADS>
-static int launch_tile_bin_t(const TileBinArgs& a, hipStream_t s)
+// (more than 64 KB of dynamic LDS per workgroup has to be asked for, once per kernel and device)
+template <typename K>
+static bool big_lds(K kernel, bool (&asked)[16], bool (&granted)[16])
 {
-    const unsigned block = (unsigned)(TB_THREADS * TB_ITEMS);
-    const unsigned grid = (a.n_cap + block - 1u) / block;
-    const size_t lds = (size_t)a.T * sizeof(uint32_t);
-    // (more than 64 KB of dynamic LDS per workgroup has to be asked for, once per kernel and device)
-    static bool asked[16] = {false}, granted[16] = {false};
     int dev = 0;
-    GS_HIP(hipGetDevice(&dev));
+    if (hipGetDevice(&dev) != hipSuccess) return false;
     const int di = dev >= 0 && dev < 16 ? dev : 0;
     if (!asked[di] || dev != di) {
-        const int big = 160 * 1024 - 256;
-        granted[di] = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist_kernel<TB_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, big) == hipSuccess &&
-                      hipFuncSetAttribute(reinterpret_cast<const void*>(tile_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, big) == hipSuccess &&
-                      hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bin_kernel<TB_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, big) == hipSuccess;
+        granted[di] = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess;
         asked[di] = true;
         (void)hipGetLastError();
     }
-    if (!granted[di] && a.T > 15000) return set_error(GSLIC_ERR_HIP, "tile binning: the kernels' dynamic LDS limit could not be raised");
-    GS_LAUNCH(K_TILE_HIST, tile_hist_kernel<TB_THREADS>, dim3(grid), dim3(TB_THREADS), lds, s, a);
-    const int per = (a.T + TS_THREADS - 1) / TS_THREADS;
-    const size_t slds = ((size_t)per * TS_THREADS + (size_t)per * TS_THREADS / 32 + 1) * sizeof(uint32_t);
-    GS_LAUNCH(K_TILE_HIST, tile_scan_kernel, dim3(1), dim3(TS_THREADS), slds, s, a);
-    GS_LAUNCH(K_TILE_BIN, tile_bin_kernel<TB_THREADS>, dim3(grid), dim3(TB_THREADS), lds, s, a);
+    return granted[di];
+}
+template <int TB_THREADS>
+static int launch_tile_hist_t(const TileBinArgs& a, hipStream_t s)
+{
+    static bool asked[16] = {false}, granted[16] = {false};
+    if (!big_lds(tile_hist_kernel<TB_THREADS>, asked, granted) && a.T > 15000) return set_error(GSLIC_ERR_HIP, "tile binning: the dynamic LDS limit could not be raised");
+    const unsigned block = (unsigned)(TB_THREADS * TB_ITEMS);
+    GS_LAUNCH(K_TILE_HIST, tile_hist_kernel<TB_THREADS>, dim3((a.n_cap + block - 1u) / block), dim3(TB_THREADS), (size_t)a.T * sizeof(uint32_t), s, a);
+    return GSLIC_OK;
+}
+template <int TB_THREADS>
+static int launch_tile_bin_t(const TileBinArgs& a, hipStream_t s)
+{
+    static bool asked[16] = {false}, granted[16] = {false};
+    if (!big_lds(tile_bin_kernel<TB_THREADS>, asked, granted) && a.T > 15000) return set_error(GSLIC_ERR_HIP, "tile binning: the dynamic LDS limit could not be raised");
+    const unsigned block = (unsigned)(TB_THREADS * TB_ITEMS);
+    GS_LAUNCH(K_TILE_BIN, tile_bin_kernel<TB_THREADS>, dim3((a.n_cap + block - 1u) / block), dim3(TB_THREADS), (size_t)a.T * sizeof(uint32_t), s, a);
     return GSLIC_OK;
 }
 
@@ -165,7 +170,19 @@ int launch_tile_bin(const TileBinArgs& a, hipStream_t s)
 {
     if (a.n_cap == 0 || a.T <= 0) return GSLIC_OK;
     if (a.T > GS_TILE_BIN_MAX_T) return set_error(GSLIC_ERR_INVALID_ARG, "tile binning: more than %d tiles", GS_TILE_BIN_MAX_T);
-    return a.T <= 8192 ? launch_tile_bin_t<256>(a, s) : launch_tile_bin_t<1024>(a, s);
+    // Workgroup sizes as measured at 2M / 1080p (8160 tiles; histogram 14 -> 7 us with 1024 threads, binning 55 -> 61) and at the config-5 shape
+    // (32 400 tiles, 130 KB of counters: one workgroup per CU either way — 0.36 -> 0.18 ms for the two with sixteen waves instead of four)
+    GS_TRY(launch_tile_hist_t<1024>(a, s));
+    {
+        static bool asked[16] = {false}, granted[16] = {false};
+        const int per = (a.T + TS_THREADS - 1) / TS_THREADS;
+        const size_t slds = ((size_t)per * TS_THREADS + (size_t)per * TS_THREADS / 32 + 1) * sizeof(uint32_t);
+        if (!big_lds(tile_scan_kernel, asked, granted) && slds > 60000) return set_error(GSLIC_ERR_HIP, "tile binning: the dynamic LDS limit could not be raised");
+        GS_LAUNCH(K_TILE_HIST, tile_scan_kernel, dim3(1), dim3(TS_THREADS), slds, s, a);
+    }
+    static const int forced = [] { const char* e = getenv("GSLIC_BIN_THREADS"); return e ? atoi(e) : 0; }();   // (A/B runs)
+    if (forced == 1024 || (a.T > 8192 && !(forced == 256 && a.T <= 16384))) return launch_tile_bin_t<1024>(a, s);
+    return launch_tile_bin_t<256>(a, s);
 }
 
 }  // namespace gslic
