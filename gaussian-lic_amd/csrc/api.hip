@@ -147,7 +147,7 @@ SampleState SampleState::carve(const void* base, size_t B, size_t* bytes)
 // for the host's wake-up + the next launch, and a hipMemcpyAsync + hipStreamSynchronize pair costs ~40 us of that per count
 // (measured from the kernel trace); the mailbox costs ~15.  Falls back to a stream synchronise if the word does not arrive.
 struct Mailbox {
-    volatile uint32_t* host = nullptr;  // [4]: value0, value1, seq, pad
+    volatile uint32_t* host = nullptr;  // [16]: value0, value1, seq, two extra words riding along, pad
     uint32_t* dev = nullptr;
     uint32_t seq = 0;
 };
@@ -185,15 +185,16 @@ __global__ void publish_kernel(const uint32_t* __restrict__ v0, const uint32_t* 
 {
     const uint32_t st = status ? atomicExch(status, 0u) : 0u;  // bit 0: a bounded spin-wait gave up somewhere upstream
     __hip_atomic_store(box + 0, v0 ? *v0 : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(box + 3, v2 ? *v2 : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(box + 3, v2 ? v2[0] : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(box + 4, v2 ? v2[1] : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(box + 1, (v1 ? (*v1 & 1u) : 0u) | ((st & 3u) << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(box + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// out[0] = *v0, out[1] = (*v1 & 1) | scan-timeout << 1 | scan-overflow << 2; *extra_out = *extra (an optional third word riding along)
+// out[0] = *v0, out[1] = (*v1 & 1) | scan-timeout << 1 | scan-overflow << 2; extra_out[0..1] = extra[0..1] (two optional words riding along)
 static int fetch_counts(const uint32_t* v0, const uint32_t* v1, uint32_t out[2], hipStream_t s, uint32_t* fault = nullptr,
                         const uint32_t* extra = nullptr, uint32_t* extra_out = nullptr)
 {
-    if (extra_out) *extra_out = 0;
+    if (extra_out) extra_out[0] = extra_out[1] = 0;
     int dev = 0;
     GS_HIP(hipGetDevice(&dev));
     static const bool use_mailbox = getenv("GSLIC_NO_MAILBOX") == nullptr;
@@ -230,7 +231,7 @@ static int fetch_counts(const uint32_t* v0, const uint32_t* v1, uint32_t out[2],
                 return set_error(GSLIC_ERR_HIP, "count mailbox: the publish kernel did not report");
             out[0] = m.host[0];
             out[1] = m.host[1];
-            if (extra_out) *extra_out = m.host[3];
+            if (extra_out) { extra_out[0] = m.host[3]; extra_out[1] = m.host[4]; }
             return GSLIC_OK;
         }
     }
@@ -239,7 +240,7 @@ static int fetch_counts(const uint32_t* v0, const uint32_t* v1, uint32_t out[2],
     if (v0) GS_HIP(hipMemcpyAsync(&out[0], v0, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (v1) GS_HIP(hipMemcpyAsync(&out[1], v1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (status) GS_HIP(hipMemcpyAsync(&st, status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (extra && extra_out) GS_HIP(hipMemcpyAsync(extra_out, extra, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (extra && extra_out) GS_HIP(hipMemcpyAsync(extra_out, extra, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     GS_HIP(hipStreamSynchronize(s));
     if (st) GS_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t), s));
     out[1] = (out[1] & 1u) | ((st & 3u) << 1);
@@ -364,7 +365,7 @@ __global__ void forward_status_kernel(const uint32_t* __restrict__ R, const uint
 }  // namespace gslic
 
 // GSLIC_BINNING = auto (default) | atomic | radix.  auto: per host thread and per kind of map (rows in the caller's order / rows permuted by
-// the library: tie_rank set), the path follows what the last binned forward measured — the global atomics its tile histogram needed per
+// the library: tie_rank set), the path follows what the last binned forward measured — the global atomics its binning kernel needed per
 // instance (0.08 with the rows of the 2M / 1080p scene in Morton order, 0.79 in random order; the two paths cost the same at about 0.5).  A map
 // found incoherent is probed again every 64th forward.  Capacity-mode forwards read nothing back: they follow the last measurement of the
 // thread, and before any, bin exactly when the library permuted the rows.
@@ -387,12 +388,12 @@ static bool binning_choice(int T, bool permuted, bool capacity)
     if (capacity) return false;
     return ++st.since_probe >= 64u;   // (a probe: binning_feedback resets the count)
 }
-static void binning_feedback(bool permuted, bool used_bin, uint32_t atomics, uint32_t R)
+static void binning_feedback(bool permuted, bool used_bin, uint32_t atomics, uint32_t instances)
 {
-    if (!used_bin || R < 4096u) return;
+    if (!used_bin || instances < 4096u) return;
     BinningAuto& st = t_binning[permuted ? 1 : 0];
     st.measured = 1;
-    st.coherent = (double)atomics <= 0.4 * (double)R;
+    st.coherent = (double)atomics <= 0.4 * (double)instances;
     st.since_probe = 0;
 }
 
@@ -496,6 +497,8 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
             TileBinArgs tb;
             tb.T = T; tb.n_cap = R; tb.n_dev = R_dev; tb.tile = ka.tile_keys; tb.gid = ka.gauss; tb.depth = ka.depth; tb.tie_rank = prm->tie_rank;
             tb.ranges = img.ranges; tb.binned = bin.binned(); tb.dead = bin.dead; tb.status = geom.flags;
+            tb.bucket_offsets = no_color ? nullptr : img.bucket_offsets; tb.max_contrib = img.max_contrib;   // (the bucket scan rides on the tile scan)
+            ts.long_tiles = reinterpret_cast<uint32_t*>(bin.sort_scratch);   // (the radix sort's scratch, unused on this path: at least R / 4 bytes)
             GS_TRY(launch_tile_bin(tb, s));
             DEBUG_SYNC(prm, s);
             ts.binned = bin.binned(); ts.depth = nullptr; ts.gauss_in = nullptr; ts.slot_in = nullptr;
@@ -522,16 +525,16 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
     memset(&smp, 0, sizeof(smp));
     uint32_t B = 0;
     if (!no_color) {
-        GS_TRY(launch_bucket_scan(T, img.ranges, img.bucket_offsets, img.max_contrib, s));
+        if (!use_bin) GS_TRY(launch_bucket_scan(T, img.ranges, img.bucket_offsets, img.max_contrib, s));
         if (cap) {
             B = capacity_for(cap->sample_bytes, [&](uint32_t b) { size_t n; SampleState::carve(nullptr, (size_t)b, &n); return n; });
         } else {
-            uint32_t bin_atomics = 0;
+            uint32_t bin_sample[2] = {0, 0};   // {global atomics, instances} of the binning kernel's sampled workgroups
             GS_TRY(fetch_counts(img.bucket_offsets + (T - 1), nullptr, hostbuf, s, geom.flags + GS_FLAG_FAULT,
-                                use_bin ? geom.flags + GS_FLAG_BIN_ATOMICS : nullptr, &bin_atomics));  // rasterizer_impl.cu:442
+                                use_bin ? geom.flags + GS_FLAG_BIN_ATOMICS : nullptr, bin_sample));  // rasterizer_impl.cu:442
             if (hostbuf[1] & 2u) return set_error(GSLIC_ERR_HIP, "a sort look-back / chained-scan wait timed out (device preempted?): the forward was abandoned");
             B = hostbuf[0];
-            binning_feedback(prm->tie_rank != nullptr, use_bin, bin_atomics, R);
+            binning_feedback(prm->tie_rank != nullptr, use_bin, bin_sample[0], bin_sample[1]);
         }
         size_t smp_bytes;
         SampleState::carve(nullptr, (size_t)B, &smp_bytes);

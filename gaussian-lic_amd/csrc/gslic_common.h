@@ -72,8 +72,8 @@ void prof_begin(int id, hipStream_t s);
 void prof_end(int id, hipStream_t s);
 extern bool g_prof_on;
 #define GS_FLAG_HITBITS 4   // index into GeomState::flags: set by a forward that recorded SampleState::hit
-#define GS_FLAG_BIN_ATOMICS 10   // index into GeomState::flags: global atomics of the tile histogram of this forward (sum over its blocks of the distinct
-                                 // tiles of a block: what grouping by tile without a sort costs on this map's row order — api.hip picks the path by it)
+#define GS_FLAG_BIN_ATOMICS 10   // index into GeomState::flags: [10] global atomics of a SAMPLE of the binning kernel's workgroups (their distinct tiles), [11] the
+                                 // instances of those workgroups: what grouping by tile without a sort costs on this map's row order — api.hip picks the path by it
 #define GS_FLAG_LONG 9      // index into GeomState::flags: number of tiles whose instance list is longer than the one-wave depth sort takes (radix_sort.hip)
 #define GS_FLAG_FAULT 8     // index into GeomState::flags: bit 0 a bounded look-back wait of THIS forward's scans / sorts gave up, bit 1 its instance count
                             // overflowed.  Per forward (the flags are zeroed at its start), so forwards running concurrently on several streams of
@@ -178,6 +178,8 @@ struct TileBinArgs {
     uint2* ranges;              // [T] zero on entry (preprocess_kernel); the tiles' list ranges on exit, (0, 0) for an empty tile
     uint4* binned;              // [R] out, grouped by tile: {depth bits, tie key, Gaussian id, emission slot}
     uint8_t* dead;              // optional [R]: the backward's per-slot dead flags, cleared here (a coalesced byte store riding on the pass)
+    uint32_t* bucket_offsets;   // optional [T] out: inclusive scan of the tiles' 64-entry bucket counts, and with it
+    uint32_t* max_contrib;      // [T] out: zeroed (ImageState: what launch_bucket_scan does on the radix path)
     uint32_t* status;           // device status words: a non-zero [2] (capacity overflow) makes the kernels return
 };
 static constexpr int GS_TILE_BIN_MAX_T = 36864;   // tiles the block histogram of the binning kernels holds in LDS (4 bytes each, 144 of 160 KB)

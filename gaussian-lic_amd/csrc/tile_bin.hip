@@ -10,9 +10,10 @@
 // and block.  tools/ubench/tile_binning.hip on the scene's real tile stream: histogram 14 us + binning 46 us (rows in Morton order; 51 + 153
 // in random order, where api.hip keeps the radix sort).
 //
-//   tile_hist_kernel : count[tile] += the block's count (ranges[tile].y, zero on entry); status[GS_FLAG_BIN_ATOMICS] += the block's distinct tiles
+//   tile_hist_kernel : count[tile] += the block's count (ranges[tile].y, zero on entry)
 //   tile_scan_kernel : ranges[tile] = {start, start} (the cursor), {0, 0} for an empty tile (as the reference's zeroed ranges)
-//   tile_bin_kernel  : position = atomicAdd(ranges[tile].y, the block's count) + rank; on exit ranges[tile] = {start, end}
+//   tile_bin_kernel  : position = atomicAdd(ranges[tile].y, the block's count) + rank; on exit ranges[tile] = {start, end};
+//                      every 16th block: status[GS_FLAG_BIN_ATOMICS] += its distinct tiles, [+ 1] += its instances
 #include "kernels.h"
 #include <cstdlib>
 
@@ -30,13 +31,11 @@ template <int TB_THREADS>
 __global__ __launch_bounds__(TB_THREADS) void tile_hist_kernel(const TileBinArgs a)
 {
     extern __shared__ uint32_t h[];   // [T]
-    __shared__ uint32_t red;
     if (a.status[2] != 0u) return;
     const uint32_t n = tb_count(a);
     const uint32_t b0 = blockIdx.x * (uint32_t)(TB_THREADS * TB_ITEMS);
     if (b0 >= n) return;
     for (int i = threadIdx.x; i < a.T; i += TB_THREADS) h[i] = 0u;
-    if (threadIdx.x == 0) red = 0u;
     __syncthreads();
     uint32_t t[TB_ITEMS];
 #pragma unroll
@@ -48,24 +47,20 @@ __global__ __launch_bounds__(TB_THREADS) void tile_hist_kernel(const TileBinArgs
     for (int j = 0; j < TB_ITEMS; j++)
         if (t[j] < (uint32_t)a.T) atomicAdd(&h[t[j]], 1u);
     __syncthreads();
-    uint32_t distinct = 0;
     for (int i = threadIdx.x; i < a.T; i += TB_THREADS) {
         const uint32_t c = h[i];
-        if (c) { atomicAdd(&a.ranges[i].y, c); distinct++; }
+        if (c) atomicAdd(&a.ranges[i].y, c);
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) distinct += (uint32_t)__shfl_xor((int)distinct, d, 64);
-    if ((threadIdx.x & 63) == 0 && distinct) atomicAdd(&red, distinct);
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(a.status + GS_FLAG_BIN_ATOMICS, red);
 }
 
 // One workgroup: the counts reach the threads through LDS (coalesced loads; a thread scans TS_PER consecutive tiles), the ranges leave the same way.
+// The tiles' 64-entry bucket counts are scanned on the way (perTileBucketCount + InclusiveSum, rasterizer_impl.cu:433-441) and max_contrib is
+// zeroed: what bucket_scan_kernel does on the radix path, without its launch.
 static constexpr int TS_THREADS = 1024;
 __global__ __launch_bounds__(TS_THREADS) void tile_scan_kernel(const TileBinArgs a)
 {
     extern __shared__ uint32_t c[];   // [per * TS_THREADS (+ padding)]: count of tile t at c[t + t / 32] (a thread's run starts on its own bank)
-    __shared__ uint32_t wsum[TS_THREADS / 64];
+    __shared__ uint32_t wsum[TS_THREADS / 64], wsum_b[TS_THREADS / 64];
     if (a.status[2] != 0u) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (a.T + TS_THREADS - 1) / TS_THREADS;
@@ -73,14 +68,19 @@ __global__ __launch_bounds__(TS_THREADS) void tile_scan_kernel(const TileBinArgs
     for (int t = tid; t < a.T; t += TS_THREADS) at(t) = a.ranges[t].y;
     __syncthreads();
     const int t0 = tid * per, t1 = (t0 + per) < a.T ? (t0 + per) : a.T;
-    uint32_t sum = 0;
-    for (int t = t0; t < t1; t++) sum += at(t);
-    const uint32_t inc = wave_inclusive_scan(sum);
-    if (lane == 63) wsum[wave] = inc;
+    uint32_t sum = 0, sum_b = 0;
+    for (int t = t0; t < t1; t++) { const uint32_t n = at(t); sum += n; sum_b += (n + (uint32_t)(GS_BUCKET - 1)) / (uint32_t)GS_BUCKET; }
+    const uint32_t inc = wave_inclusive_scan(sum), inc_b = wave_inclusive_scan(sum_b);
+    if (lane == 63) { wsum[wave] = inc; wsum_b[wave] = inc_b; }
     __syncthreads();
-    uint32_t start = inc - sum;
-    for (int w = 0; w < wave; w++) start += wsum[w];
-    for (int t = t0; t < t1; t++) { const uint32_t n = at(t); at(t) = n ? start : 0xffffffffu; start += n; }
+    uint32_t start = inc - sum, run_b = inc_b - sum_b;
+    for (int w = 0; w < wave; w++) { start += wsum[w]; run_b += wsum_b[w]; }
+    for (int t = t0; t < t1; t++) {
+        const uint32_t n = at(t);
+        at(t) = n ? start : 0xffffffffu;
+        start += n;
+        if (a.bucket_offsets) { run_b += (n + (uint32_t)(GS_BUCKET - 1)) / (uint32_t)GS_BUCKET; a.bucket_offsets[t] = run_b; a.max_contrib[t] = 0u; }
+    }
     __syncthreads();
     for (int t = tid; t < a.T; t += TS_THREADS) {
         const uint32_t st = at(t);
@@ -92,11 +92,13 @@ template <int TB_THREADS>
 __global__ __launch_bounds__(TB_THREADS) void tile_bin_kernel(const TileBinArgs a)
 {
     extern __shared__ uint32_t h[];   // [T]: the block's count per tile, then the tile's reserved position
+    __shared__ uint32_t n_owned;
     if (a.status[2] != 0u) return;
     const uint32_t n = tb_count(a);
     const uint32_t b0 = blockIdx.x * (uint32_t)(TB_THREADS * TB_ITEMS);
     if (b0 >= n) return;
     for (int i = threadIdx.x; i < a.T; i += TB_THREADS) h[i] = 0u;
+    if (threadIdx.x == 0) n_owned = 0u;
     __syncthreads();
     uint32_t t[TB_ITEMS], r[TB_ITEMS], g[TB_ITEMS], d[TB_ITEMS];
 #pragma unroll
@@ -121,10 +123,21 @@ __global__ __launch_bounds__(TB_THREADS) void tile_bin_kernel(const TileBinArgs 
 #pragma unroll
     for (int j = 0; j < TB_ITEMS; j++) c[j] = (r[j] == 0u && t[j] != 0xffffffffu) ? h[t[j]] : 0u;
     __syncthreads();
+    uint32_t owned = 0;
 #pragma unroll
     for (int j = 0; j < TB_ITEMS; j++)
-        if (c[j]) h[t[j]] = atomicAdd(&a.ranges[t[j]].y, c[j]);   // (one global atomic per distinct tile of the block)
+        if (c[j]) { h[t[j]] = atomicAdd(&a.ranges[t[j]].y, c[j]); owned++; }   // (one global atomic per distinct tile of the block)
+    // the path's cost on this map, for api.hip's choice: runs of rows it stores = global atomics it needed (one word per wave)
+    // (ONE word per workgroup: 5.8k atomics on one address — one per wave — took as long as the rest of the kernel, 56 -> 93 us)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) owned += (uint32_t)__shfl_xor((int)owned, d, 64);
+    if ((threadIdx.x & 63) == 0 && owned) atomicAdd(&n_owned, owned);
     __syncthreads();
+    if (threadIdx.x == 0 && (blockIdx.x & 15u) == 0u) {   // (a sample of the workgroups: every one of them adding to the same word cost the kernel 8 us of 56)
+        atomicAdd(a.status + GS_FLAG_BIN_ATOMICS, n_owned);
+        const uint32_t left = n - b0;
+        atomicAdd(a.status + GS_FLAG_BIN_ATOMICS + 1, left < (uint32_t)(TB_THREADS * TB_ITEMS) ? left : (uint32_t)(TB_THREADS * TB_ITEMS));
+    }
 #pragma unroll
     for (int j = 0; j < TB_ITEMS; j++) {
         if (t[j] == 0xffffffffu) continue;

@@ -444,7 +444,7 @@ int gslic_set_math_mode(int32_t strict);
 /* How the forward groups the (Gaussian, tile) instances by tile — the tile half of cub::DeviceRadixSort::SortPairs,
  * rasterizer_impl.cu:419-424; the lists are the reference's bit for bit on either path.  Returns the previous mode.
  * 0 = auto (default; GSLIC_BINNING=auto): block-aggregated atomics on the tiles' list cursors while the map's row order keeps consecutive
- *     Gaussians on neighbouring tiles (measured per forward: the global atomics the tile histogram needed per instance), the stable radix sort
+ *     Gaussians on neighbouring tiles (measured per forward: the global atomics the binning kernel needed per instance), the stable radix sort
  *     otherwise and above 16384 tiles;  1 = always the radix sort (GSLIC_BINNING=radix);  2 = atomics whenever the tile count allows
  *     (GSLIC_BINNING=atomic).  Any other value only reads the mode. */
 int gslic_set_binning_mode(int32_t mode);

@@ -84,7 +84,7 @@ def test_auto_mode_follows_the_row_order(binning_mode):
     """auto: rows in Morton order -> the atomic path; rows in random order -> one probing forward on it, then the radix sort"""
     from gaussian_lic_amd import _lib, trainer
     from gpu_helpers import hip_forward
-    P, W, H = 300000, 960, 540
+    P, W, H = 300000, 1920, 1080
     raw, sc, camd, cam = make_scene("random", P, W, H, 3, 3)
     order = trainer.morton_order(raw["xyz"])
     raw_m = {k: (v[order].contiguous() if torch.is_tensor(v) and v.shape[:1] == (P,) else v) for k, v in raw.items()}
