@@ -61,8 +61,14 @@ __global__ __launch_bounds__(TS_THREADS) void tile_scan_kernel(const TileBinArgs
 {
     extern __shared__ uint32_t c[];   // [per * TS_THREADS (+ padding)]: count of tile t at c[t + t / 32] (a thread's run starts on its own bank)
     __shared__ uint32_t wsum[TS_THREADS / 64], wsum_b[TS_THREADS / 64];
-    if (a.status[2] != 0u) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.status[2] != 0u) {   // capacity mode: the instances did not fit — no lists, no buckets (B = 0 reaches the status words, as on the radix path)
+        for (int t = tid; t < a.T; t += TS_THREADS) {
+            a.ranges[t] = make_uint2(0u, 0u);
+            if (a.bucket_offsets) { a.bucket_offsets[t] = 0u; a.max_contrib[t] = 0u; }
+        }
+        return;
+    }
     const int per = (a.T + TS_THREADS - 1) / TS_THREADS;
     auto at = [&](int t) -> uint32_t& { return c[t + (t >> 5)]; };
     for (int t = tid; t < a.T; t += TS_THREADS) at(t) = a.ranges[t].y;
