@@ -498,7 +498,7 @@ static constexpr int LW_PHYS = 64 * 17;
 #define GS_WAVE_ORDER() __builtin_amdgcn_wave_barrier()
 
 template <bool BINNED>
-__global__ __launch_bounds__(64) void tile_depth_sort_wave_kernel(const TileDepthSortArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void tile_depth_sort_wave_kernel(const TileDepthSortArgs a)
 {
     __shared__ uint32_t sk[2][LW_PHYS];
     __shared__ uint16_t si[2][LW_PHYS];
@@ -632,21 +632,51 @@ __global__ __launch_bounds__(64) void tile_depth_sort_wave_kernel(const TileDept
         }
         GS_WAVE_SYNC();
         if (phase == 0) {
+#ifdef GS_LSORT_NO_TIES
+            break;
+#endif
             if (!in.two_keys()) break;
             // two equal depths anywhere in the tile?  Every lane looks at its own run of the sorted list (consecutive words: no phys() arithmetic)
             // and at the first element of the next lane's run.
             uint32_t kr[16];
 #pragma unroll
             for (int j = 0; j < 16; j++) kr[j] = ((uint32_t)j < E && (uint32_t)j < mine) ? sk[cur][run0 + j] : 0u;
-            bool dup = false;
+            uint32_t pairs = 0;   // equal neighbours seen by this lane
             uint32_t last = kr[0];
 #pragma unroll
             for (int j = 1; j < 16; j++)
-                if ((uint32_t)j < E && (uint32_t)j < mine) { dup |= kr[j] == last; last = kr[j]; }
+                if ((uint32_t)j < E && (uint32_t)j < mine) { pairs += kr[j] == last ? 1u : 0u; last = kr[j]; }
             const uint32_t next_first = (uint32_t)__shfl_down((int)kr[0], 1, 64);
             const uint32_t next_mine = (uint32_t)__shfl_down((int)mine, 1, 64);
-            if (lane < 63u && mine > 0u && next_mine > 0u) dup |= last == next_first;
-            if (__ballot(dup) == 0ull) break;   // (wave-uniform)
+            if (lane < 63u && mine > 0u && next_mine > 0u && last == next_first) pairs++;
+            if (__ballot(pairs != 0u) == 0ull) break;   // (wave-uniform)
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) pairs += (uint32_t)__shfl_xor((int)pairs, d, 64);
+            // A few pairs of equal neighbours = a few SHORT runs (eight pairs: at most nine elements in a run): every run is put into tie-key order
+            // by the lane that finds its head, by insertion — a tile that sorts by both keys lives three times as long as its neighbours, and one
+            // such wave among the last to start (1.6 % of the tiles of the 2M / 1080p scene tie somewhere) kept the whole launch waiting: + 34 us.
+            if (pairs <= 8u) {
+                for (uint32_t j = lane; j + 1u < n; j += 64u) {
+                    const uint32_t k = sk[cur][phys(j)];
+                    if (sk[cur][phys(j + 1u)] != k || (j > 0u && sk[cur][phys(j - 1u)] == k)) continue;
+                    uint32_t e = j + 1u;
+                    while (e + 1u < n && sk[cur][phys(e + 1u)] == k) e++;      // run = [j, e]: this lane owns it (runs are disjoint)
+                    for (uint32_t p = j + 1u; p <= e; p++) {
+                        const uint16_t ip = si[cur][phys(p)];
+                        const uint32_t rp = in.tie(ip);
+                        uint32_t q = p;
+                        while (q > j) {
+                            const uint16_t iq = si[cur][phys(q - 1u)];
+                            if (in.tie(iq) <= rp) break;
+                            si[cur][phys(q)] = iq;
+                            q--;
+                        }
+                        si[cur][phys(q)] = ip;
+                    }
+                }
+                GS_WAVE_SYNC();
+                break;
+            }
         }
     }
     {   // the tile's Gaussian ids and emission slots in list order: every gather of the wave in flight before the first store
