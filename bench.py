@@ -59,7 +59,8 @@ def algorithmic_bytes(kernel, s):
         # grouping by tile without a sort (tile_bin.hip): the histogram reads the tile ids and the single-workgroup scan turns the counts into ranges;
         # the binning reads tile, Gaussian id, depth bits (12) and writes one 16-byte row + the cleared dead flag (1) per instance.  The per-tile
         # sort then reads rows (16) instead of three arrays (12): + 4 R on "tile_lsort", not itemised
-        "tile_hist": 4 * R + 24 * T,
+        "tile_hist": 4 * R + 8 * T,
+        "tile_scan": 24 * T,                      # counts in; ranges, bucket offsets and the zeroed max_contrib out
         "tile_bin": 29 * R,
         # list 4 + record 48 per instance of a live bucket; checkpoints 4096 (+ decision masks) per live bucket; pix_final 16/px(padded), image 16/px
         "render_fwd": 52 * Rl + (4096 + hb) * Bl + 16 * Np + 16 * N,

@@ -39,7 +39,7 @@ static bool g_prof_cur_on = false;
 static const char* const k_names[K_COUNT] = {
     "preprocess", "scan_reduce", "scan_spine", "scan_apply", "keybuild", "sort_hist", "sort_scatter", "finalize_lists",
     "bucket_count", "render_fwd", "render_bwd", "preprocess_bwd", "adam", "ssim_fwd", "ssim_bwd", "knn_minmax", "knn_morton",
-    "knn_boxes", "knn_search", "debug_export", "extend", "dsort_hist", "dsort_scatter", "sh_grad_from_rgb", "tile_lsort", "tile_hist", "tile_bin"};
+    "knn_boxes", "knn_search", "debug_export", "extend", "dsort_hist", "dsort_scatter", "sh_grad_from_rgb", "tile_lsort", "tile_hist", "tile_bin", "tile_scan", "tile_lsort_long"};
 uint32_t g_lds_pad[K_COUNT] = {0};
 static const bool g_lds_pad_parsed = [] {   // GSLIC_LDS_PAD="name=bytes,name=bytes"
     const char* e = getenv("GSLIC_LDS_PAD");

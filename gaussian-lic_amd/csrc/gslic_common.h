@@ -66,6 +66,8 @@ enum KernelId {
     K_TILE_LSORT,
     K_TILE_HIST,
     K_TILE_BIN,
+    K_TILE_SCAN,
+    K_TILE_LSORT_LONG,
     K_COUNT
 };
 void prof_begin(int id, hipStream_t s);

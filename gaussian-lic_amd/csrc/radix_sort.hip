@@ -721,10 +721,10 @@ int launch_tile_depth_sort(const TileDepthSortArgs& a, hipStream_t s)
     const dim3 lgrid((unsigned)(a.T < 512 ? a.T : 512));
     if (a.binned) {
         GS_LAUNCH(K_TILE_LSORT, tile_depth_sort_wave_kernel<true>, dim3((unsigned)a.T), dim3(64), 0, s, a);
-        GS_LAUNCH(K_TILE_LSORT, tile_depth_sort_kernel<true>, lgrid, dim3(LS_THREADS), 0, s, a);
+        GS_LAUNCH(K_TILE_LSORT_LONG, tile_depth_sort_kernel<true>, lgrid, dim3(LS_THREADS), 0, s, a);
     } else {
         GS_LAUNCH(K_TILE_LSORT, tile_depth_sort_wave_kernel<false>, dim3((unsigned)a.T), dim3(64), 0, s, a);
-        GS_LAUNCH(K_TILE_LSORT, tile_depth_sort_kernel<false>, lgrid, dim3(LS_THREADS), 0, s, a);
+        GS_LAUNCH(K_TILE_LSORT_LONG, tile_depth_sort_kernel<false>, lgrid, dim3(LS_THREADS), 0, s, a);
     }
     return GSLIC_OK;
 }

@@ -197,7 +197,7 @@ int launch_tile_bin(const TileBinArgs& a, hipStream_t s)
         const int per = (a.T + TS_THREADS - 1) / TS_THREADS;
         const size_t slds = ((size_t)per * TS_THREADS + (size_t)per * TS_THREADS / 32 + 1) * sizeof(uint32_t);
         if (!big_lds(tile_scan_kernel, asked, granted) && slds > 60000) return set_error(GSLIC_ERR_HIP, "tile binning: the dynamic LDS limit could not be raised");
-        GS_LAUNCH(K_TILE_HIST, tile_scan_kernel, dim3(1), dim3(TS_THREADS), slds, s, a);
+        GS_LAUNCH(K_TILE_SCAN, tile_scan_kernel, dim3(1), dim3(TS_THREADS), slds, s, a);
     }
     static const int forced = [] { const char* e = getenv("GSLIC_BIN_THREADS"); return e ? atoi(e) : 0; }();   // (A/B runs)
     if (forced == 1024 || (a.T > 8192 && !(forced == 256 && a.T <= 16384))) return launch_tile_bin_t<1024>(a, s);
