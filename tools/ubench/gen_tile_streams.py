@@ -1,5 +1,10 @@
+"""Writes the REAL emission-order tile streams of the 2M / 1080p bench scene for tools/ubench/tile_binning.hip: tiles_morton.bin (the map's rows in
+Morton order) and tiles_insertion.bin (rows as generated), uint32 tile id per (Gaussian, tile) instance, from the CPU oracle's preprocess + binning
+(test infrastructure; runs without a GPU in about a minute; the .bin files are git-ignored, 24 MB each).
+    python tools/ubench/gen_tile_streams.py"""
 import sys, os, numpy as np, torch, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import make_scene
 import importlib
 pkg = importlib.import_module("gaussian-lic_amd")
@@ -19,5 +24,5 @@ order = trainer.morton_order(torch.as_tensor(xyz)).numpy()      # row r of the s
 rank = np.empty(P, np.int64); rank[order] = np.arange(P)
 for name, r in (("morton", rank[gid]), ("insertion", gid)):
     idx = np.lexsort((tile, r))
-    tile[idx].astype(np.uint32).tofile(f"/root/repo/tools/ubench/tiles_{name}.bin")
+    tile[idx].astype(np.uint32).tofile(os.path.join(ROOT, "tools", "ubench", f"tiles_{name}.bin"))
     print(name, "written")
