@@ -229,17 +229,22 @@ struct ImageState {
     static ImageState carve(const void* base, size_t T, size_t* bytes);
 };
 struct BinningState {
-    uint32_t* tile_keys[2];   // [R] ping-pong: tile id of the instance
-    uint32_t* slots[2];       // [R] ping-pong payload: emission slot u (where the backward writes the instance's partials)
-    uint32_t* gauss[2];       // [R] ping-pong payload: Gaussian id; after the tile sort gauss[passes & 1] holds the ids by tile, in index order inside
-                              // a tile; the per-tile depth sort writes the point list into the OTHER side
-    uint32_t* lsort[4];       // [R] each: depth bits of the instance (third payload of the tile sort, ping-pong [0] / [1]) and the index scratch of
-                              // the per-tile depth sort ([2] / [3]).  They alias the first 16 R bytes of `partials` (dead during the forward) when
-                              // there is a backward (!no_color); a transmittance-only forward carves them
+    // Emission order -> lists, on either grouping path (api.hip: binning_choice).  pp = plan.passes & 1 names the side the lists do NOT go to.
+    //   radix path : keybuild -> tile_keys[0] / gauss[0] / lsort[0] (tile, Gaussian id, depth bits); the stable tile sort ping-pongs all of them with
+    //                the slots and leaves tile / slot / id / depth sorted by tile in tile_keys[pp] / slots[pp] / gauss[pp] / lsort[pp]; the per-tile sort's
+    //                long lists use lsort[pp ^ 1], tile_keys[pp ^ 1], lsort[2], lsort[3] as scratch
+    //   atomic path: keybuild -> tile_keys[0] / gauss[pp] / slots[pp]; tile_bin -> binned() (16-byte rows grouped by tile); the per-tile sort's long lists
+    //                use tile_keys[0], tile_keys[1], gauss[pp], slots[pp] (all dead by then) and queue their tiles in sort_scratch
+    //   both       : the per-tile sort writes the point list to gauss[pp ^ 1] and the slot list to slots[pp ^ 1]
+    uint32_t* tile_keys[2];   // [R] each
+    uint32_t* slots[2];       // [R] each: emission slot u of an instance = where the backward writes its partial row
+    uint32_t* gauss[2];       // [R] each
+    uint32_t* lsort[4];       // [R] each, CONTIGUOUS (= the 16 R bytes of binned()).  They alias the first 16 R bytes of `partials` (dead during the
+                              // forward) when there is a backward (!no_color); a transmittance-only forward carves them
     void* sort_scratch;
     float* partials;          // [9R] per emission slot: the instance's 9 partial gradients (36-byte rows), only when !no_color
     uint8_t* dead;            // [R] per emission slot: 1 = the instance lies in a bucket behind its tile's last contributor (its partial row is
-                              // NOT written and must not be read: all nine gradients are exactly zero); zeroed by finalize_ranges_kernel
+                              // NOT written and must not be read: all nine gradients are exactly zero); zeroed by finalize_ranges_kernel / tile_bin_kernel
     SortPlan plan;
     uint32_t* point_list() const { return gauss[(plan.passes & 1) ^ 1]; }    // (written by the per-tile depth sort)
     uint32_t* inst_slot() const { return slots[(plan.passes & 1) ^ 1]; }

@@ -266,9 +266,9 @@ __global__ __launch_bounds__(BS) void preprocess_kernel(PreprocessArgs a)
 
 // Thread i emits the instances of Gaussian g = i (index order, as duplicateWithKeys does: rasterizer_impl.cu:59-193) into the emission
 // slots u in [offsets[i-1], offsets[i]), tiles in row-major order: tile_keys[u] = tile, gauss[u] = g, depth[u] = the Gaussian's depth bits.
-// A STABLE sort on the tile id (radix_sort.hip) then groups the instances by tile, in index order inside a tile, and the per-tile depth
-// sort (tile_depth_sort_kernel, stable as well) puts every tile's segment into the order the reference's 64-bit (tile << 32 | depth) sort of
-// the same index-ordered emission produces (rasterizer_impl.cu:86-128, 419-424).  The slot u is also where the backward writes the
+// The instances are then grouped by tile — block-aggregated atomics (tile_bin.hip) or a STABLE sort on the tile id (radix_sort.hip) — and the
+// per-tile sort (tile_depth_sort_wave_kernel) puts every tile's segment into (depth, original index) order: the order the reference's 64-bit
+// (tile << 32 | depth) sort of the same index-ordered emission produces (rasterizer_impl.cu:86-128, 419-424).  The slot u is also where the backward writes the
 // instance's partial gradients: contiguous per Gaussian, starting at gauss_start[g].
 // (Rounds 2-4 sorted the GAUSSIANS by depth first — four passes over P, a gather scan, a depth-ordered gather of the records here — and
 // emitted in that order; the per-tile sort replaces all of it: every read of this kernel is coalesced now.)
