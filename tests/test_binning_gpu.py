@@ -35,6 +35,8 @@ CASES = [
     ("random", 40000, 320, 192, 0.0, 1.0, 4),      # no quantisation (the odd natural tie only)
     ("random", 60000, 160, 96, 0.5, 3.0, 7),       # ties in lists of thousands (the workgroup kernel: LDS and global-scratch paths)
     ("lidar", 30000, 333, 190, 0.25, 1.0, 5),      # ragged image
+    ("random", 60000, 3840, 2400, 0.0, 1.0, 9),    # 36 000 tiles: the largest LDS histogram the atomic path takes (144 KB), 1024-thread workgroups
+    ("random", 60000, 4096, 2400, 0.0, 1.0, 10),   # 38 400 tiles: beyond it — "atomic" sorts as well
 ]
 
 
