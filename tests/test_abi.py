@@ -97,3 +97,45 @@ def test_tensor_allocator_is_freed_by_refcount_alone():
         assert wr_alloc() is None and wr_box() is None
     finally:
         gc.enable()
+
+
+def test_large_scratch_requests_round_up_geometrically():
+    """A growing map must not pay a hipMalloc at every append: above 64 MB the allocator's granule is half the largest power of two in the request
+    (_lib.TensorAllocator; the C++ shim's resize callbacks have the same rule).  Sizes only: nothing this large is allocated here."""
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import _lib
+    G = _lib.TensorAllocator.GRANULE
+    seen = []
+
+    import torch
+    real_empty = torch.empty
+    try:
+        torch.empty = lambda n, **kw: (seen.append(int(n)), real_empty(0, dtype=torch.uint8))[1]
+        a = _lib.TensorAllocator(torch.device("cpu"))
+        for n in (1000, (1 << 20) + 1, 50 << 20, (64 << 20) + 1, 366 << 20, 457 << 20, 597 << 20, (1 << 30) + 5):
+            a.cb(None, n)
+    finally:
+        torch.empty = real_empty
+    assert seen[-8:] == [1000, G, 64 << 20, 96 << 20, 384 << 20, 512 << 20, 768 << 20, 3 << 29]
+    # 1.5M -> 2.0M Gaussians: the binning buffer (61 B per instance, 4.5M -> 6M instances) takes ONE size on the way, with 32 MB granules three
+    seen.clear()
+    try:
+        torch.empty = lambda n, **kw: (seen.append(int(n)), real_empty(0, dtype=torch.uint8))[1]
+        for r in range(4_500_000, 6_000_001, 50_000):
+            a.cb(None, 61 * r)
+    finally:
+        torch.empty = real_empty
+    assert len(set(seen)) == 1 and len({(61 * r + G - 1) // G for r in range(4_500_000, 6_000_001, 50_000)}) == 3
+
+
+def test_binning_mode_switch_without_gpu():
+    """gslic_set_binning_mode touches host state only: returns the previous mode, ignores values outside 0..2"""
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import _lib
+    old = _lib.set_binning_mode("radix")
+    try:
+        assert _lib.set_binning_mode("atomic") == "radix"
+        assert _lib.lib().gslic_set_binning_mode(7) == 2 and _lib.lib().gslic_set_binning_mode(-1) == 2   # (only reads the mode)
+        assert _lib.set_binning_mode("auto") == "atomic"
+    finally:
+        _lib.set_binning_mode(old)
