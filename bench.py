@@ -1183,46 +1183,68 @@ def cpu_baseline(args):
             del sc_f, st_f
         except Exception as ex:
             full = {"error": str(ex)[:200]}
-    # the oracle as the CHECKER on the sample: PSNR of the HIP image against the oracle image, maximum gradient error
+    # the oracle as the CHECKER on the sample: PSNR of the HIP image against the oracle image, maximum gradient error — on the
+    # configuration that is TIMED (round 6): trainer.GaussianModel in --map-order (default: rows in Morton order, ties broken by tie_rank), the
+    # forward / backward calls training_step_fused makes (raw parameters, activations inside the kernels), binning as the timed run has it
     parity = None
     try:
         import torch
-        from gaussian_lic_amd import rasterizer as rz
+        from gaussian_lic_amd import _lib, rasterizer as rz, trainer
         from gaussian_lic_amd.camera import synthetic_camera as _sc
         dev = torch.device("cuda", torch.cuda.current_device())
-        camo = _sc(Ws, Hs)
+        camo = _sc(Ws, Hs).to_device(dev)
         scp = to_numpy(activate(raw))
         dL = pixel_grad(Hs, Ws).numpy()
         f = orc.forward(scp, cam)
         ob = orc.backward(scp, cam, f, dL)
-        act = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in activate(raw).items()}
+        # the oracle differentiates w.r.t. the ACTIVATED parameters (as the reference's kernels): chain to the raw leaves like LibTorch's autograd
+        leaves = {k: raw[k].detach().clone().float().requires_grad_(True) for k in ("opacity", "scaling", "rotation")}
+        acts = [torch.sigmoid(leaves["opacity"]), torch.exp(leaves["scaling"]), torch.nn.functional.normalize(leaves["rotation"])]
+        torch.autograd.backward(acts, [torch.from_numpy(np.ascontiguousarray(ob[k], np.float32)).reshape(a_.shape)
+                                       for k, a_ in zip(("dL_dopacity", "dL_dscale", "dL_drot"), acts)])
+        P_s = int(raw["xyz"].shape[0])
+        oref = {"xyz": np.asarray(ob["dL_dmean3D"]).reshape(P_s, 3), "features_dc": np.asarray(ob["dL_ddc"]).reshape(P_s, 1, 3),
+                "features_rest": np.asarray(ob["dL_dsh"]).reshape(tuple(raw["features_rest"].shape)), "opacity": leaves["opacity"].grad.numpy(),
+                "scaling": leaves["scaling"].grad.numpy(), "rotation": leaves["rotation"].grad.numpy()}
+        model = trainer.GaussianModel({k: (v.clone() if torch.is_tensor(v) else v) for k, v in raw.items()}, dev, order=args.map_order)
         e = torch.empty(0, device=dev)
-        vm, pm = torch.from_numpy(camo.world_view_transform).to(dev), torch.from_numpy(camo.full_proj_transform).to(dev)
-        cp = torch.from_numpy(camo.camera_center).to(dev)
+        bg0 = torch.zeros(3, device=dev)
         lim = (float(camo.limx_neg), float(camo.limx_pos), float(camo.limy_neg), float(camo.limy_pos))
-        R, B, color, final_T, radii, geom, binning, img, sample = rz.rasterize_gaussians(
-            torch.zeros(3, device=dev), act["means"], e, act["opac"], act["scales"], act["rots"], 1.0, e, vm, pm, float(camo.tanfovx),
-            float(camo.tanfovy), Hs, Ws, *lim, act["dc"], act["shs"], act["D"], cp, False, False, False)
-        g = rz.rasterize_gaussians_backward(torch.zeros(3, device=dev), act["means"], radii, e, act["scales"], act["rots"], 1.0, e, vm, pm,
-                                            float(camo.tanfovx), float(camo.tanfovy), *lim, torch.from_numpy(dL).to(dev), act["dc"], act["shs"],
-                                            act["D"], cp, geom, R, binning, img, B, sample, 0.0, False)
+        with torch.no_grad():
+            xyz, dc_, rest = model.xyz.detach(), model.features_dc.detach(), model.features_rest.detach()
+            op, sc_, rot = model.opacity.detach(), model.scaling.detach(), model.rotation.detach()
+            R, B, color, final_T, radii, geom, binning, img, sample = rz.rasterize_gaussians(
+                bg0, xyz, e, op, sc_, rot, 1.0, e, camo.d_world_view_transform, camo.d_full_proj_transform, float(camo.tanfovx), float(camo.tanfovy),
+                Hs, Ws, *lim, dc_, rest, model.sh_degree, camo.d_camera_center, False, False, False, raw_params=True, tie_rank=model.tie_rank)
+            path = _lib.binning_path()
+            out = {n: torch.empty_like(getattr(model, n).detach()) for n in model.NAMES}
+            rz.rasterize_gaussians_backward(bg0, xyz, radii, e, sc_, rot, 1.0, e, camo.d_world_view_transform, camo.d_full_proj_transform,
+                                            float(camo.tanfovx), float(camo.tanfovy), *lim, torch.from_numpy(dL).to(dev), dc_, rest, model.sh_degree,
+                                            camo.d_camera_center, geom, R, binning, img, B, sample, 0.0, False, raw_params=True, out=out)
+        order_idx = model.original_order()
         cimg = color.cpu().numpy().astype(np.float64)
         mse = float(np.mean((cimg - f["color"].astype(np.float64)) ** 2))
         img_err = np.abs(cimg - f["color"]) / max(float(np.abs(f["color"]).max()), 1e-30)
-        names = ["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_ddc", "dL_dsh", "dL_dscale", "dL_drot"]
         worst, over, total = 0.0, 0, 0
-        for n_, t_ in zip(names, g):
-            if n_ in ob and t_ is not None and t_.numel():
-                ref = np.asarray(ob[n_], dtype=np.float64).reshape(-1)
-                got = t_.detach().cpu().numpy().astype(np.float64).reshape(-1)
-                if ref.shape == got.shape and np.abs(ref).max() > 0:
-                    err = np.abs(got - ref) / np.abs(ref).max()
-                    worst = max(worst, float(err.max()))
-                    over += int((err > 1e-4).sum()); total += err.size
+        for n_ in model.NAMES:
+            t_ = out[n_] if order_idx is None else out[n_][order_idx]
+            ref = np.asarray(oref[n_], dtype=np.float64).reshape(-1)
+            got = t_.cpu().numpy().astype(np.float64).reshape(-1)
+            if ref.shape == got.shape and np.abs(ref).max() > 0:
+                scale = np.abs(ref).max()
+                if n_ == "rotation":   # (gradient w.r.t. the raw quaternion: the scale of the chain it belongs to, as the tests)
+                    scale = max(scale, float(np.abs(oref["scaling"]).max()))
+                err = np.abs(got - ref) / scale
+                worst = max(worst, float(err.max()))
+                over += int((err > 1e-4).sum()); total += err.size
         parity = {"psnr_image_vs_oracle_db": round(10.0 * np.log10(1.0 / max(mse, 1e-30)), 1), "image_max_rel_err": float(f"{img_err.max():.2e}"),
                   "image_elements_over_1e-4": int((img_err > 1e-4).sum()), "grad_max_rel_err": float(f"{worst:.2e}"),
                   "grad_elements_over_1e-4": over, "grad_elements": total, "instances_equal": int(R) == int(f["num_rendered"]),
-                  "note": "the library's default (strict) arithmetic of the blend kernels unless GSLIC_FAST_MATH=1; relative to the tensor's max-abs"}
+                  "configuration": {"map_order": args.map_order, "tie_rank": model.tie_rank is not None, "binning_path": path[0],
+                                    "calls": "rasterize_gaussians / _backward with raw_params, as trainer.training_step_fused"},
+                  "note": "the TIMED configuration on the 1/16 sample against the C oracle: the library's default (strict) arithmetic of the blend kernels unless "
+                          "GSLIC_FAST_MATH=1; six parameter gradients w.r.t. the raw leaves, un-permuted; relative to the tensor's max-abs.  The full-size "
+                          "comparison with the reference's own kernels is tests/test_timed_path_reference_gpu.py"}
     except Exception as ex:  # the baseline leg must never take the bench line down
         parity = {"error": str(ex)[:200]}
     # BASELINE config 1 exactly: 10k random Gaussians, 640x480, SH degree 0 — the reference's own CPU-runnable case

@@ -41,7 +41,7 @@ EXPORTS = [
     "gslic_profile_kernel_name", "gslic_profile_get", "gslic_debug_export", "gslic_extend_select", "gslic_extend_emit", "gslic_loss_partials_count", "gslic_l1_ssim_loss_forward", "gslic_l1_ssim_loss_forward_backward",
     "gslic_l1_ssim_loss_backward", "gslic_set_math_mode", "gslic_set_binning_mode", "gslic_rasterize_forward_capacity", "gslic_rasterize_backward_rgb",
     "gslic_rasterize_backward_rgb_rows", "gslic_sh_grad_from_rgb", "gslic_sh_grad_from_rgb_adam", "gslic_rasterize_backward_rgb_payload",
-    "gslic_sh_grad_from_rgb_adam_all",
+    "gslic_sh_grad_from_rgb_adam_all", "gslic_get_binning_path", "gslic_scratch_round_up",
 ]
 
 _lib = None
@@ -109,7 +109,10 @@ def lib():
     L.gslic_l1_ssim_loss_forward_backward.argtypes = [i32, i32, i32, i32, f32, f32, f32] + [vp] * 8 + [vp]
     L.gslic_set_math_mode.argtypes = [i32]
     L.gslic_set_binning_mode.argtypes = [i32]
-    if L.gslic_abi_version() != 7:
+    L.gslic_get_binning_path.argtypes = [ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    L.gslic_scratch_round_up.restype = ctypes.c_size_t
+    L.gslic_scratch_round_up.argtypes = [ctypes.c_size_t]
+    if L.gslic_abi_version() != 8:
         raise GslicError("libgslic_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -126,6 +129,14 @@ def set_binning_mode(mode):
     Returns the previous mode's name."""
     names = ("auto", "radix", "atomic")
     return names[lib().gslic_set_binning_mode(names.index(mode))]
+
+
+def binning_path():
+    """gslic_get_binning_path: ("none" | "radix" | "atomic", sampled global atomics, sampled instances) of the calling thread's last forward
+    that had instances — which grouping ran, and what `auto` decides on (atomics <= 0.4 * instances keeps the atomic path)."""
+    a, n = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    path = lib().gslic_get_binning_path(ctypes.byref(a), ctypes.byref(n))
+    return ("none", "radix", "atomic")[path], a.value, n.value
 
 
 def check(rc):
@@ -159,21 +170,18 @@ class TensorAllocator:
     """Allocator callback backed by torch's caching allocator — the role of resizeFunctional
     (rasterize_points.cu:40-48): one growable uint8 tensor per scratch buffer.  Freed by reference counting alone."""
 
-    GRANULE = 32 << 20  # large requests are rounded up so that step-to-step drift of R / B (the Gaussians move)
-                        # keeps hitting the same cached block instead of forcing a fresh hipMalloc; above 64 MB the granule is half the
-                        # largest power of two in the request (366 MB -> 384, 457 -> 512): a map that GROWS (extend() every few iterations)
-                        # crosses a granule once per 1.3x of growth instead of at every append — a hipMalloc is milliseconds, a step is 1.8
+    GRANULE = 32 << 20  # large requests are rounded up (gslic_scratch_round_up: the rule lives in the library, the C++ shim's callbacks call it too) so
+                        # that step-to-step drift of R / B (the Gaussians move) keeps hitting the same cached block instead of forcing a fresh
+                        # hipMalloc; above 64 MB the granule is min(half the largest power of two in the request, 256 MB) (366 MB -> 384, 457 -> 512,
+                        # 2.1 GB -> 2.25): a map that GROWS (extend() every few iterations) crosses a granule once per ~1.3x of growth instead of
+                        # at every append — a hipMalloc is milliseconds, a step is 1.8 — and a large map does not over-allocate by half
 
     def __init__(self, device):
         box = self._box = _AllocBox(device)
-        granule = self.GRANULE
+        round_up = lib().gslic_scratch_round_up
 
         def _alloc(_ctx, nbytes):
-            n = int(nbytes)
-            if n > (1 << 20):
-                g = granule if n <= (64 << 20) else max(granule, (1 << (n.bit_length() - 1)) >> 1)
-                n = (n + g - 1) // g * g
-            box.tensor = torch.empty(n, dtype=torch.uint8, device=box.device)
+            box.tensor = torch.empty(int(round_up(int(nbytes))), dtype=torch.uint8, device=box.device)
             return box.tensor.data_ptr()
 
         self.cb = ALLOC_FN(_alloc)

@@ -3,6 +3,7 @@
 // CudaRasterizer::Rasterizer::forward/backward (rasterizer_impl.cu:312-581); kernels live in the other .hip files.
 #include "gslic_common.h"
 #include "kernels.h"
+#include <atomic>
 #include <chrono>
 
 #include <stdarg.h>
@@ -369,29 +370,48 @@ __global__ void forward_status_kernel(const uint32_t* __restrict__ R, const uint
 // instance (0.08 with the rows of the 2M / 1080p scene in Morton order, 0.79 in random order; the two paths cost the same at about 0.5).  A map
 // found incoherent is probed again every 64th forward.  Capacity-mode forwards read nothing back: they follow the last measurement of the
 // thread, and before any, bin exactly when the library permuted the rows.
-struct BinningAuto { int measured = 0; bool coherent = true; uint32_t since_probe = 0; };
+struct BinningAuto { int measured = 0; bool coherent = true; uint32_t since_probe = 0; uint32_t epoch = 0; };
 static thread_local BinningAuto t_binning[2];
-static int g_binning_mode = [] {
+static thread_local int t_last_path = GSLIC_BINNING_PATH_NONE;       // gslic_get_binning_path
+static thread_local uint32_t t_last_sample[2] = {0u, 0u};
+// The mode is process-wide and may be set while other host threads run forwards: an atomic, and an epoch that makes every thread drop what it
+// measured under the previous mode (round 5 reset the calling thread's state only).
+static std::atomic<int> g_binning_mode{[] {
     const char* e = getenv("GSLIC_BINNING");
     if (e && strcmp(e, "radix") == 0) return 1;
     if (e && strcmp(e, "atomic") == 0) return 2;
     return 0;
-}();
-static int binning_mode() { return g_binning_mode; }
-static bool binning_choice(int T, bool permuted, bool capacity)
+}()};
+static std::atomic<uint32_t> g_binning_epoch{0u};
+static BinningAuto& binning_state(bool permuted)
 {
-    if (T > gslic::GS_TILE_BIN_MAX_T || binning_mode() == 1) return false;
-    if (binning_mode() == 2) return true;
     BinningAuto& st = t_binning[permuted ? 1 : 0];
-    if (!st.measured) return capacity ? permuted : true;
-    if (st.coherent) return true;
-    if (capacity) return false;
-    return ++st.since_probe >= 64u;   // (a probe: binning_feedback resets the count)
+    const uint32_t ep = g_binning_epoch.load(std::memory_order_acquire);
+    if (st.epoch != ep) { st = BinningAuto(); st.epoch = ep; }
+    return st;
+}
+// 1 = block-aggregated atomics, 0 = the radix sort, < 0 = an error code (the atomic path was forced and the device cannot run it)
+static int binning_choice(int T, bool permuted, bool capacity)
+{
+    const int mode = g_binning_mode.load(std::memory_order_relaxed);
+    if (T > gslic::GS_TILE_BIN_MAX_T || mode == 1) return 0;
+    if (!gslic::tile_bin_lds_ok(T)) {   // more than 64 KB of dynamic LDS asked for and refused: same lists from the sort
+        if (mode == 2) return set_error(GSLIC_ERR_HIP, "GSLIC_BINNING=atomic: the device does not grant the %d-tile histogram's dynamic LDS", T);
+        return 0;
+    }
+    if (mode == 2) return 1;
+    BinningAuto& st = binning_state(permuted);
+    if (!st.measured) return (capacity ? permuted : true) ? 1 : 0;
+    if (st.coherent) return 1;
+    if (capacity) return 0;
+    return ++st.since_probe >= 64u ? 1 : 0;   // (a probe: binning_feedback resets the count)
 }
 static void binning_feedback(bool permuted, bool used_bin, uint32_t atomics, uint32_t instances)
 {
+    t_last_sample[0] = used_bin ? atomics : 0u;
+    t_last_sample[1] = used_bin ? instances : 0u;
     if (!used_bin || instances < 4096u) return;
-    BinningAuto& st = t_binning[permuted ? 1 : 0];
+    BinningAuto& st = binning_state(permuted);
     st.measured = 1;
     st.coherent = (double)atomics <= 0.4 * (double)instances;
     st.since_probe = 0;
@@ -479,8 +499,12 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
 
     // How the instances get grouped by tile (same lists either way, bit for bit): block-aggregated atomics on the tiles' cursors (tile_bin.hip) when
     // the map's row order keeps a block's instances on few tiles, the stable radix sort on the tile id otherwise (and above GS_TILE_BIN_MAX_T tiles).
-    const bool use_bin = R > 0 && binning_choice(T, prm->tie_rank != nullptr, cap != nullptr);
+    const int bin_choice = R > 0 ? binning_choice(T, prm->tie_rank != nullptr, cap != nullptr) : 0;
+    if (bin_choice < 0) return bin_choice;
+    const bool use_bin = bin_choice == 1;
     if (R > 0) {
+        t_last_path = use_bin ? GSLIC_BINNING_PATH_ATOMIC : GSLIC_BINNING_PATH_RADIX;
+        t_last_sample[0] = t_last_sample[1] = 0u;
         const int pp = bin.plan.passes & 1;   // the lists go to gauss[pp ^ 1] / slots[pp ^ 1] on either path (BinningState::point_list())
         KeybuildArgs ka;
         ka.P = P; ka.gx = gx; ka.gy = gy; ka.rec = geom.rec; ka.order = nullptr; ka.offsets = geom.point_offsets;
@@ -565,13 +589,28 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
 extern "C" {
 int gslic_set_binning_mode(int32_t mode)
 {
-    const int old = g_binning_mode;
-    if (mode >= 0 && mode <= 2) {
-        g_binning_mode = mode;
-        t_binning[0] = BinningAuto();
-        t_binning[1] = BinningAuto();
-    }
+    if (mode < 0 || mode > 2) return g_binning_mode.load(std::memory_order_relaxed);
+    const int old = g_binning_mode.exchange(mode, std::memory_order_relaxed);
+    g_binning_epoch.fetch_add(1u, std::memory_order_release);   // every thread's BinningAuto starts over (binning_state)
     return old;
+}
+int gslic_get_binning_path(uint32_t* sampled_atomics, uint32_t* sampled_instances)
+{
+    if (sampled_atomics) *sampled_atomics = t_last_sample[0];
+    if (sampled_instances) *sampled_instances = t_last_sample[1];
+    return t_last_path;
+}
+size_t gslic_scratch_round_up(size_t n)
+{
+    if (n <= (size_t(1) << 20)) return n;
+    size_t g = size_t(32) << 20;
+    if (n > (size_t(64) << 20)) {
+        size_t p = 1;
+        while ((p << 1) <= n && (p << 1) != 0) p <<= 1;
+        const size_t half = p >> 1, cap = size_t(256) << 20;
+        g = half > cap ? cap : (half > g ? half : g);
+    }
+    return (n + g - 1) / g * g;
 }
 int gslic_rasterize_forward(const gslic_raster_params* prm, gslic_alloc_fn geom_alloc, void* geom_ctx, gslic_alloc_fn binning_alloc,
                             void* binning_ctx, gslic_alloc_fn img_alloc, void* img_ctx, gslic_alloc_fn sample_alloc,

@@ -186,6 +186,7 @@ struct TileBinArgs {
 };
 static constexpr int GS_TILE_BIN_MAX_T = 36864;   // tiles the block histogram of the binning kernels holds in LDS (4 bytes each, 144 of 160 KB)
 int launch_tile_bin(const TileBinArgs& a, hipStream_t s);
+bool tile_bin_lds_ok(int T);   // the device grants the dynamic LDS the binning kernels need at T tiles (asked once per device)
 
 struct TileDepthSortArgs {
     int T;

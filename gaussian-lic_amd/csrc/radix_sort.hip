@@ -494,8 +494,9 @@ static constexpr int LW_CAP = 1024;
 static constexpr int LW_PHYS = 64 * 17;
 #define GS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 // LDS accesses of ONE wave execute in program order, an instruction at a time for all its lanes: lane A's write is seen by lane B's later read
-// without a wait of its own.  GS_WAVE_ORDER() only keeps the COMPILER from moving accesses across it.
-#define GS_WAVE_ORDER() __builtin_amdgcn_wave_barrier()
+// without a wait of its own.  GS_WAVE_ORDER() keeps the COMPILER from moving accesses across it — a wavefront-scope fence plus the barrier, like
+// the key build and the scans (the bare barrier intrinsic is not a memory fence for IR-level passes: ADVICE round 5); no instruction either way.
+#define GS_WAVE_ORDER() GS_WAVE_SYNC()
 
 template <bool BINNED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void tile_depth_sort_wave_kernel(const TileDepthSortArgs a)

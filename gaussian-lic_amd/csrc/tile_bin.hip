@@ -15,6 +15,7 @@
 //   tile_bin_kernel  : position = atomicAdd(ranges[tile].y, the block's count) + rank; on exit ranges[tile] = {start, end};
 //                      every 16th block: status[GS_FLAG_BIN_ATOMICS] += its distinct tiles, [+ 1] += its instances
 #include "kernels.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace gslic {
@@ -152,25 +153,31 @@ __global__ __launch_bounds__(TB_THREADS) void tile_bin_kernel(const TileBinArgs 
     }
 }
 
-// (more than 64 KB of dynamic LDS per workgroup has to be asked for, once per kernel and device)
-template <typename K>
-static bool big_lds(K kernel, bool (&asked)[16], bool (&granted)[16])
+// More than 64 KB of dynamic LDS per workgroup has to be asked for, once per kernel and device.  ONE query per device covers the four kernels
+// (state per device: 0 = not asked, 1 = granted, 2 = refused; atomics — host threads may race to ask, the answer is the same).
+static constexpr int TB_BIG_LDS_T = 14336;   // tiles above which the scan's padded counters (and, from 15 000, the histograms) pass 60 000 bytes
+static std::atomic<int> g_big_lds[16];
+bool tile_bin_lds_ok(int T)
 {
+    if (T <= TB_BIG_LDS_T) return true;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    const int di = dev >= 0 && dev < 16 ? dev : 0;
-    if (!asked[di] || dev != di) {
-        granted[di] = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess;
-        asked[di] = true;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return false; }
+    int st = g_big_lds[dev].load(std::memory_order_acquire);
+    if (st == 0) {
+        const int want = 160 * 1024 - 256;
+        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bin_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bin_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(tile_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
         (void)hipGetLastError();
+        st = ok ? 1 : 2;
+        g_big_lds[dev].store(st, std::memory_order_release);
     }
-    return granted[di];
+    return st == 1;
 }
 template <int TB_THREADS>
 static int launch_tile_hist_t(const TileBinArgs& a, hipStream_t s)
 {
-    static bool asked[16] = {false}, granted[16] = {false};
-    if (!big_lds(tile_hist_kernel<TB_THREADS>, asked, granted) && a.T > 15000) return set_error(GSLIC_ERR_HIP, "tile binning: the dynamic LDS limit could not be raised");
     const unsigned block = (unsigned)(TB_THREADS * TB_ITEMS);
     GS_LAUNCH(K_TILE_HIST, tile_hist_kernel<TB_THREADS>, dim3((a.n_cap + block - 1u) / block), dim3(TB_THREADS), (size_t)a.T * sizeof(uint32_t), s, a);
     return GSLIC_OK;
@@ -178,8 +185,6 @@ static int launch_tile_hist_t(const TileBinArgs& a, hipStream_t s)
 template <int TB_THREADS>
 static int launch_tile_bin_t(const TileBinArgs& a, hipStream_t s)
 {
-    static bool asked[16] = {false}, granted[16] = {false};
-    if (!big_lds(tile_bin_kernel<TB_THREADS>, asked, granted) && a.T > 15000) return set_error(GSLIC_ERR_HIP, "tile binning: the dynamic LDS limit could not be raised");
     const unsigned block = (unsigned)(TB_THREADS * TB_ITEMS);
     GS_LAUNCH(K_TILE_BIN, tile_bin_kernel<TB_THREADS>, dim3((a.n_cap + block - 1u) / block), dim3(TB_THREADS), (size_t)a.T * sizeof(uint32_t), s, a);
     return GSLIC_OK;
@@ -191,12 +196,12 @@ int launch_tile_bin(const TileBinArgs& a, hipStream_t s)
     if (a.T > GS_TILE_BIN_MAX_T) return set_error(GSLIC_ERR_INVALID_ARG, "tile binning: more than %d tiles", GS_TILE_BIN_MAX_T);
     // Workgroup sizes as measured at 2M / 1080p (8160 tiles; histogram 14 -> 7 us with 1024 threads, binning 55 -> 61) and at the config-5 shape
     // (32 400 tiles, 130 KB of counters: one workgroup per CU either way — 0.36 -> 0.18 ms for the two with sixteen waves instead of four)
+    // (api.hip's binning_choice only comes here when the device grants the LDS these launches ask for; a direct caller is told)
+    if (!tile_bin_lds_ok(a.T)) return set_error(GSLIC_ERR_HIP, "tile binning: the dynamic LDS limit could not be raised");
     GS_TRY(launch_tile_hist_t<1024>(a, s));
     {
-        static bool asked[16] = {false}, granted[16] = {false};
         const int per = (a.T + TS_THREADS - 1) / TS_THREADS;
         const size_t slds = ((size_t)per * TS_THREADS + (size_t)per * TS_THREADS / 32 + 1) * sizeof(uint32_t);
-        if (!big_lds(tile_scan_kernel, asked, granted) && slds > 60000) return set_error(GSLIC_ERR_HIP, "tile binning: the dynamic LDS limit could not be raised");
         GS_LAUNCH(K_TILE_SCAN, tile_scan_kernel, dim3(1), dim3(TS_THREADS), slds, s, a);
     }
     static const int forced = [] { const char* e = getenv("GSLIC_BIN_THREADS"); return e ? atoi(e) : 0; }();   // (A/B runs)

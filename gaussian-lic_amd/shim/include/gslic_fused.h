@@ -69,7 +69,13 @@ public:
     // memory) passes the rows' ORIGINAL indices (device int32 [P]): the forward then lists Gaussians of equal depth in the original order, as the
     // reference's stable sort does (gslic_raster_params.tie_rank), and the map renders / trains bit-identically to the unpermuted one.
     // Rows appended by extend() get their row index.
-    void set_tie_rank(torch::Tensor original_index) { tie_ = original_index.to(torch::kInt32).contiguous(); }
+    void set_tie_rank(torch::Tensor original_index)
+    {
+        TORCH_CHECK(original_index.defined() && original_index.device() == prm_[0].device() && original_index.numel() == prm_[0].size(0),
+                    "FusedStep::set_tie_rank: expected one index per Gaussian (", prm_[0].size(0), ") on the model's device; got ", original_index.numel(),
+                    " on ", original_index.device());   // (its data pointer goes straight to the kernels)
+        tie_ = original_index.to(torch::kInt32).contiguous();
+    }
 
     // extend() of gaussian.cpp:499-638 for one new LiDAR frame: transmittance-only render of `cam` (no_color, :501-507), device-side
     // selection of the points that land on not-yet-opaque pixels (nearest per pixel, gslic_extend_select), append of the new Gaussians'

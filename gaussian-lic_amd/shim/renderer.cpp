@@ -27,20 +27,10 @@ using torch::autograd::tensor_list;
 inline const float* fp(const torch::Tensor& t) { return t.numel() ? t.data_ptr<float>() : nullptr; }
 inline char* bp(const torch::Tensor& t) { return t.numel() ? reinterpret_cast<char*>(t.data_ptr()) : nullptr; }
 inline void check(int rc, const char* what) { TORCH_CHECK(rc == GSLIC_OK, what, " failed (", rc, "): ", gslic_last_error()); }
-// Large scratch requests are rounded up — 32 MB granules, above 64 MB half the largest power of two in the request — so that the caching
-// allocator keeps serving the same block while R and B drift, and a GROWING map (extend() every few iterations) pays a hipMalloc once per 1.3x
-// of growth instead of at almost every append (gaussian-lic_amd/_lib.py: TensorAllocator has the same rule).
-inline size_t scratch_round_up(size_t n)
-{
-    if (n <= (size_t(1) << 20)) return n;
-    size_t g = size_t(32) << 20;
-    if (n > (size_t(64) << 20)) {
-        size_t p = 1;
-        while ((p << 1) <= n) p <<= 1;
-        g = (p >> 1) > g ? (p >> 1) : g;
-    }
-    return (n + g - 1) / g * g;
-}
+// Large scratch requests are rounded up by the library's rule (gslic_scratch_round_up, include/gslic_hip.h: 32 MB granules, above 64 MB
+// min(half the largest power of two in the request, 256 MB)), so that the caching allocator keeps serving the same block while R and B drift
+// and a growing map pays a hipMalloc once per ~1.3x of growth; _lib.TensorAllocator calls the same function.
+inline size_t scratch_round_up(size_t n) { return gslic_scratch_round_up(n); }
 // resizeFunctional of rasterize_points.cu:40-48: the callback grows one byte tensor and returns its storage
 char* resize_cb(void* ctx, size_t n)
 {

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSLIC_ABI_VERSION 7
+#define GSLIC_ABI_VERSION 8
 
 typedef enum gslic_status {
     GSLIC_OK = 0,
@@ -445,9 +445,28 @@ int gslic_set_math_mode(int32_t strict);
  * rasterizer_impl.cu:419-424; the lists are the reference's bit for bit on either path.  Returns the previous mode.
  * 0 = auto (default; GSLIC_BINNING=auto): block-aggregated atomics on the tiles' list cursors while the map's row order keeps consecutive
  *     Gaussians on neighbouring tiles (measured per forward: the global atomics the binning kernel needed per instance), the stable radix sort
- *     otherwise and above 16384 tiles;  1 = always the radix sort (GSLIC_BINNING=radix);  2 = atomics whenever the tile count allows
- *     (GSLIC_BINNING=atomic).  Any other value only reads the mode. */
+ *     otherwise, above 36864 tiles (the block histogram's 144 KB of LDS) and on a device / driver that does not grant a kernel more than
+ *     64 KB of dynamic LDS while the image has more than 14336 tiles;  1 = always the radix sort (GSLIC_BINNING=radix);  2 = atomics
+ *     whenever the tile count allows (GSLIC_BINNING=atomic: a refused LDS grant is then an error, GSLIC_ERR_HIP, instead of a fallback).
+ *     Any other value only reads the mode.  Process-wide: the mode is atomic, and setting it makes EVERY host thread forget what its last
+ *     forwards measured (ABI 8; until ABI 7 only the calling thread's state was reset). */
 int gslic_set_binning_mode(int32_t mode);
+
+/* Which grouping the calling thread's LAST forward with at least one instance took (ABI 8): GSLIC_BINNING_PATH_NONE before any,
+ * _RADIX (sort_hist / sort_scatter / finalize_ranges launches) or _ATOMIC (tile_hist / tile_scan / tile_bin launches).  sampled_atomics /
+ * sampled_instances (either may be NULL): what the binning kernel's sampled workgroups reported for that forward — global atomics and
+ * instances; `auto` keeps the atomic path while atomics <= 0.4 * instances.  Zero on the radix path and in capacity mode (nothing is read back). */
+#define GSLIC_BINNING_PATH_NONE 0
+#define GSLIC_BINNING_PATH_RADIX 1
+#define GSLIC_BINNING_PATH_ATOMIC 2
+int gslic_get_binning_path(uint32_t* sampled_atomics, uint32_t* sampled_instances);
+
+/* The size a host allocator should round a scratch request of `bytes` up to (ABI 8; the allocator callbacks of this repository's hosts —
+ * _lib.TensorAllocator, the LibTorch shim's resize callbacks — all call it): requests above 1 MB go to 32 MB granules, above 64 MB to
+ * granules of min(half the largest power of two in the request, 256 MB).  A caching allocator then keeps serving the same block while R and B
+ * drift from step to step, a GROWING map pays a hipMalloc once per ~1.3x of growth below 512 MB, and the over-allocation stays below 50 % up
+ * to 512 MB and below 256 MB beyond (a 2.1 GB request becomes 2.25 GB, not 3). */
+size_t gslic_scratch_round_up(size_t bytes);
 
 /* Sizes the four scratch buffers would need, for hosts that prefer to pre-size (bytes incl. slack). */
 size_t gslic_geom_bytes(int32_t P);

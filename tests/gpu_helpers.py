@@ -14,14 +14,16 @@ def settings_from(cam, deg, dev, no_color=False, lambda_erank=0.0, debug=False, 
         torch.from_numpy(cam.camera_center).to(dev), False, debug, no_color, lambda_erank)
 
 
-def hip_forward(raw, cam, no_color=False, export=(), debug=False, scale_modifier=1.0):
+def hip_forward(raw, cam, no_color=False, export=(), debug=False, scale_modifier=1.0, tie_rank=None):
+    """tie_rank: int32 device tensor [P] — the rows' original indices when `raw` holds the map's rows in a permuted order
+    (gslic_raster_params.tie_rank: what trainer.GaussianModel(order="morton") passes)."""
     dev = torch.device("cuda:0")
     act = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in activate(raw).items()}
     rs = settings_from(cam, act["D"], dev, no_color, debug=debug, scale_modifier=scale_modifier)
     empty = torch.empty(0, device=dev)
     out = rz.rasterize_gaussians(rs.bg, act["means"], empty, act["opac"], act["scales"], act["rots"], rs.scale_modifier, empty, rs.viewmatrix,
                                  rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, rs.limx_neg, rs.limx_pos,
-                                 rs.limy_neg, rs.limy_pos, act["dc"], act["shs"], act["D"], rs.campos, False, debug, no_color)
+                                 rs.limy_neg, rs.limy_pos, act["dc"], act["shs"], act["D"], rs.campos, False, debug, no_color, tie_rank=tie_rank)
     R, B, color, final_T, radii, geom, binning, img, sample = out
     res = dict(R=R, B=B, color=color, final_T=final_T, radii=radii, bufs=(geom, binning, img, sample), act=act, rs=rs)
     if export:

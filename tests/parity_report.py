@@ -32,9 +32,14 @@ def main():
     ap.add_argument("--no-ref-contract", action="store_true", help="skip the reference-vs-reference (contraction on / off) yardstick column")
     ap.add_argument("--poses", action="store_true", help="2M Gaussians / 1920x1080 at the eight config-4 views and the four general SE(3) poses of "
                                                          "camera.SE3_POSES, a clamp-masked case and two scale_modifier cases; one line per view")
+    ap.add_argument("--timed-path", action="store_true", help="round 6: the configuration bench.py times (rows in Morton order + tie_rank, atomic binning forced, "
+                                                              "fused step) against the reference's kernels at full size: the cases of "
+                                                              "tests/test_timed_path_reference_gpu.py as a table, the path taken printed per case")
     args = ap.parse_args()
     if args.poses:
         return poses(args)
+    if args.timed_path:
+        return timed_path(args)
     from oracle.ref_build import refkernels
     from refcompare import compare, compare_reference_builds, summarize, summarize_reference_builds
     results = {}
@@ -50,6 +55,36 @@ def main():
             print(summarize_reference_builds(res["ref_contract"]), flush=True)
         os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
         json.dump(results, open(args.out, "w"), indent=1)
+
+
+def timed_path(args):
+    """What tests/test_timed_path_reference_gpu.py asserts, printed: per case the grouping that was forced AND the one that ran (gslic_get_binning_path,
+    launch counts of both paths' kernels), the row order, and every parity count; then the fused step on the Morton model against the reference chain."""
+    from refcompare import GRADS, compare, summarize
+    from test_timed_path_reference_gpu import CASES, fused_step_vs_reference_chain, summarize_fused
+    results, rows = {}, []
+    for name, scene, view, binning, morton in CASES:
+        t0 = time.time()
+        res = compare(*scene, modes=("strict",), view=view, binning=binning, morton=morton)
+        res["seconds"] = round(time.time() - t0, 1)
+        results[name] = res
+        print(f"== {name} ({res['seconds']} s)\n" + summarize(res), flush=True)
+        rows.append((name, res))
+    print("\n| case | binning forced -> path taken (launches atomic / radix kernels) | rows | visible | instances R | integer stages + lists + ranges + geometry + SH colour | "
+          "image / final_T / n_contrib | gradient elements over 1e-4 | max gradient error |\n|---|---|---|---|---|---|---|---|---|")
+    for name, res in rows:
+        st = res["strict"]
+        ints = (st["radii_mismatch"] == 0 and st["tiles_touched_mismatch"] == 0 and st["point_list_equal"] and st["ranges_equal"] and
+                all(st[k + "_bit_equal"] for k in ("means2D", "depths", "conic_opacity", "rgb")))
+        img = st["color"]["bit_equal"] and st["final_T"]["bit_equal"] and st["n_contrib_mismatch"] == 0
+        print(f"| {name} | {res['scene']['binning']} -> {st['binning_path']} ({st['path_launches']['atomic']} / {st['path_launches']['radix']}) | "
+              f"{'Morton + tie_rank' if res['scene']['morton'] else 'insertion'} | {res['ref']['visible']} | {res['ref']['R']} | {'bit-identical' if ints else 'DIFFERENT'} | "
+              f"{'bit-identical' if img else 'DIFFERENT'} | {sum(st[k]['over'] for k in GRADS)} | {max(st[k]['max_rel'] for k in GRADS):.1e} |", flush=True)
+    fused = fused_step_vs_reference_chain()
+    results["fused_step_vs_reference_chain"] = fused
+    print("\n" + summarize_fused(fused), flush=True)
+    os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+    json.dump(results, open(args.out, "w"), indent=1, default=str)
 
 
 def poses(args):

@@ -51,65 +51,116 @@ def conditioning_probe(st, sc, camd, dL, scale_modifier, lambda_erank=0.0):
             st[k].pop("_over_idx", None); st[k].pop("_scale", None)
 
 
-def compare(kind, P, W, H, deg, seed, modes=("fast", "strict"), backward=True, view=None, sigma_scale=1.0, scale_modifier=1.0):
+PATH_KERNELS = {"atomic": ("tile_hist", "tile_scan", "tile_bin"), "radix": ("sort_hist", "sort_scatter", "finalize_lists")}
+
+
+def compare(kind, P, W, H, deg, seed, modes=("fast", "strict"), backward=True, view=None, sigma_scale=1.0, scale_modifier=1.0, binning="radix", morton=False):
     """Returns {"scene":…, "ref": {...unit counts}, "<mode>": {stage: stats}}.  P must be a multiple of 256 (with a partial last block
     the reference's duplicateWithKeys races pad keys over the last Gaussian's slots, rasterizer_impl.cu:73-131).
     view / sigma_scale: conftest.make_scene (camera pose: identity, a config-4 view, a general SE(3) pose; extent of the Gaussians);
-    scale_modifier: the rasterizer setting of renderer.h:36 / forward.cu:120-149, passed to both sides."""
+    scale_modifier: the rasterizer setting of renderer.h:36 / forward.cu:120-149, passed to both sides.
+    binning: "radix" | "atomic" — how the HIP forward groups the instances by tile, FORCED (gslic_set_binning_mode; never `auto`, whose choice
+    depends on what the thread's earlier forwards measured) and then VERIFIED: st["binning_path"] is what gslic_get_binning_path reports and
+    st["path_launches"] the launch counts of the two paths' kernels from the library's profiler — the caller asserts on them.
+    morton: the HIP side gets the map's rows PERMUTED into Morton order (trainer.morton_order) with tie_rank = the rows' original indices — what
+    trainer.GaussianModel(order="morton"), i.e. bench.py's timed configuration, hands the kernels; the reference gets the rows in the original
+    order (rasterizer_impl.cu:395-424 defines the order of the lists on those).  Per-Gaussian outputs are un-permuted and the lists' Gaussian
+    ids mapped back to original indices before anything is compared."""
     import torch
     from conftest import make_scene
     from gpu_helpers import hip_backward, hip_forward, npy
     from gaussian_lic_amd import _lib
     from gaussian_lic_amd.synthetic import pixel_grad
     from oracle.ref_build import refkernels
-    assert P % 256 == 0
+    assert P % 256 == 0 and binning in PATH_KERNELS
     rk = refkernels.RefKernels()
     from conftest import clamp_masked_visible
     raw, sc, camd, cam = make_scene(kind, P, W, H, deg, seed, view=view, sigma_scale=sigma_scale)
     dL = pixel_grad(H, W, seed=1)
     ref = rk.run(sc, camd, dL.numpy() if backward else None, scale_modifier=scale_modifier)
     vis = ref["radii"] > 0
-    out = dict(scene=dict(kind=kind, P=P, W=W, H=H, deg=deg, seed=seed, view=view, sigma_scale=sigma_scale, scale_modifier=scale_modifier),
+    out = dict(scene=dict(kind=kind, P=P, W=W, H=H, deg=deg, seed=seed, view=view, sigma_scale=sigma_scale, scale_modifier=scale_modifier,
+                          binning=binning, morton=bool(morton)),
                ref=dict(R=int(ref["R"]), B32=int(ref["B"]), visible=int(vis.sum()), clamp_masked_visible=clamp_masked_visible(sc, camd, ref["radii"])))
-    for mode in modes:
-        prev = _lib.set_math_mode(mode == "strict")
-        try:
-            got = hip_forward(raw, cam, export=("tiles_touched", "means2D", "depths", "conic_opacity", "rgb", "point_list", "ranges",
-                                                "n_contrib"), scale_modifier=scale_modifier)
-            d = got["dbg"]
-            st = {}
-            tt_h = npy(d["tiles_touched"]).astype(np.uint32)
-            bad = np.nonzero(tt_h != ref["tiles_touched"])[0]
-            st["radii_mismatch"] = int((npy(got["radii"]) != ref["radii"]).sum())
-            st["tiles_touched_mismatch"] = int(bad.size)
-            st["R"] = int(got["R"])
-            pl_h, pl_r = npy(d["point_list"]).astype(np.uint32), ref["point_list"]
-            if bad.size:
-                pl_h, pl_r = pl_h[~np.isin(pl_h, bad)], pl_r[~np.isin(pl_r, bad)]
-            st["point_list_equal"] = bool(pl_h.shape == pl_r.shape and np.array_equal(pl_h, pl_r))
-            st["ranges_equal"] = bool(np.array_equal(npy(d["ranges"]).astype(np.uint32), ref["ranges"])) if not bad.size else None
-            for k, rkey in (("means2D", "means2D"), ("depths", "depths"), ("conic_opacity", "conic_opacity"), ("rgb", "rgb")):
-                st[k + "_bit_equal"] = bool(np.array_equal(npy(d[k])[vis], ref[rkey][vis]))
-            st["color"] = _err_stats(npy(got["color"]), ref["color"])
-            st["final_T"] = _err_stats(npy(got["final_T"]), ref["final_T"])
-            nc = npy(d["n_contrib"]).astype(np.uint32)
-            st["n_contrib_mismatch"] = int((nc != ref["n_contrib"]).sum())
-            st["pixels"] = int(nc.size)
-            if backward:
-                g = hip_backward(got, dL)
-                for k in GRADS:
-                    scale = None
-                    if k == "dL_drot":   # unnormalised-quaternion gradient: scale of the chain it belongs to (as test_vs_reference_kernels_gpu.py)
-                        scale = max(float(np.abs(ref["dL_drot"]).max()), float(np.abs(ref["dL_dscale"]).max() * sc["scales"].max()), 1e-30)   # (a view that sees nothing: all zeros)
-                    st[k] = _err_stats(g[k], ref[k], scale, keep_over=(mode == "strict" and P <= PROBE_MAX_P))
-                if mode == "strict" and P <= PROBE_MAX_P:
-                    conditioning_probe(st, sc, camd, dL.numpy(), scale_modifier)
-            out[mode] = st
-            del got
-            torch.cuda.empty_cache()
-        finally:
-            _lib.set_math_mode(prev)
+    perm = tie = None
+    if morton:
+        from gaussian_lic_amd import trainer
+        perm = trainer.morton_order(raw["xyz"])                      # storage row s holds original row perm[s]
+        raw = {k: (v[perm].contiguous() if (torch.is_tensor(v) and k in trainer.GaussianModel.NAMES) else v) for k, v in raw.items()}
+        tie = perm.to(torch.int32).to("cuda:0")
+        perm = perm.numpy()
+
+    def unperm(a):   # per-Gaussian array in storage order -> original order
+        if perm is None:
+            return a
+        o = np.empty_like(a)
+        o[perm] = a
+        return o
+
+    prev_binning = _lib.set_binning_mode(binning)
+    try:
+        for mode in modes:
+            prev = _lib.set_math_mode(mode == "strict")
+            try:
+                _lib.profile_enable(True, only=[k for ks in PATH_KERNELS.values() for k in ks])
+                _lib.profile_reset()
+                got = hip_forward(raw, cam, export=("tiles_touched", "means2D", "depths", "conic_opacity", "rgb", "point_list", "ranges",
+                                                    "n_contrib"), scale_modifier=scale_modifier, tie_rank=tie)
+                launches = {k: v[1] for k, v in _lib.profile_collect().items()}
+                _lib.profile_enable(False)
+                d = got["dbg"]
+                st = {}
+                st["binning_path"] = _lib.binning_path()[0]
+                st["path_launches"] = {p_: int(sum(launches.get(k, 0) for k in ks)) for p_, ks in PATH_KERNELS.items()}
+                tt_h = unperm(npy(d["tiles_touched"]).astype(np.uint32))
+                bad = np.nonzero(tt_h != ref["tiles_touched"])[0]
+                st["radii_mismatch"] = int((unperm(npy(got["radii"])) != ref["radii"]).sum())
+                st["tiles_touched_mismatch"] = int(bad.size)
+                st["R"] = int(got["R"])
+                pl_h, pl_r = npy(d["point_list"]).astype(np.uint32), ref["point_list"]
+                if perm is not None:
+                    pl_h = perm[pl_h].astype(np.uint32)
+                if bad.size:
+                    pl_h, pl_r = pl_h[~np.isin(pl_h, bad)], pl_r[~np.isin(pl_r, bad)]
+                st["point_list_equal"] = bool(pl_h.shape == pl_r.shape and np.array_equal(pl_h, pl_r))
+                st["ranges_equal"] = bool(np.array_equal(npy(d["ranges"]).astype(np.uint32), ref["ranges"])) if not bad.size else None
+                for k, rkey in (("means2D", "means2D"), ("depths", "depths"), ("conic_opacity", "conic_opacity"), ("rgb", "rgb")):
+                    st[k + "_bit_equal"] = bool(np.array_equal(unperm(npy(d[k]))[vis], ref[rkey][vis]))
+                st["color"] = _err_stats(npy(got["color"]), ref["color"])
+                st["final_T"] = _err_stats(npy(got["final_T"]), ref["final_T"])
+                nc = npy(d["n_contrib"]).astype(np.uint32)
+                st["n_contrib_mismatch"] = int((nc != ref["n_contrib"]).sum())
+                st["pixels"] = int(nc.size)
+                if backward:
+                    g = hip_backward(got, dL)
+                    for k in GRADS:
+                        scale = None
+                        if k == "dL_drot":   # unnormalised-quaternion gradient: scale of the chain it belongs to (as test_vs_reference_kernels_gpu.py)
+                            scale = max(float(np.abs(ref["dL_drot"]).max()), float(np.abs(ref["dL_dscale"]).max() * sc["scales"].max()), 1e-30)   # (a view that sees nothing: all zeros)
+                        st[k] = _err_stats(unperm(g[k]), ref[k], scale, keep_over=(mode == "strict" and P <= PROBE_MAX_P))
+                    if mode == "strict" and P <= PROBE_MAX_P:
+                        conditioning_probe(st, sc, camd, dL.numpy(), scale_modifier)
+                out[mode] = st
+                del got
+                torch.cuda.empty_cache()
+            finally:
+                _lib.profile_enable(False)
+                _lib.set_math_mode(prev)
+    finally:
+        _lib.set_binning_mode(prev_binning)
     return out
+
+
+def assert_path(res):
+    """The HIP forward of every mode of `res` took the grouping the comparison FORCED: the library says so (gslic_get_binning_path) and only that
+    path's kernels were launched (profiler counts).  Above GS_TILE_BIN_MAX_T = 36 864 tiles the atomic path does not exist."""
+    want = res["scene"]["binning"]
+    other = "radix" if want == "atomic" else "atomic"
+    for mode in ("fast", "strict"):
+        if mode in res and res["ref"]["R"] > 0:
+            st = res[mode]
+            assert st["binning_path"] == want, (mode, st["binning_path"], want)
+            assert st["path_launches"][want] > 0 and st["path_launches"][other] == 0, (mode, st["path_launches"])
 
 
 def compare_reference_builds(kind, P, W, H, deg, seed):
@@ -170,6 +221,7 @@ def summarize(res):
     pose = "" if s.get("view") is None else f" view={s['view']}"
     pose += "" if s.get("sigma_scale", 1.0) == 1.0 else f" sigma_scale={s['sigma_scale']}"
     pose += "" if s.get("scale_modifier", 1.0) == 1.0 else f" scale_modifier={s['scale_modifier']}"
+    pose += f" [binning forced: {s.get('binning')}; rows: {'Morton order + tie_rank' if s.get('morton') else 'insertion order'}]"
     lines.append(f"{s['kind']} P={s['P']} {s['W']}x{s['H']} deg{s['deg']} seed={s['seed']}{pose}: R={res['ref']['R']} visible={res['ref']['visible']} "
                  f"clamp-masked visible={res['ref'].get('clamp_masked_visible')}")
     for mode in ("fast", "strict"):
@@ -177,7 +229,8 @@ def summarize(res):
             continue
         st = res[mode]
         npx = st["pixels"]
-        parts = [f"radii!={st['radii_mismatch']}", f"tiles_touched!={st['tiles_touched_mismatch']}", f"lists_equal={st['point_list_equal']}",
+        parts = [f"path={st.get('binning_path')} launches={st.get('path_launches')}",
+                 f"radii!={st['radii_mismatch']}", f"tiles_touched!={st['tiles_touched_mismatch']}", f"lists_equal={st['point_list_equal']}",
                  f"geom_bits={'ok' if all(st[k + '_bit_equal'] for k in ('means2D', 'depths', 'conic_opacity')) else 'DIFF'}",
                  f"rgb_bits={'ok' if st['rgb_bit_equal'] else 'diff'}",
                  f"color over1e-4={st['color']['over']}/{st['color']['n']} max={st['color']['max_rel']:.2e} bit_equal={st['color']['bit_equal']}",

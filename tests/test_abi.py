@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in gslic_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names
-    assert _lib.lib().gslic_abi_version() == 7
+    assert _lib.lib().gslic_abi_version() == 8
 
 
 def test_scratch_sizes_and_errors_without_gpu():
@@ -100,8 +100,9 @@ def test_tensor_allocator_is_freed_by_refcount_alone():
 
 
 def test_large_scratch_requests_round_up_geometrically():
-    """A growing map must not pay a hipMalloc at every append: above 64 MB the allocator's granule is half the largest power of two in the request
-    (_lib.TensorAllocator; the C++ shim's resize callbacks have the same rule).  Sizes only: nothing this large is allocated here."""
+    """A growing map must not pay a hipMalloc at every append: above 64 MB the granule is min(half the largest power of two in the request,
+    256 MB) — gslic_scratch_round_up, ONE rule in the library that _lib.TensorAllocator and the C++ shim's resize callbacks all call.
+    Sizes only: nothing this large is allocated here."""
     import gaussian_lic_amd  # noqa: F401
     from gaussian_lic_amd import _lib
     G = _lib.TensorAllocator.GRANULE
@@ -112,11 +113,11 @@ def test_large_scratch_requests_round_up_geometrically():
     try:
         torch.empty = lambda n, **kw: (seen.append(int(n)), real_empty(0, dtype=torch.uint8))[1]
         a = _lib.TensorAllocator(torch.device("cpu"))
-        for n in (1000, (1 << 20) + 1, 50 << 20, (64 << 20) + 1, 366 << 20, 457 << 20, 597 << 20, (1 << 30) + 5):
+        for n in (1000, (1 << 20) + 1, 50 << 20, (64 << 20) + 1, 366 << 20, 457 << 20, 597 << 20, (1 << 30) + 5, (2 << 30) + 5):
             a.cb(None, n)
     finally:
         torch.empty = real_empty
-    assert seen[-8:] == [1000, G, 64 << 20, 96 << 20, 384 << 20, 512 << 20, 768 << 20, 3 << 29]
+    assert seen[-9:] == [1000, G, 64 << 20, 96 << 20, 384 << 20, 512 << 20, 768 << 20, 5 << 28, 9 << 28]
     # 1.5M -> 2.0M Gaussians: the binning buffer (61 B per instance, 4.5M -> 6M instances) takes ONE size on the way, with 32 MB granules three
     seen.clear()
     try:
@@ -128,8 +129,28 @@ def test_large_scratch_requests_round_up_geometrically():
     assert len(set(seen)) == 1 and len({(61 * r + G - 1) // G for r in range(4_500_000, 6_000_001, 50_000)}) == 3
 
 
+def test_scratch_round_up_worst_case_overhead():
+    """the rounding must not turn a map that fits into an out-of-memory.  Over-allocation is below 50 % up to 512 MB (where the
+    granule is half a power of two) and below 256 MB in absolute terms beyond; never below the request, idempotent, monotonic."""
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import _lib
+    up = _lib.lib().gslic_scratch_round_up
+    prev = 0
+    sizes = [1, 1 << 20, (1 << 20) + 1] + [int(1.07 ** k * (1 << 20)) for k in range(1, 160)] + [(k << 28) + 1 for k in range(1, 200, 7)]
+    for n in sorted(sizes):
+        r = up(n)
+        assert r >= n and up(r) == r and r >= prev, (n, r)
+        prev = r
+        if n > (512 << 20):
+            assert r - n < (256 << 20), (n, r)
+        elif n > (1 << 20):
+            assert r < 1.5 * n + (32 << 20), (n, r)
+    assert up((2 << 30) + 5) == (9 << 28) and up((100 << 30) + 1) == (100 << 30) + (256 << 20)
+
+
 def test_binning_mode_switch_without_gpu():
-    """gslic_set_binning_mode touches host state only: returns the previous mode, ignores values outside 0..2"""
+    """gslic_set_binning_mode touches host state only: returns the previous mode, ignores values outside 0..2; gslic_get_binning_path reports
+    "none" for a thread that has not run a forward with instances"""
     import gaussian_lic_amd  # noqa: F401
     from gaussian_lic_amd import _lib
     old = _lib.set_binning_mode("radix")
@@ -139,3 +160,29 @@ def test_binning_mode_switch_without_gpu():
         assert _lib.set_binning_mode("auto") == "atomic"
     finally:
         _lib.set_binning_mode(old)
+    import threading
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(_lib.binning_path()))   # (a fresh host thread: the state is per thread)
+    t.start(); t.join()
+    assert seen == [("none", 0, 0)]
+
+
+def test_binning_mode_is_safe_to_set_while_other_threads_read_it():
+    """The mode is an atomic and setting it bumps an epoch every thread's auto state follows (a plain global + the calling
+    thread's state only).  Host-side only: hammer set / read from four threads, the value is always one of the three modes."""
+    import threading
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import _lib
+    L = _lib.lib()
+    old = _lib.set_binning_mode("auto")
+    bad = []
+
+    def work(k):
+        for i in range(2000):
+            v = L.gslic_set_binning_mode((i + k) % 3)
+            if v not in (0, 1, 2) or L.gslic_set_binning_mode(-1) not in (0, 1, 2):
+                bad.append(v)
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    _lib.set_binning_mode(old)
+    assert not bad

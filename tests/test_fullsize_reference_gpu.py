@@ -31,8 +31,10 @@ def test_fullsize_matches_reference_kernels(name):
     _need_ref()
     from parity_report import CONFIGS
     from refcompare import GRADS, compare, summarize
-    res = compare(*CONFIGS[name])
-    print("\n" + summarize(res))
+    from refcompare import assert_path
+    res = compare(*CONFIGS[name])      # binning forced to the stable radix sort, rows in insertion order; the timed configuration (atomics + Morton
+    print("\n" + summarize(res))       # rows) is held to the same bars in tests/test_timed_path_reference_gpu.py
+    assert_path(res)
     P = res["scene"]["P"]
     for mode in ("fast", "strict"):
         st = res[mode]

@@ -1,0 +1,181 @@
+"""-m gpu: the configuration bench.py TIMES, held to the reference's own kernels at BASELINE.json's full sizes (round-5 review, item 1).
+
+What is timed: trainer.GaussianModel(order="morton") — the map's rows permuted into Morton order, the forward breaking depth ties by the rows'
+ORIGINAL indices (gslic_raster_params.tie_rank) — + the block-aggregated ATOMIC grouping of the instances (csrc/tile_bin.hip) + the fused step
+(activations inside the kernels, the fused L1 + SSIM loss kernels, Adam inside the per-Gaussian backward).  Until round 6 the full-size
+comparisons with the reference's kernels ran the functional API on insertion-order rows with the binning mode on `auto`.
+
+Here, against oracle/_ref/libref_hip.so (the reference's .cu files compiled for gfx950) on the same MI355X and inputs:
+
+  * config 3/4 (2 000 128 Gaussians, 1920x1080: 8160 tiles) at the identity pose, config-4 views 0 and 7 and the general SE(3) pose se3_b, and
+    config 5 (5 000 192 Gaussians, 3840x2160: 32 400 tiles — the 1024-thread binning kernels and their 130 KB histograms), all with the
+    grouping FORCED to "atomic" and the rows in Morton order + tie_rank; the atomics also on the rows as generated (what `auto` probes with) and
+    the radix sort on Morton rows (what `auto` falls back to for a permuted map).  The path taken is asserted (gslic_get_binning_path + the
+    profiler's launch counts), never assumed.  Bars unchanged: radii, tiles_touched, per-tile lists — the order rasterizer_impl.cu:395-424 defines —,
+    ranges, means2D / depth / conic / opacity / SH colour bit-exact; image, final_T, n_contrib bit-identical; ZERO gradient elements over 1e-4;
+  * ONE fused training step at 2M on the Morton model against the reference CHAIN: LibTorch activations (gaussian.cpp:147-175) -> the reference's
+    forward -> 0.8 L1 + 0.2 (1 - fused-SSIM) through the reference's ssim.cu kernels (gaussian.cpp:685-691) -> the reference's backward -> the
+    activations' autograd -> the reference's adam.cu on the six groups with `visible = radii > 0` (optim_utils.h:102-137, adam.cu:9-38):
+    parameters and both Adam moments after the step, un-permuted.
+`python tests/parity_report.py --timed-path` prints the same as a table (profiles/r06_parity_timed_path.log)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+C3 = ("random", 2000128, 1920, 1080, 3, 0)
+C5 = ("random", 5000192, 3840, 2160, 3, 0)
+# (name, scene, view, binning, morton)
+CASES = [
+    ("c3_identity_atomic_morton", C3, None, "atomic", True),
+    ("c3_view0_atomic_morton", C3, 0, "atomic", True),
+    ("c3_view7_atomic_morton", C3, 7, "atomic", True),
+    ("c3_se3b_atomic_morton", C3, "se3_b", "atomic", True),
+    ("c5_identity_atomic_morton", C5, None, "atomic", True),
+    ("c3_identity_atomic_insertion", C3, None, "atomic", False),
+    ("c3_view7_radix_morton", C3, 7, "radix", True),
+]
+
+
+def _need_ref():
+    from oracle.ref_build import refkernels
+    if not refkernels.available():
+        pytest.skip("oracle/_ref/libref_hip.so not built")
+
+
+def assert_timed_path_parity(res):
+    from refcompare import GRADS, assert_path
+    assert_path(res)
+    st = res["strict"]
+    assert st["radii_mismatch"] == 0 and st["tiles_touched_mismatch"] == 0, (st["radii_mismatch"], st["tiles_touched_mismatch"])
+    assert st["R"] == res["ref"]["R"]
+    assert st["point_list_equal"] and st["ranges_equal"]
+    assert st["means2D_bit_equal"] and st["depths_bit_equal"] and st["conic_opacity_bit_equal"] and st["rgb_bit_equal"]
+    assert st["color"]["bit_equal"] and st["final_T"]["bit_equal"] and st["n_contrib_mismatch"] == 0, (st["color"], st["final_T"], st["n_contrib_mismatch"])
+    for k in ("color", "final_T") + GRADS:
+        assert st[k]["over"] == 0, (k, st[k])
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_timed_configuration_matches_reference_kernels_full_size(case):
+    _need_ref()
+    from refcompare import compare, summarize
+    _name, scene, view, binning, morton = case
+    res = compare(*scene, modes=("strict",), view=view, binning=binning, morton=morton)
+    print("\n" + summarize(res))
+    assert res["ref"]["R"] > 1000000
+    assert_timed_path_parity(res)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+def reference_chain_step(raw, cam, gt, lrs, lambda_dssim=0.2, device="cuda:0"):
+    """One iteration of optimize() (gaussian.cpp:674-716) with every kernel the REFERENCE's: activations and their backward by LibTorch ops on the
+    device (what the reference host runs), forward / backward / fused-SSIM / Adam by oracle/_ref/libref_hip.so.  Returns
+    (params, exp_avg, exp_avg_sq) as dicts of numpy arrays in `raw`'s row order, the visible mask, the image and dL/dimage."""
+    import torch
+    from gaussian_lic_amd import trainer
+    from oracle.ref_build import refkernels
+    rk = refkernels.RefKernels()
+    names = trainer.GaussianModel.NAMES
+    leaves = {n: raw[n].detach().clone().float().to(device).requires_grad_(True) for n in names}
+    opac, scales, rots = torch.sigmoid(leaves["opacity"]), torch.exp(leaves["scaling"]), torch.nn.functional.normalize(leaves["rotation"])
+    npy = lambda t: t.detach().cpu().numpy()
+    sc = dict(means=npy(leaves["xyz"]), dc=npy(leaves["features_dc"]), shs=npy(leaves["features_rest"]), opac=npy(opac), scales=npy(scales),
+              rots=npy(rots), D=int(raw["sh_degree"]))
+    camd = cam.as_dict()
+    fwd = rk.run(sc, camd)
+    img = fwd["color"]
+    gtn = npy(gt)
+    N = img.size
+    # loss = (1 - l) * mean|img - gt| + l * (1 - mean(ssim_map))   (gaussian.cpp:685-691, loss_utils.h:30-33,130-193)
+    a4, b4 = img[None], gtn[None]
+    _map, dmu, dsig, dsig12 = rk.ssim_forward(a4, b4)
+    dL_dmap = np.full_like(a4, -lambda_dssim / N)
+    dL = rk.ssim_backward(a4, b4, dL_dmap, dmu, dsig, dsig12)[0] + np.float32((1.0 - lambda_dssim) / N) * np.sign(img - gtn).astype(np.float32)
+    dL = np.ascontiguousarray(dL, np.float32)
+    out = rk.run(sc, camd, dL)
+    vis = out["radii"] > 0
+    P = sc["means"].shape[0]
+    t = lambda a, like: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device).reshape(like.shape)
+    torch.autograd.backward([opac, scales, rots], [t(out["dL_dopacity"], opac), t(out["dL_dscale"], scales), t(out["dL_drot"], rots)])
+    grads = dict(xyz=out["dL_dmean3D"].reshape(P, 3), features_dc=out["dL_ddc"].reshape(P, 1, 3), features_rest=out["dL_dsh"].reshape(sc["shs"].shape),
+                 opacity=npy(leaves["opacity"].grad), scaling=npy(leaves["scaling"].grad), rotation=npy(leaves["rotation"].grad))
+    prm, m, v = {}, {}, {}
+    for n, lr in zip(names, lrs):
+        prm[n] = np.ascontiguousarray(npy(leaves[n]), np.float32)
+        m[n], v[n] = np.zeros_like(prm[n]), np.zeros_like(prm[n])
+        rk.adam(prm[n], np.ascontiguousarray(grads[n], np.float32), m[n], v[n], vis, lr)
+    return prm, m, v, vis, img, dL, grads
+
+
+def fused_step_vs_reference_chain(P=2000128, W=1920, H=1080, seed=0, order="morton", binning="atomic"):
+    """Statistics of one training_step_fused on trainer.GaussianModel(order=...) against reference_chain_step on the same start."""
+    import torch
+    from conftest import make_scene
+    from gaussian_lic_amd import _lib, trainer
+    from gaussian_lic_amd.synthetic import gt_image
+    dev = torch.device("cuda:0")
+    raw, _sc, _camd, cam = make_scene("random", P, W, H, 3, seed)
+    cam.to_device(dev)
+    gt = gt_image(H, W).to(dev)
+    model = trainer.GaussianModel({k: (v.clone() if torch.is_tensor(v) else v) for k, v in raw.items()}, dev, order=order)
+    model.training_setup()          # the reference's learning rates (config/fastlivo.yaml:18-22)
+    lrs = list(model.optimizer.lrs)
+    prev = _lib.set_binning_mode(binning)
+    try:
+        terms, vis_h = trainer.training_step_fused(model, cam, gt, torch.zeros(3, device=dev))
+        torch.cuda.synchronize()
+        path = _lib.binning_path()
+    finally:
+        _lib.set_binning_mode(prev)
+    order_idx = model.original_order()
+    un = (lambda x: x) if order_idx is None else (lambda x: x[order_idx])
+    got_p = {n: un(getattr(model, n).detach()).cpu().numpy() for n in model.NAMES}
+    got_m = {n: un(model._m[n][:model.P]).cpu().numpy() for n in model.NAMES}
+    got_v = {n: un(model._v[n][:model.P]).cpu().numpy() for n in model.NAMES}
+    vis_h = un(vis_h).cpu().numpy()
+    prm, m, v, vis_r, _img, _dL, _g = reference_chain_step(raw, cam, gt, lrs)
+    res = dict(P=P, W=W, H=H, order=order, binning_forced=binning, binning_path=path[0], visible_reference=int(vis_r.sum()),
+               visible_mismatch=int((vis_h != vis_r).sum()), loss_terms=[float(x) for x in terms.cpu().tolist()], groups={})
+    b1, b2 = 0.9, 0.999
+    for n, lr in zip(model.NAMES, lrs):
+        step = lr * (1.0 - b1) / np.sqrt(1.0 - b2)     # what the first Adam step moves an element whose gradient is not ~0 (adam.cu:26-37, no bias correction)
+        st = {}
+        for what, g, r, tol in (("exp_avg", got_m[n], m[n], 1e-4), ("exp_avg_sq", got_v[n], v[n], 2e-4)):
+            scale = max(float(np.abs(r).max()), 1e-30)
+            e = np.abs(g.astype(np.float64) - r.astype(np.float64)) / scale
+            st[what] = dict(n=int(r.size), over=int((e > tol).sum()), tol=tol, max_rel=float(e.max()), bit_equal=bool(np.array_equal(g, r)))
+        d = np.abs(got_p[n].astype(np.float64) - prm[n].astype(np.float64))
+        st["param"] = dict(n=int(d.size), step=float(step), moved_differently=int((d > 1e-3 * step).sum()), max_abs_diff=float(d.max()),
+                           max_in_steps=float(d.max() / step), bit_equal=bool(np.array_equal(got_p[n], prm[n])))
+        res["groups"][n] = st
+    return res
+
+
+def summarize_fused(res):
+    lines = [f"fused step vs reference chain: P={res['P']} {res['W']}x{res['H']} rows={res['order']} binning forced={res['binning_forced']} path taken={res['binning_path']} "
+             f"visible(ref)={res['visible_reference']} visible mask mismatches={res['visible_mismatch']} loss terms [L1, SSIM]={res['loss_terms']}"]
+    for n, st in res["groups"].items():
+        lines.append(f"  {n}: exp_avg over{st['exp_avg']['tol']:g}={st['exp_avg']['over']}/{st['exp_avg']['n']} max={st['exp_avg']['max_rel']:.2e} | "
+                     f"exp_avg_sq over{st['exp_avg_sq']['tol']:g}={st['exp_avg_sq']['over']} max={st['exp_avg_sq']['max_rel']:.2e} | "
+                     f"param: {st['param']['moved_differently']} of {st['param']['n']} elements moved differently (> 0.1 % of a step), largest difference "
+                     f"{st['param']['max_in_steps']:.3f} steps of {st['param']['step']:.3e}")
+    return "\n".join(lines)
+
+
+def test_fused_step_on_the_morton_model_matches_the_reference_chain_full_size():
+    """Bars.  exp_avg = (1 - b1) * gradient on the visible rows: every gradient bar of the suite applies — ZERO elements over 1e-4 of the group's
+    max-abs.  exp_avg_sq = (1 - b2) * gradient^2: twice the relative error, 2e-4.  Parameters: Adam without bias correction and eps = 1e-15
+    (adam.cu:26-37) moves an element by lr * 0.1 / sqrt(0.001) = 3.16 lr on its first step WHATEVER the size of its gradient, so an element whose
+    gradient is zero up to summation order may move the other way: such elements are counted (printed), bounded by 20 per million, and none may be
+    off by more than the two steps that a sign flip is worth.  The visible mask is exact."""
+    _need_ref()
+    res = fused_step_vs_reference_chain()
+    print("\n" + summarize_fused(res))
+    assert res["binning_path"] == "atomic"
+    assert res["visible_mismatch"] == 0
+    for n, st in res["groups"].items():
+        assert st["exp_avg"]["over"] == 0, (n, st["exp_avg"])
+        assert st["exp_avg_sq"]["over"] == 0, (n, st["exp_avg_sq"])
+        assert st["param"]["moved_differently"] <= 20e-6 * st["param"]["n"] + 2, (n, st["param"])
+        assert st["param"]["max_in_steps"] <= 2.02, (n, st["param"])
