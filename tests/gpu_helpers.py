@@ -14,11 +14,13 @@ def settings_from(cam, deg, dev, no_color=False, lambda_erank=0.0, debug=False, 
         torch.from_numpy(cam.camera_center).to(dev), False, debug, no_color, lambda_erank)
 
 
-def hip_forward(raw, cam, no_color=False, export=(), debug=False, scale_modifier=1.0, tie_rank=None):
-    """tie_rank: int32 device tensor [P] — the rows' original indices when `raw` holds the map's rows in a permuted order
-    (gslic_raster_params.tie_rank: what trainer.GaussianModel(order="morton") passes)."""
+def hip_forward(raw, cam, no_color=False, export=(), debug=False, scale_modifier=1.0, tie_rank=None, act=None):
+    """tie_rank: int32 device tensor [P] — the rows' original indices when the map's rows are given in a permuted order
+    (gslic_raster_params.tie_rank: what trainer.GaussianModel(order="morton") passes).
+    act: the ACTIVATED scene (synthetic.activate's dict) instead of `raw` — a caller that permutes rows activates first and permutes the activated
+    tensors, so that both sides of a comparison see the same bits whatever the host's LibTorch does at its chunk boundaries."""
     dev = torch.device("cuda:0")
-    act = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in activate(raw).items()}
+    act = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in (activate(raw) if act is None else act).items()}
     rs = settings_from(cam, act["D"], dev, no_color, debug=debug, scale_modifier=scale_modifier)
     empty = torch.empty(0, device=dev)
     out = rz.rasterize_gaussians(rs.bg, act["means"], empty, act["opac"], act["scales"], act["rots"], rs.scale_modifier, empty, rs.viewmatrix,

@@ -86,8 +86,13 @@ def compare(kind, P, W, H, deg, seed, modes=("fast", "strict"), backward=True, v
     if morton:
         from gaussian_lic_amd import trainer
         perm = trainer.morton_order(raw["xyz"])                      # storage row s holds original row perm[s]
-        raw = {k: (v[perm].contiguous() if (torch.is_tensor(v) and k in trainer.GaussianModel.NAMES) else v) for k, v in raw.items()}
         tie = perm.to(torch.int32).to("cuda:0")
+    # the HIP side's inputs: the SAME activated values the reference gets (activated once, in the original order: LibTorch's CPU reductions need not
+    # give a row the same last bit at every position of a tensor), then the rows permuted
+    from gaussian_lic_amd.synthetic import activate
+    act = activate(raw)
+    if morton:
+        act = {k: (v[perm].contiguous() if torch.is_tensor(v) else v) for k, v in act.items()}
         perm = perm.numpy()
 
     def unperm(a):   # per-Gaussian array in storage order -> original order
@@ -105,7 +110,7 @@ def compare(kind, P, W, H, deg, seed, modes=("fast", "strict"), backward=True, v
                 _lib.profile_enable(True, only=[k for ks in PATH_KERNELS.values() for k in ks])
                 _lib.profile_reset()
                 got = hip_forward(raw, cam, export=("tiles_touched", "means2D", "depths", "conic_opacity", "rgb", "point_list", "ranges",
-                                                    "n_contrib"), scale_modifier=scale_modifier, tie_rank=tie)
+                                                    "n_contrib"), scale_modifier=scale_modifier, tie_rank=tie, act=act)
                 launches = {k: v[1] for k, v in _lib.profile_collect().items()}
                 _lib.profile_enable(False)
                 d = got["dbg"]
