@@ -114,6 +114,13 @@ _T0 = time.perf_counter()
 _LEG = ["start"]
 
 
+def _freeze_gc():
+    """gc.collect() + gc.freeze(): no generation-2 pass of Python's cyclic collector (47-75 ms over a torch process's heap) inside a timed loop."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def _trace(msg):
     """Progress line on stderr (never on stdout: the contract is ONE JSON line there): which leg runs and since when — a leg that stalls is then
     visible in the driver's log instead of being a silent timeout."""
@@ -214,7 +221,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="the contract line only: no second process at all (neither the growth-schedule leg nor --extras)")
     ap.add_argument("--extras", action="store_true", help="after the contract measurements, run the secondary legs (views_cycle, math_modes, other_host_path, graphed, "
                                                           "joint_pose_step, cpp hosts) in a SECOND process and merge its results into the line")
-    ap.add_argument("--leg", default=None, choices=["growth_schedule", "extras"], help=argparse.SUPPRESS)   # child mode of the two lines above
+    ap.add_argument("--leg", default=None, choices=["growth_schedule", "extras", "dropin"], help=argparse.SUPPRESS)   # child mode: one leg process
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every kernel inside the timed region (adds overhead)")
     args = ap.parse_args()
 
@@ -253,7 +260,7 @@ def main():
     from gaussian_lic_amd.synthetic import gt_image, lidar_scene, pixel_grad, random_scene
 
     if args.leg is not None:   # child mode: one secondary leg in this process, its JSON dict on stdout, nothing else
-        res = growth_schedule(args, dev) if args.leg == "growth_schedule" else secondary_legs(args, dev)
+        res = {"growth_schedule": growth_schedule, "extras": secondary_legs, "dropin": dropin_legs}[args.leg](args, dev)
         print(json.dumps(res), flush=True)
         return
     W, H, P = args.width, args.height, args.gaussians
@@ -330,12 +337,15 @@ def main():
 
     if args.graph:
         assert world == 1 and args.mode == "train" and args.host == "fused" and not args.split_adam, "--graph: single GPU, --mode train --host fused"
-    # ---- N > 1 (and the one-rank group that stands in for it): prime the exchange path before the W warm-up steps.  The 79th step of a process
-    # group stalls for 36-39 ms, once, reproducibly (tools/diag_dist_warmup.py: a runtime-side pool growing after ~240 collectives); inside
-    # a 20- or 100-step timed region that one stall reads as +0.4 .. +1.9 ms per step.  Priming is initialisation, not part of W or K.
-    prime_steps = 0
-    if trainer._dist_on() and args.mode == "train" and args.host == "fused":
-        prime_steps = int(os.environ.get("GSLIC_DIST_PRIME_STEPS", "90"))
+    # ---- Python's cyclic garbage collector out of the timed loop.  A generation-2 pass over this process's heap (torch imported: ~1e6 objects) takes
+    # 47-75 ms, and the N > 1 step allocates enough container objects (c10d Work handles, lists of views) to trigger ONE at about its 70th-79th
+    # step — the "one-off 36-39 ms stall at the 79th step of a process group" that rounds 4-5 pushed out of the window with 90 untimed priming steps
+    # and attributed to a runtime pool (tools/diag_dist_stall.py, profiles/r06g_dist_stall.log: the collector's own callbacks place the pass inside
+    # the slow step; no stall with gc.freeze() or with the collector off; 400 extra collectives beforehand do not move it).  gc.freeze() moves
+    # everything allocated so far into the permanent generation: later passes only look at what the loop itself creates.  No priming steps.
+    _freeze_gc()
+    prime_steps = int(os.environ.get("GSLIC_DIST_PRIME_STEPS", "0"))
+    if prime_steps and trainer._dist_on() and args.mode == "train" and args.host == "fused":
         for _ in range(prime_steps):
             step()
         torch.cuda.synchronize()
@@ -384,9 +394,10 @@ def main():
             mode = trainer.exchange_mode()
             # ring all-reduce: 2 (n-1)/n of the buffer per rank; all-gather: (n-1) x the per-rank payload
             sent = {"rank1": 2.0 * (n - 1) / n * 44 * Pn + (n - 1) * (13 * Pn + 12),
-                    "dense": 2.0 * (n - 1) / n * 236 * Pn + 2.0 * (n - 1) / n * Pn}.get(mode)
+                    "dense": 2.0 * (n - 1) / n * 236 * Pn + 2.0 * (n - 1) / n * Pn,
+                    "single": 2.0 * (n - 1) / n * 240 * Pn}.get(mode)
             chunks = trainer.exchange_chunks() if mode == "rank1" else 1
-            exchange = {"mode": mode, "chunks": chunks, "collectives_per_step": {"rank1": 3 if chunks == 1 else 2 * chunks, "dense": 4, "sparse": 2}[mode],
+            exchange = {"mode": mode, "chunks": chunks, "collectives_per_step": {"rank1": 3 if chunks == 1 else 2 * chunks, "dense": 4, "sparse": 2, "single": 1}[mode],
                         "compute_ms": round(comp, 3),
                         "exchange_window_ms": round(tail, 3),
                         "window_note": "GPU time from the end of the backward (chunks > 1: of its FIRST chunk) to the end of the step: the collectives AND the "
@@ -574,7 +585,8 @@ def main():
                                + ("; extend() append of a LiDAR frame every 10 steps, timed" if args.mode == "slam" else "")
                                + ("" if world == 1 else f"; {world} views/step, one gradient exchange per step ({trainer.exchange_mode()}: "
                                   + {"rank1": "xyz / opacity / scaling / rotation all-reduced, the 3-float colour gradients all-gathered and the SH rows rebuilt locally",
-                                     "dense": "the [P x 59] slab all-reduced", "sparse": "the visible rows of the slab all-reduced"}[trainer.exchange_mode()] + ")"),
+                                     "dense": "the [P x 59] slab all-reduced", "sparse": "the visible rows of the slab all-reduced",
+                                     "single": "ONE all-reduce of the [P x 59] slab + the visibility mask as P more floats"}[trainer.exchange_mode()] + ")"),
                    "mode": args.mode, "host": args.host if args.mode != "render" else "dropin", "parallelism": f"dp{world}" if world > 1 else "single",
                    "math": "strict" if strict_mode else "fast", "map_order": args.map_order,
                    # how the forward grouped the instances by tile in the instrumented warm-up pass (GSLIC_BINNING / gslic_set_binning_mode; auto follows the row order)
@@ -588,6 +600,7 @@ def main():
         "views_cycle": None,
         "math_modes": None,
         "other_host_path": None,
+        "dropin_host": None,
         "graphed": None,
         "cpp_fused_host": None,
         "joint_pose_step": None,
@@ -625,8 +638,8 @@ def main():
                                      "gloo on device tensors: more ranks than GPUs on this box, RCCL refuses duplicate devices — plumbing check, not a scaling number"),
                          "ranks": world, "devices": ndev, "ranks_reached_by_all_reduce": int(ones.item()),
                          "self_launched": os.environ.get("GSLIC_BENCH_SELF_LAUNCHED") == "1",
-                         "prime_steps": prime_steps, "prime_note": "untimed optimiser steps before the W warm-up steps: the ~79th step of a process group stalls "
-                                                                   "once for 36-39 ms (profiles/r04_dist_warmup_stall.txt); `value` is the steady state behind it"}
+                         "prime_steps": prime_steps, "gc": "gc.collect() + gc.freeze() before the warm-up: the one-off 36-75 ms stall of rounds 4-5 at the ~79th step of a "
+                                                           "process group was a generation-2 pass of Python's garbage collector (profiles/r06g_dist_stall.log), not the runtime"}
         try:
             out["rccl_microbench"] = collectives_alone(model.P, world, rank, dev, backend)
         except Exception as ex:
@@ -654,6 +667,23 @@ def main():
         # SURVEY 8d's literal config-3 instance (1.5M -> 2.0M by five appends, the reference's learning rates) beside the stationary line
         out["config"]["growth_schedule"] = {k: growth.get(k) for k in ("workload", "value", "unit", "ms_per_iteration", "gaussians_start", "gaussians_end",
                                                                         "extend_ms_per_call", "error") if k in growth}
+        # The reference's UNMODIFIED host on the drop-in boundary (north_star: "the C++ host keeps its torch::Tensor operator API") beside the fused
+        # host `value` is measured on, on the contract line by default since round 6: C++ (the reference's renderer.cpp / rasterizer.cpp / loss_utils.h /
+        # optim_utils.h compiled unmodified) and the Python mirror, on the map in BOTH row orders, plus a SLAM-like map grown by extend() in insertion order
+        _trace("dropin (third process)")
+        drop = run_leg_process("dropin", float(os.environ.get("GSLIC_BENCH_DROPIN_BUDGET_S", "300")), args)
+        out["dropin_host"] = drop
+        if "error" not in drop:
+            out["other_host_path"] = drop.get("python_mirror", {}).get("map_order_of_value")
+            out["cpp_fused_host"] = drop.get("cpp")
+            best = drop.get("headline_dropin") or {}
+            out["config"]["dropin_host"] = {"what": "the reference's unmodified C++ host lines (renderer.cpp:21-88 + gaussian.cpp:683-707 + optim_utils.h:102-137) on libgslic_torch_shim.so, same map, "
+                                                    "same view, reference learning rates; rows in the order the HOST keeps them (as generated = random for the synthetic scene)",
+                                            "value": best.get("value"), "unit": "views/s", "ms_per_step": best.get("ms_per_step"),
+                                            "ratio_to_value": (round(best["value"] / out["value"], 3) if best.get("value") else None),
+                                            "ratio_to_fused_step_on_the_same_row_order": drop.get("ratio_dropin_to_fused_same_row_order"),
+                                            "fused_step_same_row_order": (drop.get("fused_insertion_order") or {}).get("value"),
+                                            "map_order_sort_ms": drop.get("map_order_sort_ms")}
         if args.extras:
             _trace("extras (second process)")
             legs = run_leg_process("extras", float(os.environ.get("GSLIC_BENCH_LEGS_BUDGET_S", "300")), args)
@@ -743,6 +773,7 @@ def secondary_legs(args, dev):
         torch.cuda.synchronize()
         return time.perf_counter() - o0
 
+    _freeze_gc()
     for _ in range(25):
         step()
     torch.cuda.synchronize()
@@ -965,7 +996,7 @@ def mode_differences(model, cam, dL, bg):
     return res
 
 
-def cpp_fused_host(args, model, cam, gt, n):
+def cpp_fused_host(args, model, cam, gt, n, fused=True, tag=""):
     """The fused step driven from C++ (gaussian-lic_amd/shim/include/gslic_fused.h, program fused_check): the current map, camera and
     target are handed over as files, the program runs n timed steps in its own process on the same GPU and reports its own clock."""
     import shutil
@@ -975,7 +1006,9 @@ def cpp_fused_host(args, model, cam, gt, n):
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gaussian-lic_amd", "fused_check")
     if not os.path.exists(exe):
         return None
-    keep = os.environ.get("GSLIC_CPP_HOST_DIR")   # keep the hand-over files there (to run fused_check by hand, e.g. under rocprofv3)
+    keep = os.environ.get("GSLIC_CPP_HOST_DIR")   # keep the hand-over files there (to run fused_check / dropin_check_* by hand, e.g. under rocprofv3)
+    if keep and tag:
+        keep = os.path.join(keep, tag)
     d = keep or tempfile.mkdtemp(prefix="gslic_cpp_host_")
     os.makedirs(d, exist_ok=True)
     try:
@@ -988,21 +1021,25 @@ def cpp_fused_host(args, model, cam, gt, n):
         if getattr(model, "tie_rank", None) is not None:   # rows in Morton order: the C++ host gets their original indices (FusedStep::set_tie_rank)
             w("tie_rank", model.tie_rank.cpu().numpy())
         w("scalars", np.array([cam.tanfovx, cam.tanfovy, cam.limx_neg, cam.limx_pos, cam.limy_neg, cam.limy_pos], np.float32))
-        r = subprocess.run([exe, d, str(model.P), str(args.width), str(args.height), "3", "1", str(n), str(args.lr_scale)], capture_output=True,
-                           text=True, timeout=180)
-        line = [l for l in r.stdout.splitlines() if l.startswith("views_per_s")]
-        if r.returncode != 0 or not line:
-            return {"error": (r.stdout[-300:] + r.stderr[-300:]).strip()}
-        tok = line[0].split()
-        res = {"host": "C++ (LibTorch tensors + C-ABI, no autograd graph)", "value": round(float(tok[1]), 3), "unit": "views/s",
-               "ms_per_step": round(float(tok[3]), 3), "steps": n}
+        res = {}
+        if fused:
+            r = subprocess.run([exe, d, str(model.P), str(args.width), str(args.height), "3", "1", str(n), str(args.lr_scale)], capture_output=True,
+                               text=True, timeout=180)
+            line = [l for l in r.stdout.splitlines() if l.startswith("views_per_s")]
+            if r.returncode != 0 or not line:
+                return {"error": (r.stdout[-300:] + r.stderr[-300:]).strip()}
+            tok = line[0].split()
+            res = {"host": "C++ (LibTorch tensors + C-ABI, no autograd graph)", "value": round(float(tok[1]), 3), "unit": "views/s",
+                   "ms_per_step": round(float(tok[3]), 3), "steps": n}
         # the REFERENCE's host lines (render() -> l1_loss + fused_ssim -> loss.backward() -> SparseGaussianAdam::step(), gaussian.cpp:683-707) compiled
         # unmodified, linked with (a) the reference's own renderer.cpp, (b) this repository's drop-in renderer.cpp (activations inside the kernels),
         # (c) the drop-in renderer + the optional one-node loss: what an unchanged / a one-file-swapped / a five-line-edited Gaussian-LIC host runs at.
         # Full learning rates (the program's own): the scene fades over the run, so the three are compared with each other, not with `value`.
         pkg = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gaussian-lic_amd")
         drop = {}
-        for key, name in (("reference_renderer_cpp", "dropin_check_render_ref"), ("dropin_renderer_cpp", "dropin_check_render"),
+        for key, name in (("reference_host_unmodified", "dropin_check_render_refhost"),   # the reference's renderer.cpp AND optim_utils.h (six grad.clone() + six adamUpdate)
+                          ("reference_renderer_cpp", "dropin_check_render_ref"),          # its renderer.cpp, this repository's one-launch optim_utils.h (header swap)
+                          ("dropin_renderer_cpp", "dropin_check_render"),                 # + renderer.cpp swapped for shim/renderer.cpp (activations inside the kernels)
                           ("dropin_renderer_cpp_one_node_loss", "dropin_check_render_loss")):
             exe2 = os.path.join(pkg, name)
             if not os.path.exists(exe2):
@@ -1021,6 +1058,169 @@ def cpp_fused_host(args, model, cam, gt, n):
             shutil.rmtree(d, ignore_errors=True)
 
 
+def slam_like_map(args, dev, frames=24):
+    """A map GROWN THE WAY THE REFERENCE GROWS ITS MAP (gaussian.cpp:212-304 initialize, :499-638 extend): keyframe 0's LiDAR points become the first
+    Gaussians, then every further keyframe — the rig of SURVEY 8d continued: yaw (k - frames/2) * 4 deg about +y, x = (k - frames/2) * 0.25 m —
+    appends, through trainer.GaussianModel.extend(), the points of ITS LiDAR frame that land on pixels the map does not cover yet.  Rows stay in
+    insertion order: what the reference host hands the drop-in boundary.  Returns (model in insertion order, the middle keyframe's camera)."""
+    from gaussian_lic_amd import trainer
+    from gaussian_lic_amd.camera import synthetic_camera
+    from gaussian_lic_amd.synthetic import lidar_scene, place_scene
+    from gaussian_lic_amd.trainer import DEFAULT_LRS
+    W, H = args.width, args.height
+    per = max(args.gaussians // 16, 1024)
+    views = [dict(ypr=((k - frames / 2.0) * 4.0, 0.0, 0.0), t=((k - frames / 2.0) * 0.25, 0.0, 0.0), place=True) for k in range(frames)]
+    cams = [synthetic_camera(W, H, v).to_device(dev) for v in views]
+    from gaussian_lic_amd.camera import resolve_view
+    model, inserted = None, []
+    for k, (v, cam) in enumerate(zip(views, cams)):
+        fr = lidar_scene(per, W, H, sh_degree=3, seed=300 + k)           # generated in the identity camera frame ...
+        Rwc, twc, _ = resolve_view(v)
+        fw = place_scene(fr, Rwc, twc)                                    # ... and moved rigidly into keyframe k's frame
+        if model is None:
+            model = trainer.GaussianModel(fw, dev, capacity=int(frames * per * 1.02), order="insertion")
+            inserted.append(model.P)
+            continue
+        col = (fr["features_dc"].reshape(-1, 3) * 0.28209479177387814 + 0.5).to(dev)
+        Rcw = torch.from_numpy(cam.world_view_transform[:3, :3].T.copy())
+        tcw = torch.from_numpy(cam.world_view_transform[3, :3].copy())
+        intr = (float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy))
+        inserted.append(int(model.extend(cam, fw["xyz"].to(dev), col, fr["xyz"][:, 2].contiguous().to(dev), Rcw, tcw, intr)))
+    model.training_setup({k_: v_ * args.lr_scale for k_, v_ in DEFAULT_LRS.items()})
+    return model, cams[frames // 2], inserted
+
+
+def dropin_legs(args, dev):
+    """`bench.py --leg dropin` (a process of its own, run by default since round 6): what a host that keeps the reference's operator API gets.
+      cpp.reference_host_lines_cpp   the reference's OWN host code compiled unmodified (dropin_check*.cpp: renderer.cpp / rasterizer.cpp / loss_utils.h /
+                                     optim_utils.h read in place) on libgslic_torch_shim.so — with the rows as the host keeps them (as generated) and, for
+                                     reference, pre-sorted into Morton order by the host
+      python_mirror                  the same lines through the Python mirror of the operator API (trainer.training_step)
+      fused_insertion_order          the framework's fused step on the rows as generated: the like-for-like denominator of the drop-in ratio
+      slam_like_map                  a map grown by extend() over 24 keyframes, rows in insertion order (what `auto` binning measures on it, the fused
+                                     and the drop-in step on it, and the same map re-sorted into Morton order)"""
+    import gaussian_lic_amd  # noqa: F401
+    from gaussian_lic_amd import _lib, trainer
+    from gaussian_lic_amd.camera import synthetic_camera
+    from gaussian_lic_amd.synthetic import gt_image, lidar_scene, random_scene
+    from gaussian_lic_amd.trainer import DEFAULT_LRS
+    W, H, P = args.width, args.height, args.gaussians
+    raw = (random_scene if args.scene == "random" else lidar_scene)(P, W, H, sh_degree=3, seed=0)
+    cam = synthetic_camera(W, H).to_device(dev)
+    gt, bg = gt_image(H, W, seed=2).to(dev), torch.zeros(3, device=dev)
+    lrs = {k: v * args.lr_scale for k, v in DEFAULT_LRS.items()}
+    n = max(60, min(args.steps, 100))   # (its own step count: the driver's --steps 20 is too short for a stable leg)
+
+    def timed_loop(fn, k):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        o0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - o0
+
+    def rate(fn, k=n):
+        sec = timed_loop(fn, k)
+        return {"value": round(k / sec, 3), "unit": "views/s", "ms_per_step": round(1e3 * sec / k, 3), "steps": k}
+
+    def kernel_ms(fn, names, k=20):
+        _lib.profile_reset(); _lib.profile_enable(True, only=list(names))
+        for _ in range(k):
+            fn()
+        res = _lib.profile_collect(); _lib.profile_enable(False)
+        return {a: round(v[0] / max(v[1], 1), 4) for a, v in res.items()}
+
+    out = {"learning_rates": f"reference x {args.lr_scale:g} for the Python legs (as `value`); the C++ programs run the reference's own rates"}
+    _freeze_gc()
+    both = {}
+    sort_ms = None
+    for order in ("insertion", "morton"):
+        _trace(f"dropin: bench map, rows in {order} order")
+        model = trainer.GaussianModel(raw, dev, order=order)
+        model.training_setup(lrs)
+        if order == "morton":
+            sort_ms = {"construction_cpu_numpy_ms": model.sort_ms[0] if model.sort_ms else None}
+        for _ in range(25):
+            trainer.training_step_fused(model, cam, gt, bg)
+        torch.cuda.synchronize()
+        leg = {"fused_step": rate(lambda: trainer.training_step_fused(model, cam, gt, bg)), "binning_path_auto": _lib.binning_path()}
+        leg["python_mirror_dropin_renderer"] = rate(lambda: trainer.training_step(model, cam, gt, bg))
+        leg["python_mirror_dropin_renderer"]["binning_path_auto"] = _lib.binning_path()
+        prev_raw = os.environ.get("GSLIC_RENDER_RAW")
+        os.environ["GSLIC_RENDER_RAW"] = "0"
+        try:
+            leg["python_mirror_renderer_as_written"] = rate(lambda: trainer.training_step(model, cam, gt, bg))
+        finally:
+            if prev_raw is None:
+                os.environ.pop("GSLIC_RENDER_RAW", None)
+            else:
+                os.environ["GSLIC_RENDER_RAW"] = prev_raw
+        try:
+            leg["cpp"] = cpp_fused_host(args, model, cam, gt, n, fused=(order == args.map_order), tag="rows_" + order)
+        except Exception as ex:
+            leg["cpp"] = {"error": str(ex)[:200]}
+        if order == "morton":   # what the periodic re-sort of a grown map costs on the device (GaussianModel.resort)
+            model.resort()
+            sort_ms["resort_on_device_ms"] = model.sort_ms[-1]
+        both[order] = leg
+        del model
+        torch.cuda.empty_cache()
+    out["map_order_sort_ms"] = sort_ms
+    out["rows_as_generated"] = both["insertion"]
+    out["rows_in_morton_order"] = both["morton"]
+    out["fused_insertion_order"] = both["insertion"]["fused_step"]
+    lines_ins = (both["insertion"].get("cpp") or {}).get("reference_host_lines_cpp") or {}
+    ref_ins = lines_ins.get("reference_host_unmodified") or lines_ins.get("reference_renderer_cpp") or {}
+    out["headline_dropin"] = (dict(ref_ins, what=("reference_host_unmodified" if lines_ins.get("reference_host_unmodified") else "reference_renderer_cpp") +
+                                   " (C++) on the rows as generated") if ref_ins.get("value") else None)
+    out["python_mirror"] = {"map_order_of_value": dict(both[args.map_order]["python_mirror_dropin_renderer"], host="dropin",
+                                                        what="reference operator API + LibTorch autograd (Python mirror), drop-in renderer, rows in --map-order",
+                                                        renderer_as_written=both[args.map_order]["python_mirror_renderer_as_written"]),
+                            "rows_as_generated": both["insertion"]["python_mirror_dropin_renderer"]}
+    out["cpp"] = both[args.map_order].get("cpp")
+    if ref_ins.get("value"):
+        out["ratio_dropin_to_fused_same_row_order"] = round(ref_ins["value"] / both["insertion"]["fused_step"]["value"], 3)
+    # ---- a map grown by extend(), in insertion order (the reference's own growth pattern)
+    try:
+        _trace("dropin: slam-like map")
+        m, cam_s, inserted = slam_like_map(args, dev)
+        gt_s = gt
+        for _ in range(10):
+            trainer.training_step_fused(m, cam_s, gt_s, bg)
+        torch.cuda.synchronize()
+        prevb = _lib.set_binning_mode("atomic")
+        trainer.training_step_fused(m, cam_s, gt_s, bg); torch.cuda.synchronize()
+        forced = _lib.binning_path()
+        _lib.set_binning_mode("auto")
+        for _ in range(3):
+            trainer.training_step_fused(m, cam_s, gt_s, bg)
+        torch.cuda.synchronize()
+        auto = _lib.binning_path()
+        names = ("preprocess_bwd", "preprocess", "tile_bin", "tile_hist", "sort_scatter", "sort_hist", "tile_lsort", "keybuild", "render_fwd", "render_bwd")
+        slam = {"gaussians": m.P, "keyframes": len(inserted), "inserted_per_keyframe": inserted,
+                "binning_forced_atomic": {"sampled_atomics": forced[1], "sampled_instances": forced[2], "atomics_per_instance": round(forced[1] / max(forced[2], 1), 4)},
+                "binning_auto_path": auto[0],
+                "insertion_order": {"fused_step": rate(lambda: trainer.training_step_fused(m, cam_s, gt_s, bg)),
+                                    "python_mirror_dropin_renderer": rate(lambda: trainer.training_step(m, cam_s, gt_s, bg)),
+                                    "kernel_ms_per_launch": kernel_ms(lambda: trainer.training_step_fused(m, cam_s, gt_s, bg), names)}}
+        raw_s = {k_: getattr(m, k_).detach().cpu() for k_ in m.NAMES}
+        raw_s["sh_degree"] = m.sh_degree
+        mm = trainer.GaussianModel(raw_s, dev, order="morton")
+        mm.training_setup(lrs)
+        for _ in range(10):
+            trainer.training_step_fused(mm, cam_s, gt_s, bg)
+        torch.cuda.synchronize()
+        slam["morton_order"] = {"fused_step": rate(lambda: trainer.training_step_fused(mm, cam_s, gt_s, bg)), "binning_auto_path": _lib.binning_path()[0],
+                                "kernel_ms_per_launch": kernel_ms(lambda: trainer.training_step_fused(mm, cam_s, gt_s, bg), names)}
+        _lib.set_binning_mode(prevb)
+        out["slam_like_map"] = slam
+    except Exception as ex:
+        out["slam_like_map"] = {"error": str(ex)[:300]}
+    return out
+
+
 def growth_schedule(args, dev):
     """SURVEY.md section 8d, config 3 as written: the map starts at 75 % of --gaussians and grows by five extend() appends of LiDAR frames
     (one every 20 iterations) over 100 training iterations at the reference's learning rates — the reference's only densification
@@ -1036,7 +1236,7 @@ def growth_schedule(args, dev):
     keep = torch.nonzero(u_pix < 0.7 * W).squeeze(1)[:P_start]
     assert keep.numel() == P_start, "not enough Gaussians left of the uncovered strip"
     raw = {k: (v[keep].contiguous() if torch.is_tensor(v) else v) for k, v in big.items()}
-    model = trainer.GaussianModel(raw, dev, capacity=int(1.05 * P), order=args.map_order)
+    model = trainer.GaussianModel(raw, dev, capacity=int(1.05 * P), order=args.map_order, resort_fraction=None)   # (this leg cuts every append to n_frame rows: it re-sorts itself, below)
     model.training_setup()
     cam = synthetic_camera(W, H).to_device(dev)
     gt = gt_image(H, W, seed=2).to(dev)
@@ -1062,6 +1262,7 @@ def growth_schedule(args, dev):
         xyz = torch.stack([(px_ - intr[2]) * z / intr[0], (py_ - intr[3]) * z / intr[1], z], 1).contiguous()
         col = torch.rand(n_cand, 3, generator=g)
         frames.append((xyz.to(dev), col.to(dev), z.contiguous().to(dev)))
+    _freeze_gc()
     P0 = model.P
     warm = model.extend(cam, *frames[0], Rcw, tcw, intr)     # warm-up: one-off allocations of extend(); its rows are dropped again
     model.P = P0
@@ -1070,7 +1271,7 @@ def growth_schedule(args, dev):
         trainer.training_step_fused(model, cam, gt, bg)
     torch.cuda.synchronize()
     clocks0 = _gpu_clocks()
-    P1, inserted, ext_ms, survivors = model.P, 0, 0.0, []
+    P1, inserted, ext_ms, survivors, resorts = model.P, 0, 0.0, [], 0
     from gaussian_lic_amd import _lib
     _lib.profile_reset()
     _lib.profile_enable(True, only=["render_bwd", "preprocess_bwd", "render_fwd"])   # (three event pairs per step: where a slow run loses its time)
@@ -1086,6 +1287,9 @@ def growth_schedule(args, dev):
                 model.P = p_before + n_frame
                 model._rebind()
             inserted += min(int(k_ins), n_frame)
+            if model.tie_rank is not None and (model.P - model._sorted_P) > 0.1 * model.P:
+                model.resort()        # the appended tail passed 10 % of the map: Morton order again, on the device (timed: part of extend_ms)
+                resorts += 1
             e1 = time.perf_counter()
             ext_ms += 1e3 * (e1 - e0)
             seg_ms.append(1e3 * (e0 - t0))   # (the device is idle at e0: extend() of the previous segment synchronised, or nothing ran yet)
@@ -1098,7 +1302,7 @@ def growth_schedule(args, dev):
     return {"workload": f"SURVEY 8d config 3 schedule: {P1} -> {model.P} Gaussians by 5 extend() appends (every 20 iterations), 100 iterations, reference learning rates",
             "warmup_frame_inserted_then_dropped": int(warm), "candidates_per_frame": n_cand, "survivors_per_frame": survivors, "clocks_before": clocks0, "clocks_after": _gpu_clocks(),
             "value": round(100.0 / sec, 3), "unit": "views/s", "ms_per_iteration": round(10.0 * sec, 3), "iterations": 100, "appends": 5,
-            "gaussians_start": P1, "gaussians_end": model.P, "inserted": inserted, "extend_ms_per_call": round(ext_ms / 5.0, 3),
+            "gaussians_start": P1, "gaussians_end": model.P, "inserted": inserted, "extend_ms_per_call": round(ext_ms / 5.0, 3), "resorts_into_morton_order": resorts, "sort_ms": model.sort_ms,
             "gaussians_before_warmup_frame": P0,
             "kernel_ms_per_launch": {k: round(v[0] / max(v[1], 1), 4) for k, v in kms.items()},
             "ms_per_20_iterations": [round(b - a, 2) for a, b in zip(seg_ms[:-1], seg_ms[1:])]}

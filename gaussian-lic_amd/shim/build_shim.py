@@ -40,6 +40,7 @@ CHECK_DIST = os.path.join(PKG, "dropin_check_dist")
 CHECK_RENDER_REF = os.path.join(PKG, "dropin_check_render_ref")   # render() of the REFERENCE's renderer.cpp (on the stand-in Camera / GaussianModel)
 CHECK_RENDER = os.path.join(PKG, "dropin_check_render")           # render() of shim/renderer.cpp, the drop-in replacement
 CHECK_RENDER_LOSS = os.path.join(PKG, "dropin_check_render_loss") # ... + the optional one-node loss (loss_utils_fused.h)
+CHECK_RENDER_REFHOST = os.path.join(PKG, "dropin_check_render_refhost")   # EVERY host line the reference's: its renderer.cpp AND its optim_utils.h (six clones + six launches)
 
 
 def build_dropin_check(force=False, groups=False):
@@ -52,6 +53,12 @@ def build_dropin_check(force=False, groups=False):
     if groups == "dist":   # + the N > 1 exchange step over c10d / RCCL (shim/include/gslic_dist.h) between loss.backward() and step()
         return _build_check(CHECK_DIST, ["-DGSLIC_DIST", "-DUSE_C10D_NCCL", "-DUSE_ROCM", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(HERE, "include"),
                                          "-I", os.path.join(HERE, "include", "nccl_fwd"), "-isystem", "/opt/rocm/include"], force)
+    if groups == "render_refhost":
+        # nothing of this repository's on the include path but the stand-in Camera / GaussianModel types: the reference's renderer.cpp, rasterizer.cpp,
+        # loss_utils.h and optim_utils.h (SparseGaussianAdam::custom_step: grad.clone() + adamUpdate per group, :102-137) as they are — what bench.py
+        # reports as the drop-in host's rate
+        return _build_check(CHECK_RENDER_REFHOST, ["-DGSLIC_CHECK_RENDER", "-I", os.path.join(HERE, "standin")], force,
+                            extra_src=[os.path.join(REF_SRC, "rasterizer", "renderer.cpp")])
     if groups in ("render_ref", "render", "render_loss"):
         # this repo's optim_utils.h (one Adam launch) in all three, so that the renderer / the loss is the only thing that differs
         inc = ["-DGSLIC_CHECK_RENDER", "-I", os.path.join(HERE, "standin"), "-I", os.path.join(HERE, "include")]
@@ -125,6 +132,6 @@ if __name__ == "__main__":
     print(build_dropin_check(force="--force" in sys.argv))
     print(build_dropin_check(force="--force" in sys.argv, groups=True))
     print(build_dropin_check(force="--force" in sys.argv, groups="dist"))
-    for g in ("render_ref", "render", "render_loss"):
+    for g in ("render_ref", "render", "render_loss", "render_refhost"):
         print(build_dropin_check(force="--force" in sys.argv, groups=g))
     print(build_fused_check(force="--force" in sys.argv))

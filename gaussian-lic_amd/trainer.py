@@ -39,6 +39,32 @@ def morton_order(xyz, bits=10):
     return torch.from_numpy(np.argsort(code, kind="stable").astype(np.int64))
 
 
+def morton_order_device(xyz, bits=10):
+    """morton_order with torch ops on xyz's own device (a few ms for 2M rows on the GPU: what GaussianModel.resort() runs between keyframes).
+    Same construction — `bits` per axis over a robust bounding box (the 0.1 % / 99.9 % order statistics per axis), outliers clamped, ties in row
+    order (stable sort) — but not necessarily the same permutation as the numpy version to the last row: any permutation renders and trains
+    bit-identically (tie_rank), the order only decides how coherent memory is."""
+    assert bits <= 10
+    q = xyz.detach().float()
+    P = int(q.shape[0])
+    # the robust box from a strided sample of at most 65 536 rows (sorted per axis): the bounds only place the quantisation grid, and
+    # torch.kthvalue over all rows cost 100 ms of the 103 a re-sort of 2M rows took (profiles/r06d: resort_on_device_ms)
+    smp = q[::max(1, P // 65536)]
+    srt = torch.sort(smp, dim=0).values
+    n_s = int(srt.shape[0])
+    lo, hi = srt[min(n_s - 1, int(0.001 * n_s))], srt[max(0, min(n_s - 1, int(0.999 * n_s)))]
+    u = (((q - lo) / (hi - lo).clamp_min(1e-30)).clamp(0.0, 1.0) * ((1 << bits) - 1)).to(torch.int64)
+
+    def spread(v):   # 10 bits -> every third bit
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    code = spread(u[:, 0]) | (spread(u[:, 1]) << 1) | (spread(u[:, 2]) << 2)
+    return torch.sort(code, stable=True).indices
+
+
 class GaussianModel:
     """Parameters + activations of src/gaussian.{h,cpp} that the hot path touches, with capacity-doubling storage so that
     extend() appends rows in place instead of six torch::cat reallocations of every parameter and Adam moment per keyframe
@@ -47,15 +73,23 @@ class GaussianModel:
     NAMES = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")   # group order of gaussian.cpp:399-418
     raw_parameter_leaves = True   # the attributes of those names are the PRE-activation leaves: rasterizer.render() may feed them to the raw-parameter node
 
-    def __init__(self, raw, device, lambda_erank=0.0, capacity=None, scaling_scale=1.0, order="insertion"):
+    def __init__(self, raw, device, lambda_erank=0.0, capacity=None, scaling_scale=1.0, order="insertion", resort_fraction=0.1):
         """order = "insertion": rows in the order given (the reference's: initialize() then extend() appends).
         order = "morton": the rows are stored sorted by the Morton code of their position (morton_order): what a camera sees is then contiguous
         in memory, whole waves of the per-Gaussian kernels are invisible and skip, and the 128-byte lines of parameters and Adam moments are
         no longer shared between visible and invisible rows.  self.tie_rank[s] = original index of storage row s: the forward breaks depth
         ties by it (gslic_raster_params.tie_rank), so rendering and training are bit-identical to the insertion order; original_order() /
-        io_ply.save_map() give the rows back in the original order.  Rows appended by extend() keep their insertion order behind the sorted block."""
+        io_ply.save_map() give the rows back in the original order.  Rows appended by extend() keep their insertion order behind the sorted block;
+        once they make up more than `resort_fraction` of the map, extend() re-sorts the whole map on the device (resort(): a few ms between
+        keyframes; None = never) — the coherence the layout is for would otherwise decay as a SLAM map grows.
+        self.sort_ms: what the sorts cost (the construction's CPU sort, then the device re-sorts), for the record next to a throughput number."""
         self.sh_degree = int(raw["sh_degree"])
         self._tie = None
+        self.order = order
+        self.resort_fraction = resort_fraction if order == "morton" else None
+        self.sort_ms = []
+        import time as _time
+        _t0 = _time.perf_counter()
         if order == "morton":
             perm = morton_order(raw["xyz"])
             raw = {k: (v[perm].contiguous() if (torch.is_tensor(v) and k in self.NAMES) else v) for k, v in raw.items()}
@@ -77,8 +111,32 @@ class GaussianModel:
         if perm is not None:
             self._tie = torch.empty(cap, dtype=torch.int32, device=device)
             self._tie[:self.P].copy_(perm.to(torch.int32))
+            self.sort_ms.append(round(1e3 * (_time.perf_counter() - _t0), 2))   # (CPU sort + the permuted upload, once, outside any timed region)
+        self._sorted_P = self.P      # rows [0, _sorted_P) are in Morton order (order == "morton")
         self.optimizer = None
         self._rebind()
+
+    @torch.no_grad()
+    def resort(self):
+        """Puts ALL rows back into Morton order (order == "morton" only): parameters, both Adam moments and tie_rank are permuted together on the
+        device, so the map renders, trains and exports exactly as before (tie_rank still holds every row's ORIGINAL index).  Invalidates hipGraph
+        captures of nothing (addresses do not change) but any per-row state a host keeps outside the model must be permuted by the same index:
+        returns the permutation applied (LongTensor [P] on the device; new row s = old row perm[s])."""
+        assert self._tie is not None, "resort(): the model keeps its rows in insertion order"
+        import time as _time
+        torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
+        t0 = _time.perf_counter()
+        P = self.P
+        perm = morton_order_device(self._buf["xyz"][:P])
+        for d in (self._buf, self._m, self._v):
+            for n in self.NAMES:
+                d[n][:P] = d[n][:P][perm]
+        self._tie[:P] = self._tie[:P][perm]
+        self._sorted_P = P
+        self._rebind()
+        torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
+        self.sort_ms.append(round(1e3 * (_time.perf_counter() - t0), 2))
+        return perm
 
     @property
     def tie_rank(self):
@@ -177,6 +235,8 @@ class GaussianModel:
         self.P = P0 + k
         self._rebind()
         torch.cuda.current_stream().synchronize()  # scratch (flags/pos) is released on return
+        if self._tie is not None and self.resort_fraction is not None and (self.P - self._sorted_P) > self.resort_fraction * self.P:
+            self.resort()    # the appended tail has grown past resort_fraction of the map: Morton order again (a few ms, between keyframes)
         return k
 
 
@@ -185,7 +245,7 @@ def exchange_mode():
     exchange_rank1), "dense" (the whole [P x 59] slab all-reduced in three pipelined segments), "sparse" (only the rows some view sees).
     GSLIC_EXCHANGE selects; GSLIC_SPARSE_EXCHANGE=1 is the older spelling of "sparse"."""
     m = os.environ.get("GSLIC_EXCHANGE", "").lower()
-    if m in ("rank1", "dense", "sparse"):
+    if m in ("rank1", "dense", "sparse", "single"):   # "single": north_star's wording to the letter — ONE all-reduce per step (allreduce_slab_single)
         return m
     return "sparse" if os.environ.get("GSLIC_SPARSE_EXCHANGE") == "1" else "rank1"
 
@@ -226,7 +286,10 @@ class GradSlab:
         self.P = model.P
         shapes = [tuple(p.shape) for p in model.parameters()]
         sizes = [int(torch.tensor(s).prod()) for s in shapes]
-        self.flat = torch.empty(sum(sizes), device=model.device)
+        # (the slab is followed by P more floats: GSLIC_EXCHANGE=single ships the visibility mask in the SAME all-reduce, allreduce_slab_single)
+        self.flat_and_mask = torch.empty(sum(sizes) + self.P, device=model.device)
+        self.flat = self.flat_and_mask[:sum(sizes)]
+        self.mask_f = self.flat_and_mask[sum(sizes):]
         # exchange_rank1's all-gather payload of THIS rank, one contiguous block: {colour gradient [P,3] fp32, camera centre [3] fp32,
         # visibility [P] bytes, padding to 4 bytes}; `rgb` (what the backward writes), `pay_campos` and `pay_vis` are views into it
         self.pay_bytes = (12 * self.P + 12 + self.P + 3) // 4 * 4
@@ -268,6 +331,17 @@ def allreduce_slab(slab, visible):
     torch.distributed.all_reduce(slab.flat, op=torch.distributed.ReduceOp.SUM)
     torch.distributed.all_reduce(vis, op=torch.distributed.ReduceOp.MAX)
     return vis.bool()
+
+
+def allreduce_slab_single(slab, visible):
+    """GSLIC_EXCHANGE=single — the exchange exactly as north_star words it: "a single RCCL all-reduce of Gaussian gradients over xGMI per optimiser
+    step".  ONE SUM all-reduce of [P x 59] gradient floats + P floats carrying the visibility mask (0 / 1 per view: the sum is > 0 where some view
+    sees the Gaussian — the OR), one collective on the wire instead of the default's three, at 4 (59 + 1) P bytes per rank and direction against
+    rank-1's 44 P + (N - 1) 13 P (480 vs 114-336 MB at 2M Gaussians, N = 2-8).  Kept selectable so that the first run on real links measures both
+    designs in one command (bench.py --gpus N reports `exchange.mode`)."""
+    slab.mask_f.copy_(visible)
+    torch.distributed.all_reduce(slab.flat_and_mask, op=torch.distributed.ReduceOp.SUM)
+    return slab.mask_f > 0
 
 
 def allreduce_slab_async(slab, visible, model):
@@ -612,6 +686,10 @@ def training_step_fused(model, camera, gt_image, bg, fused_loss=None, do_step=Tr
                 _dist_mark("bwd_done")
             if mode == "sparse":
                 visible, _rows = allreduce_slab_sparse(slab, visible, model)   # visible rows only: fewer bytes on the links, one gather / scatter pass
+                model.optimizer.set_visibility_and_N(visible, model.P)
+                model.optimizer.step(slab.grads(model))
+            elif mode == "single":
+                visible = allreduce_slab_single(slab, visible)                 # ONE collective: slab + mask (north_star's wording)
                 model.optimizer.set_visibility_and_N(visible, model.P)
                 model.optimizer.step(slab.grads(model))
             elif _dist_on():

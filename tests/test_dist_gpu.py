@@ -208,7 +208,8 @@ def test_two_ranks_rank1_exchange_equals_dense():
         return subprocess.Popen([sys.executable, "-c", TWO_RANK_SNIPPET.format(root=ROOT)], env=env, stdout=subprocess.PIPE,
                                 stderr=subprocess.PIPE, text=True)
     digests = []
-    for mode, port in (("dense", "29575"), ("rank1", "29577")):
+    # ... and GSLIC_EXCHANGE=single (round 6: north_star's "single all-reduce" to the letter — slab and mask in ONE collective): the same bits again
+    for mode, port in (("dense", "29575"), ("rank1", "29577"), ("single", "29579")):
         procs = [run(0, mode, port), run(1, mode, port)]
         outs = [p.communicate(timeout=600) for p in procs]
         for p, (so, se) in zip(procs, outs):
@@ -216,7 +217,7 @@ def test_two_ranks_rank1_exchange_equals_dense():
         d = [[l for l in so.splitlines() if l.startswith("DIGEST")][-1].split()[2] for so, _ in outs]
         assert d[0] == d[1]
         digests.append(d[0])
-    assert digests[0] == digests[1]
+    assert digests[0] == digests[1] == digests[2]
 
 
 RCCL2_SNIPPET = r"""

@@ -44,6 +44,20 @@ def _worker(rank, world, port, q):
     for a, b in zip(slab.grads(_M()), red):
         assert torch.equal(a, b)
     assert torch.equal(svis, rvis)
+    # GSLIC_EXCHANGE=single: slab AND mask in ONE all-reduce (north_star's wording): same sums bit for bit (two addends), mask = OR
+    for v, x in zip(slab.grads(_M()), grads):
+        v.copy_(x)
+    calls = []
+    real_all_reduce = torch.distributed.all_reduce
+    torch.distributed.all_reduce = lambda *a, **k: (calls.append(1), real_all_reduce(*a, **k))[1]
+    try:
+        onevis = trainer.allreduce_slab_single(slab, vis)
+    finally:
+        torch.distributed.all_reduce = real_all_reduce
+    assert len(calls) == 1                      # exactly one collective
+    for a, b in zip(slab.grads(_M()), red):
+        assert torch.equal(a, b)
+    assert onevis.dtype == torch.bool and torch.equal(onevis, rvis)
     # the pipelined variant of the fused step: three asynchronous segment all-reduces, consumed in order
     for v, x in zip(slab.grads(_M()), grads):
         v.copy_(x)

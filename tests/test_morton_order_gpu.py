@@ -100,7 +100,7 @@ def test_morton_model_graphed_step_and_extend_and_save_map(tmp_path):
     keep = u_pix < 0.7 * W      # the map does not cover the right 30 % of the image yet: that is where extend() inserts LiDAR points
     raw = {k: (v[keep].contiguous() if torch.is_tensor(v) else v) for k, v in raw.items()}
     P = int(raw["xyz"].shape[0])
-    a, b = _models(raw, dev, capacity=2 * P)
+    a, b = _models(raw, dev, capacity=2 * P, resort_fraction=None)   # (no automatic re-sort: the appended rows' place is asserted below; resort() is exercised at the end)
     cam = synthetic_camera(W, H).to_device(dev)
     gt, bg = gt_image(H, W).to(dev), torch.zeros(3, device=dev)
     ga, gb = trainer.GraphedStep(a, cam, gt, bg, check_every=0, use_graph=True), trainer.GraphedStep(b, cam, gt, bg, check_every=0, use_graph=True)
@@ -128,3 +128,51 @@ def test_morton_model_graphed_step_and_extend_and_save_map(tmp_path):
     pa, pb = str(tmp_path / "a.ply"), str(tmp_path / "b.ply")
     io_ply.save_map(a, pa); io_ply.save_map(b, pb)
     assert open(pa, "rb").read() == open(pb, "rb").read()
+    # resort(): the grown map back in Morton order on the device — parameters, moments and tie_rank permuted together: still the same map, it keeps
+    # training bit-identically, and saveMap still writes the original order
+    tail_before = b.tie_rank[P:].clone()
+    perm = b.resort()
+    assert sorted(perm.cpu().tolist()) == list(range(b.P)) and not torch.equal(b.tie_rank[P:], tail_before)
+    assert sorted(b.tie_rank.cpu().tolist()) == list(range(b.P))
+    _same_map(a, b)
+    for _ in range(2):
+        trainer.training_step_fused(a, cam, gt, bg); trainer.training_step_fused(b, cam, gt, bg)
+    _same_map(a, b)
+    io_ply.save_map(b, pb)
+    assert open(pa, "rb").read() != open(pb, "rb").read()      # (two more steps: the file moved ...)
+    io_ply.save_map(a, pa)
+    assert open(pa, "rb").read() == open(pb, "rb").read()      # (... to the same bytes)
+
+
+def test_extend_resorts_a_morton_map_once_the_appended_tail_is_large():
+    """rows appended by extend() sit behind the sorted block, so the layout's coherence decays as a SLAM map grows.  With
+    resort_fraction (default 0.1) extend() re-sorts the map on the device once the unsorted tail passes that share: same map bit for bit as the
+    insertion-order model through appends, re-sorts and training steps; the sorts' cost is recorded (model.sort_ms)."""
+    from gaussian_lic_amd import trainer
+    from gaussian_lic_amd.camera import synthetic_camera
+    from gaussian_lic_amd.synthetic import gt_image, lidar_scene
+    dev = torch.device("cuda:0")
+    W, H = 320, 192
+    raw = _scene(30000, W, H, 11)
+    u_pix = raw["xyz"][:, 0] * (0.675 * W) / raw["xyz"][:, 2].abs().clamp_min(0.2) + 0.4857 * W
+    keep = u_pix < 0.6 * W
+    raw = {k: (v[keep].contiguous() if torch.is_tensor(v) else v) for k, v in raw.items()}
+    a, b = _models(raw, dev)
+    assert b.resort_fraction == 0.1 and a.resort_fraction is None
+    cam = synthetic_camera(W, H).to_device(dev)
+    gt, bg = gt_image(H, W).to(dev), torch.zeros(3, device=dev)
+    Rcw = torch.from_numpy(cam.world_view_transform[:3, :3].T.copy())
+    tcw = torch.from_numpy(cam.world_view_transform[3, :3].copy())
+    intr = (float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy))
+    sorts = len(b.sort_ms)
+    for f in range(4):
+        frame = lidar_scene(1500, W, H, sh_degree=3, seed=80 + f)
+        pts = frame["xyz"].to(dev)
+        col = (frame["features_dc"].reshape(-1, 3) * 0.28209479177387814 + 0.5).to(dev)
+        rsp = frame["xyz"][:, 2].contiguous().to(dev)
+        assert a.extend(cam, pts, col, rsp, Rcw, tcw, intr) == b.extend(cam, pts, col, rsp, Rcw, tcw, intr)
+        for _ in range(2):
+            trainer.training_step_fused(a, cam, gt, bg); trainer.training_step_fused(b, cam, gt, bg)
+        _same_map(a, b)
+    assert len(b.sort_ms) > sorts and b._sorted_P > int(keep.sum())       # (at least one automatic re-sort happened on the way)
+    assert (b.P - b._sorted_P) <= 0.1 * b.P
