@@ -1161,9 +1161,9 @@ def dropin_legs(args, dev):
             leg["cpp"] = cpp_fused_host(args, model, cam, gt, n, fused=(order == args.map_order), tag="rows_" + order)
         except Exception as ex:
             leg["cpp"] = {"error": str(ex)[:200]}
-        if order == "morton":   # what the periodic re-sort of a grown map costs on the device (GaussianModel.resort)
-            model.resort()
-            sort_ms["resort_on_device_ms"] = model.sort_ms[-1]
+        if order == "morton":   # what the periodic re-sort of a grown map costs on the device (GaussianModel.resort): first call (LibTorch kernels load), then steady
+            model.resort(); model.resort()
+            sort_ms["resort_on_device_first_call_ms"], sort_ms["resort_on_device_ms"] = model.sort_ms[-2], model.sort_ms[-1]
         both[order] = leg
         del model
         torch.cuda.empty_cache()
@@ -1263,6 +1263,8 @@ def growth_schedule(args, dev):
         col = torch.rand(n_cand, 3, generator=g)
         frames.append((xyz.to(dev), col.to(dev), z.contiguous().to(dev)))
     _freeze_gc()
+    if model.tie_rank is not None:
+        model.resort()      # warm-up of the re-sort's LibTorch kernels (their first use loads code objects: 0.5 s once per process; 4 ms per re-sort after that)
     P0 = model.P
     warm = model.extend(cam, *frames[0], Rcw, tcw, intr)     # warm-up: one-off allocations of extend(); its rows are dropped again
     model.P = P0

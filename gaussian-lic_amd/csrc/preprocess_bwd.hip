@@ -137,7 +137,10 @@ __device__ __forceinline__ void small_groups_sink(const AdamFusedArgs& A, float*
 // What the pass needs per Gaussian — c_0..c_14 and the clamp-masked dRGB — sits in a 64 x 19 float table.  LDS per wave 8.6 KB (table 4.75,
 // q 3.75) against the 11.3 KB of staging whole rows in and gradient rows out: 16 waves per CU instead of 13 (the kernel streams ~100 bytes
 // per flop: occupancy IS its memory-level parallelism, profiles/r03p_pbwd_occupancy.log), and features_rest is fetched once, not twice.
-static constexpr int SHT = 19;   // table row stride (odd: rows of one column sit in different banks)
+#ifndef GS_SHT
+#define GS_SHT 19
+#endif
+static constexpr int SHT = GS_SHT;   // table row stride (odd: rows of one column sit in different banks).  18 / 20 / 21 / 23 measured in round 6 (-DGS_SHT=n): see DESIGN section 4
 
 // (rem * 43) >> 7 == rem / 3 for 0 <= rem < 48
 __device__ __forceinline__ int div3_small(int rem) { return (rem * 43) >> 7; }
