@@ -125,15 +125,6 @@ __device__ __forceinline__ void half_or(uint32_t v, uint32_t& lo_half, uint32_t&
 #endif
 }
 
-// GS_SCAN_GROUP_OUTER (round 6): the loop nest of a block pass turned inside out — entry GROUP outside, pixel chunks inside — so that only ONE
-// group's entry and nine sums live in registers (the template per group count is gone): see block_pass_go.
-#ifndef GS_SCAN_GROUP_OUTER
-#define GS_SCAN_GROUP_OUTER 0
-#endif
-#ifndef GS_SCAN_UNROLL
-#define GS_SCAN_UNROLL 2
-#endif
-
 struct ScanEntry {     // one list entry of the bucket, as the pipeline's BwdLane holds it
     float d0x, d0y;    // centre relative to the tile origin
     float hA, hC, nB;  // log2(e)-scaled conic: -1/2 A, -1/2 C, -B
@@ -148,11 +139,7 @@ constexpr int SC_ENT_F4 = 3;               // float4 per staged entry
 struct ScanLds {
     float4 ent[64 * SC_ENT_F4];       // the bucket's 64 entries (stride 12 floats)
     float acc[64 * 9];                // their nine sums, accumulated over the four quadrants
-#if GS_SCAN_GROUP_OUTER
-    uint8_t list[2 * 64];             // compacted entry indices of the two half quadrants being worked on (bytes: 8144 B per wave = twenty waves per CU)
-#else
     uint32_t list[2 * 64];            // compacted entry indices of the two half quadrants being worked on
-#endif
     float2 ta[SC_NENT], rg[SC_NENT], bx[SC_NENT], py[SC_NENT];   // pixel records in compacted order: {T, A} {g.r, g.g} {g.b, px} {py, -}
     uint2 hm[SC_NENT];                // ... and the pixel's decision mask
 };
@@ -245,92 +232,9 @@ __device__ __forceinline__ void block_pass(ScanLds& S, const int lane, const int
     }
 }
 
-// The same pass with the GROUP loop outside.  A pixel's state {T, A} behind a group's sixteenth entry — what block_pass hands to the next group
-// in registers (row_newbcast) — goes back into the pixel's LDS record, where the next group's chunk loop finds it; everything else a (pixel,
-// entry) pair computes is block_pass's, operation for operation, and so is the order of every sum: the results are bit-identical.  Costs: the
-// pixel records are read once per group instead of once (1.9 groups on average), one 8-byte LDS store per (chunk, group) but the last group.
-// Buys: 21 registers of entry state instead of 21 per group (84 at four groups), i.e. five waves per SIMD without spills, and chunk iterations
-// that do not depend on each other (different pixels, nothing carried), so two of them interleave in one wave (GS_SCAN_UNROLL).
-__device__ __forceinline__ void block_pass_go(ScanLds& S, const int lane, const int rb, const int lb, const int npx_, const int ne, float c099)
-{
-    const int npx = rb + npx_;
-    const int slot_i = lane & 15, row = lane >> 4;
-    const int ng = (ne + 15) >> 4;
-    const int nchunk = ((GS_SCAN_SKIP & 4) && c099 > 0.f) ? 0 : (npx_ + 3) >> 2;
-#pragma unroll 1
-    for (int g = 0; g < ng; g++) {
-        ScanEntry E = {0.f, 0.f, 0.f, 0.f, 0.f, -__builtin_inff(), 0.f, 0.f, 0.f};   // an empty slot: alpha = exp2(-inf) = 0 whatever the masks say
-        uint32_t ent = 0u, kbit = 0u, klo = 0u;
-        const int k = 16 * g + slot_i;
-        if (k < ne) {
-            const uint32_t e = S.list[lb + k];
-            const float4 e0 = S.ent[SC_ENT_F4 * e], e1 = S.ent[SC_ENT_F4 * e + 1], e2 = S.ent[SC_ENT_F4 * e + 2];
-            E = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x};
-            ent = e; kbit = e & 31u; klo = e < 32u ? 0xffffffffu : 0u;
-        }
-        v2f_s acc_S = {0.f, 0.f}, acc_cxy = {0.f, 0.f}, acc_rg = {0.f, 0.f};
-        float acc_cw = 0.f, acc_op = 0.f, acc_b = 0.f;
-        const bool more = g + 1 < ng;   // (wave-uniform)
-        int off = rb + row;
-#pragma unroll GS_SCAN_UNROLL
-        for (int c = 0; c < nchunk; c++, off += 4) {
-            const int idx = off < npx ? off : npx;
-            const float2 ta = S.ta[idx], rg = S.rg[idx], bx = S.bx[idx], pyv = S.py[idx];
-            const uint2 hm = S.hm[idx];
-            const float Tin = ta.x, Ain = ta.y;
-            const float pxf = bx.y, pyf = pyv.x;
-            const float dx = E.d0x - pxf, dy = E.d0y - pyf;
-            float p2 = __builtin_fmaf(__builtin_fmaf(E.hA, dx, E.nB * dy), dx, E.lop);
-            p2 = __builtin_fmaf(E.hC * dy, dy, p2);
-            const float araw = __builtin_amdgcn_exp2f(p2);
-            uint32_t sel_, m_;
-            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(sel_) : "v"(klo), "v"(hm.x), "v"(hm.y));
-            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m_) : "v"(sel_), "v"(kbit));
-            const float ah = __uint_as_float(__float_as_uint(araw) & m_);
-            float alpha;
-            asm("v_min_f32 %0, %1, %2" : "=v"(alpha) : "v"(ah), "v"(c099));
-            const float om = 1.0f - alpha;
-            const float rinv = __builtin_amdgcn_rcpf(om);
-            const float Tincl = Tin * row_scan_mul(om);
-            const float Ti = Tincl * rinv;
-            const float Ta = Ti * alpha;
-            float cgd = E.cr * rg.x;
-            cgd = __builtin_fmaf(E.cg, rg.y, cgd);
-            cgd = __builtin_fmaf(E.cb, bx.x, cgd);
-            const float Ap = Ain + row_scan_add(Ta * cgd);
-            const float dLda = __builtin_fmaf(rinv, Ap, Ti * cgd);
-            const float w = ah * dLda;
-            acc_rg = __builtin_elementwise_fma((v2f_s){Ta, Ta}, (v2f_s){rg.x, rg.y}, acc_rg);
-            acc_b = __builtin_fmaf(Ta, bx.x, acc_b);
-            const v2f_s d = {dx, dy};
-            const v2f_s wd = (v2f_s){w, w} * d;
-            acc_S += wd;
-            acc_cxy = __builtin_elementwise_fma((v2f_s){wd.x, wd.x}, d, acc_cxy);
-            acc_cw = __builtin_fmaf(wd.y, dy, acc_cw);
-            acc_op += w;
-            // the pixel's state behind this group's sixteenth entry: lane 15 of the row holds it — into the pixel's record for the next group
-            // (a row without a pixel works on the block's all-zero record, which stays as it is)
-            if (more && slot_i == 15 && off < npx) S.ta[idx] = make_float2(Tincl, Ap);
-        }
-        float v[9] = {acc_S.x, acc_S.y, acc_cxy.x, acc_cxy.y, acc_cw, acc_op, acc_rg.x, acc_rg.y, acc_b};
-#pragma unroll
-        for (int kk = 0; kk < 9; kk++) {
-            v[kk] += __shfl_xor(v[kk], 16, 64);
-            v[kk] += __shfl_xor(v[kk], 32, 64);
-        }
-        if (row == 0 && k < ne) {
-#pragma unroll
-            for (int kk = 0; kk < 9; kk++) S.acc[9 * ent + kk] += v[kk];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the states written above are read by the next group's chunk loop (same wave: in order)
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// Waves per SIMD the register allocation aims at.  block_pass<NG>: 4 (124 VGPRs, no spills; 5 = 96 VGPRs with 34 spilled was measured in round 4:
-// 0.449 -> 0.592 ms, profiles/r04w_bwd_scan_five_waves_ab.log).  block_pass_go: 5 without spills.
 #ifndef GS_SCAN_WAVES
-#define GS_SCAN_WAVES (GS_SCAN_GROUP_OUTER ? 5 : 4)
+#define GS_SCAN_WAVES 4   // waves per SIMD the register allocation aims at (124 VGPRs, no spills).  5 (96 VGPRs, 34 spilled, all but three reloads outside the
+                          // chunk loops) was measured: 0.449 -> 0.592 ms (profiles/r04w_bwd_scan_five_waves_ab.log)
 #endif
 __global__ __launch_bounds__(64, GS_SCAN_WAVES) void render_bwd_scan_kernel(RenderBwdArgs a)
 {
@@ -458,11 +362,7 @@ __global__ __launch_bounds__(64, GS_SCAN_WAVES) void render_bwd_scan_kernel(Rend
         for (int h = 0; h < 2; h++) {   // the half's entries in list order: lane j with bit j of its set is entry number popcount(set below j)
             const bool mine = lane < 32 ? ((S_lo[h] >> lane) & 1u) : ((S_hi[h] >> (lane - 32)) & 1u);
             const uint32_t k = __builtin_amdgcn_mbcnt_hi(S_hi[h], __builtin_amdgcn_mbcnt_lo(S_lo[h], 0u));
-#if GS_SCAN_GROUP_OUTER
-            if (mine) S.list[64 * h + k] = (uint8_t)lane;
-#else
             if (mine) S.list[64 * h + k] = (uint32_t)lane;
-#endif
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -470,16 +370,12 @@ __global__ __launch_bounds__(64, GS_SCAN_WAVES) void render_bwd_scan_kernel(Rend
             const int npx = __popc(h ? balh[1] : balh[0]);
             if (npx == 0 || ((GS_SCAN_SKIP & 1) && a.T > -1)) continue;
             const int ne = h ? __popc(S_lo[1]) + __popc(S_hi[1]) : __popc(S_lo[0]) + __popc(S_hi[0]);
-#if GS_SCAN_GROUP_OUTER
-            block_pass_go(S, lane, h * SC_HALF, 64 * h, npx, ne, c099);
-#else
             switch ((ne + 15) >> 4) {
             case 1: block_pass<1>(S, lane, h * SC_HALF, 64 * h, npx, ne, c099); break;
             case 2: block_pass<2>(S, lane, h * SC_HALF, 64 * h, npx, ne, c099); break;
             case 3: block_pass<3>(S, lane, h * SC_HALF, 64 * h, npx, ne, c099); break;
             default: block_pass<4>(S, lane, h * SC_HALF, 64 * h, npx, ne, c099); break;
             }
-#endif
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
