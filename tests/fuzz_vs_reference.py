@@ -2,6 +2,8 @@
 """Ad-hoc fuzz (not collected by pytest): random small scenes, HIP path vs the reference's own kernels, strict and fast arithmetic.
     python tests/fuzz_vs_reference.py [n_cases] [seed0] [only]
     python tests/fuzz_vs_reference.py --poses [n_cases] [seed0]     # round 5: every scene at a random SE(3) pose (some with a scale_modifier / extent scale)
+FUZZ_PATHS=rotate (round 6, default): the grouping of the instances and the row order are FORCED per case and verified (refcompare.assert_path), rotating
+through (atomic, Morton rows + tie_rank) / (radix, rows as generated) / (atomic, rows as generated) / (radix, Morton); FUZZ_PATHS=atomic-morton etc. pins one.
 Prints one line per case and a summary; exits non-zero when a strict run is not bit-identical (radii / tile counts / lists / image /
 final_T / n_contrib) or a gradient element is beyond 1e-4.  Test infrastructure (uses oracle/_ref); needs the MI355X."""
 import os
@@ -10,6 +12,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
 import numpy as np
+
+
+PATHS = {"atomic-morton": ("atomic", True), "radix-insertion": ("radix", False), "atomic-insertion": ("atomic", False), "radix-morton": ("radix", True)}
+
+
+def path_of(i):
+    sel = os.environ.get("FUZZ_PATHS", "rotate")
+    return list(PATHS.values())[i % 4] if sel == "rotate" else PATHS[sel]
 
 
 def main_poses(argv):
@@ -22,7 +32,10 @@ def main_poses(argv):
     bad = 0
     over_ill = 0
     for i, (kind, P, W, H, deg, seed, view, sigma_scale, scale_modifier) in enumerate(fuzz_cases(n, seed0)):
-        res = compare(kind, P, W, H, deg, seed, view=view, sigma_scale=sigma_scale, scale_modifier=scale_modifier)
+        binning, morton = path_of(i)
+        res = compare(kind, P, W, H, deg, seed, view=view, sigma_scale=sigma_scale, scale_modifier=scale_modifier, binning=binning, morton=morton)
+        from refcompare import assert_path
+        assert_path(res)
         st = res["strict"]
         exact = (st["radii_mismatch"] == 0 and st["tiles_touched_mismatch"] == 0 and st["point_list_equal"] and st["color"]["bit_equal"] and
                  st["final_T"]["bit_equal"] and st["n_contrib_mismatch"] == 0 and all(st[k + "_bit_equal"] for k in ("means2D", "depths", "conic_opacity", "rgb")))
@@ -30,7 +43,7 @@ def main_poses(argv):
         ill = sum(st[k].get("over_ill_conditioned", 0) for k in GRADS)
         ok = exact and over == ill
         over_ill += ill
-        print(f"{i:3d} {kind:6s} P={P:6d} {W}x{H} deg{deg} ypr={view['ypr']} place={view['place']} mod={scale_modifier} sigma={sigma_scale}: R={res['ref']['R']} "
+        print(f"{i:3d} {kind:6s} P={P:6d} {W}x{H} deg{deg} ypr={view['ypr']} place={view['place']} mod={scale_modifier} sigma={sigma_scale} [{binning}, {'Morton' if morton else 'insertion'} rows -> ran {st['binning_path']}]: R={res['ref']['R']} "
               f"clamp-masked={res['ref']['clamp_masked_visible']} strict {'OK' if ok else 'MISMATCH'} (max grad err {max(st[k]['max_rel'] for k in GRADS):.1e}"
               + (f"; {over} element(s) over 1e-4, {ill} of them ill-conditioned in fp32" if over else "") + ")", flush=True)
         bad += 0 if ok else 1
@@ -57,7 +70,10 @@ def main():
         seed = int(rng.integers(0, 10 ** 6))
         if only >= 0 and i != only:
             continue
-        res = compare(kind, P, W, H, deg, seed)
+        binning, morton = path_of(i)
+        res = compare(kind, P, W, H, deg, seed, binning=binning, morton=morton)
+        from refcompare import assert_path
+        assert_path(res)
         st, fa = res["strict"], res["fast"]
         ok = (st["radii_mismatch"] == 0 and st["tiles_touched_mismatch"] == 0 and st["point_list_equal"] and st["color"]["bit_equal"]
               and st["final_T"]["bit_equal"] and st["n_contrib_mismatch"] == 0 and all(st[k]["over"] == 0 for k in GRADS))
@@ -69,7 +85,7 @@ def main():
             why = " [" + ", ".join(f"{k}={st[k] if not isinstance(st[k], dict) else st[k]['over']}" for k in
                                    ("radii_mismatch", "tiles_touched_mismatch", "point_list_equal", "n_contrib_mismatch") + ("color", "final_T")) + \
                   f", color_bits={st['color']['bit_equal']}, T_bits={st['final_T']['bit_equal']}]"
-        print(f"{i:3d} {kind:6s} P={P:6d} {W}x{H} deg{deg} seed={seed}: R={res['ref']['R']} strict {'OK' if ok else 'MISMATCH' + why} "
+        print(f"{i:3d} {kind:6s} P={P:6d} {W}x{H} deg{deg} seed={seed} [{binning}, {'Morton' if morton else 'insertion'} rows -> ran {st['binning_path']}]: R={res['ref']['R']} strict {'OK' if ok else 'MISMATCH' + why} "
               f"(max grad err {max(st[k]['max_rel'] for k in GRADS):.1e}); fast: {fast_over} elements over 1e-4, max {fmax:.1e}", flush=True)
         bad += 0 if ok else 1
     print(f"{n} cases, {bad} strict mismatches, worst fast-mode error {worst_fast:.2e}")
