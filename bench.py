@@ -325,7 +325,9 @@ def main():
     # the slow step; no stall with gc.freeze() or with the collector off; 400 extra collectives beforehand do not move it).  gc.freeze() moves
     # everything allocated so far into the permanent generation: later passes only look at what the loop itself creates.  No priming steps.
     _freeze_gc()
-    prime_steps = int(os.environ.get("GSLIC_DIST_PRIME_STEPS", "0"))
+    # (N > 1 keeps ten untimed steps in front of the W warm-up steps as insurance for what a first collective of each size sets up on real links —
+    # connections, channel buffers — which no box this repository ran on could show; the garbage collector needs none)
+    prime_steps = int(os.environ.get("GSLIC_DIST_PRIME_STEPS", "10" if world > 1 else "0"))
     if prime_steps and trainer._dist_on() and args.mode == "train" and args.host == "fused":
         for _ in range(prime_steps):
             step()
