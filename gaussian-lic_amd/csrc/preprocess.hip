@@ -63,8 +63,14 @@ __device__ __forceinline__ void sh_to_rgb(const PreprocessArgs& a, const int idx
 }
 
 // LDS_SH (M == 15, colour mode, one wave per workgroup): the block's SH rows reach their threads through LDS (see "SH -> RGB" below).
+// 97 VGPRs kept the kernel at four waves per SIMD; capped at 96 (two spilled) it runs five: 0.1330 -> 0.1304 ms (profiles/r06n_occupancy_others_ab.log;
+// six waves / 80 VGPRs: 0.138).  -DGS_PRE_WPE=n for A/B runs.
+#ifndef GS_PRE_WPE
+#define GS_PRE_WPE 5
+#endif
+#define GS_PRE_WPE_ATTR __attribute__((amdgpu_waves_per_eu(GS_PRE_WPE, GS_PRE_WPE)))
 template <bool LDS_SH, int BS>
-__global__ __launch_bounds__(BS) void preprocess_kernel(PreprocessArgs a)
+__global__ __launch_bounds__(BS) GS_PRE_WPE_ATTR void preprocess_kernel(PreprocessArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds_sh[LDS_SH ? (BS / 2) * 45 : 4];
     __shared__ uint8_t lds_v[LDS_SH ? BS : 4];

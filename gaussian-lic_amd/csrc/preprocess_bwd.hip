@@ -225,8 +225,16 @@ __device__ __forceinline__ void sh_columns_pass(const PreprocessBwdArgs& a, cons
     }
 }
 
+// Waves per SIMD the register allocation aims at.  The kernel streams ~100 bytes per flop and its phases (gather, table, column pass, small
+// groups) run one after the other inside a wave: the waves in flight ARE its memory-level parallelism.  At 131 VGPRs it ran three waves per
+// SIMD; capped at 128 (two spilled outside the column pass) it runs four — 0.50 -> 0.444 ms at 2M / 1080p, same box
+// (profiles/r06n_pbwd_occupancy_ab.log); five (96 VGPRs, 44 spilled) gives the gain back.  -DGS_PBWD_WPE=n for A/B runs.
+#ifndef GS_PBWD_WPE
+#define GS_PBWD_WPE 4
+#endif
+#define GS_PBWD_OCC __attribute__((amdgpu_waves_per_eu(GS_PBWD_WPE, GS_PBWD_WPE)))
 template <bool LDS_SH, int BS, bool CAM>
-__global__ __launch_bounds__(BS) void preprocess_bwd_kernel(PreprocessBwdArgs a)
+__global__ __launch_bounds__(BS) GS_PBWD_OCC void preprocess_bwd_kernel(PreprocessBwdArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds_tab[LDS_SH ? BS * SHT : 4];   // {c_0..c_14, dRGB} per Gaussian; later the 14 small gradients
     __shared__ float lds_sk[LDS_SH ? BS * 15 : 4];                                    // q_k per Gaussian

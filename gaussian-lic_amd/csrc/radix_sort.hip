@@ -147,6 +147,7 @@ struct SortPassArgs {
     uint32_t* timeout;           // onesweep: device status word (bit 0 set when a look-back wait gave up)
 };
 
+// (148 VGPRs = three waves per SIMD for the three-payload variant; capped at 128 it spills 40 and runs as fast: 0.0595 / 0.0597 ms, profiles/r06o_scatter_occupancy_ab.log)
 template <int NV, bool ONESWEEP>
 __global__ __launch_bounds__(RS_THREADS) void sort_scatter_kernel(const SortPassArgs a)
 {
@@ -498,11 +499,23 @@ static constexpr int LW_PHYS = 64 * 17;
 // the key build and the scans (the bare barrier intrinsic is not a memory fence for IR-level passes: ADVICE round 5); no instruction either way.
 #define GS_WAVE_ORDER() GS_WAVE_SYNC()
 
+// GS_LSORT_SINGLE: ONE pair buffer instead of two.  A pass holds every lane's whole run in registers before the first element is written back (the
+// reads, the counting, the scan and the ranking all come first, and a wave's LDS instructions execute in program order), so the scatter may
+// overwrite the buffer it was read from: 10.9 KB of LDS per wave instead of 17.4 — fourteen waves per CU instead of nine for a kernel that is
+// bound by the latency of a pass's dependent chain — twelve in fact, at the 168 VGPRs of three waves per SIMD: 0.1011 -> 0.097 ms (four waves: 47 spilled,
+// 0.115; profiles/r06n_lsort_single_ab.log).
+#ifndef GS_LSORT_SINGLE
+#define GS_LSORT_SINGLE 1
+#endif
+#ifndef GS_LSORT_WPE
+#define GS_LSORT_WPE 3
+#endif
+static constexpr int LW_NB = GS_LSORT_SINGLE ? 1 : 2;
 template <bool BINNED>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void tile_depth_sort_wave_kernel(const TileDepthSortArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GS_LSORT_WPE, GS_LSORT_WPE))) void tile_depth_sort_wave_kernel(const TileDepthSortArgs a)
 {
-    __shared__ uint32_t sk[2][LW_PHYS];
-    __shared__ uint16_t si[2][LW_PHYS];
+    __shared__ uint32_t sk[LW_NB][LW_PHYS];
+    __shared__ uint16_t si[LW_NB][LW_PHYS];
     __shared__ uint32_t C[16 * 64 + 64];   // counter (digit d, lane l) = word 64 d + l of the matrix, stored at f + (f >> 4): see the scan
     if (a.status[2] != 0u) return;   // capacity mode: the instance lists did not fit
     const uint2 range = a.ranges[blockIdx.x];
@@ -624,12 +637,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             for (int j = 0; j < 16; j++) {
                 if ((uint32_t)j < E && (uint32_t)j < mine) {
                     const uint32_t ph = phys(pos[j]);
-                    sk[cur ^ 1][ph] = k[j];
-                    si[cur ^ 1][ph] = (uint16_t)ix[j];
+                    sk[(cur ^ 1) & (LW_NB - 1)][ph] = k[j];
+                    si[(cur ^ 1) & (LW_NB - 1)][ph] = (uint16_t)ix[j];
                 }
             }
             GS_WAVE_ORDER();
-            cur ^= 1;
+            cur = (cur ^ 1) & (LW_NB - 1);
         }
         GS_WAVE_SYNC();
         if (phase == 0) {

@@ -64,8 +64,11 @@ __device__ __forceinline__ float strip_max_p2(float hA, float hC, float nB, floa
 #ifndef GS_FWD_SKIP
 #define GS_FWD_SKIP 0
 #endif
+#ifndef GS_FWD_WAVES
+#define GS_FWD_WAVES 7   // (8: 64 VGPRs, 12 spilled — 0.349 ms either way, profiles/r06n_occupancy_others_ab.log)
+#endif
 template <bool STRICT, int SPLIT>
-__global__ __launch_bounds__(64, SPLIT >= 2 ? 7 : 5) void render_fwd_kernel(RenderFwdArgs a)
+__global__ __launch_bounds__(64, SPLIT >= 2 ? GS_FWD_WAVES : 5) void render_fwd_kernel(RenderFwdArgs a)
 {
     constexpr int QN = 4 / SPLIT;          // quadrants (= pixels per lane) of this wave
     __shared__ float4 s_rec[3 * GS_BUCKET];

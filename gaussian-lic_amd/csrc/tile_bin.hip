@@ -95,6 +95,7 @@ __global__ __launch_bounds__(TS_THREADS) void tile_scan_kernel(const TileBinArgs
     }
 }
 
+// (134 VGPRs = three waves per SIMD; capped at 128 for four the kernel spills 24 and slows down: 0.056 -> 0.069 ms, profiles/r06n_occupancy_others_ab.log)
 template <int TB_THREADS>
 __global__ __launch_bounds__(TB_THREADS) void tile_bin_kernel(const TileBinArgs a)
 {
