@@ -137,6 +137,9 @@ __device__ __forceinline__ void small_groups_sink(const AdamFusedArgs& A, float*
 // What the pass needs per Gaussian — c_0..c_14 and the clamp-masked dRGB — sits in a 64 x 19 float table.  LDS per wave 8.6 KB (table 4.75,
 // q 3.75) against the 11.3 KB of staging whole rows in and gradient rows out: 16 waves per CU instead of 13 (the kernel streams ~100 bytes
 // per flop: occupancy IS its memory-level parallelism, profiles/r03p_pbwd_occupancy.log), and features_rest is fetched once, not twice.
+#ifndef GS_PBWD_U
+#define GS_PBWD_U 4   // float4 columns of features_rest a thread has in flight in the column pass (3 / 6 measured: profiles/r06p_pbwd_unroll_ab.log)
+#endif
 #ifndef GS_SHT
 #define GS_SHT 19
 #endif
@@ -151,7 +154,7 @@ __device__ __forceinline__ void sh_columns_pass(const PreprocessBwdArgs& a, cons
 {
 #pragma clang fp contract(off)   // q_k = (p0 + p1) + p2 of separately rounded products, here AND in the row-by-row path of a partial last block: a
                                  // Gaussian's direction gradient must not depend on which block of the map its row happens to sit in
-    constexpr int NE = BS * 45, NV = NE / 4, U = 4;
+    constexpr int NE = BS * 45, NV = NE / 4, U = GS_PBWD_U;
     const AdamFusedArgs& A = a.adam;
     const size_t base = (size_t)row0 * 45;
     const float* __restrict__ P = a.shs + base;   // (== A.p[2] + base when the update is on: api.hip checks the aliasing)
