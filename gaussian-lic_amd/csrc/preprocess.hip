@@ -63,10 +63,15 @@ __device__ __forceinline__ void sh_to_rgb(const PreprocessArgs& a, const int idx
 }
 
 // LDS_SH (M == 15, colour mode, one wave per workgroup): the block's SH rows reach their threads through LDS (see "SH -> RGB" below).
-// 97 VGPRs kept the kernel at four waves per SIMD; capped at 96 (two spilled) it runs five: 0.1330 -> 0.1304 ms (profiles/r06n_occupancy_others_ab.log;
-// six waves / 80 VGPRs: 0.138).  -DGS_PRE_WPE=n for A/B runs.
+// Latency-bound, and purely so: with LDS padding taking it from twenty waves per CU to fifteen it runs 22 % longer (profiles/r06s_small_kernels_occupancy_sensitivity.log).
+// 97 VGPRs kept it at four waves per SIMD; capped at 96 it ran five (0.1330 -> 0.1304 ms); with the SH staging's float4 columns fetched three at a time
+// instead of six (GS_PRE_NTB: 24 registers held across the staging -> 12) it fits 80 with two spilled and runs SIX: 0.1344 -> 0.1274 ms, same box
+// (profiles/r06s_preprocess_staging_batches_ab.log; seven waves / 72 VGPRs / two columns at a time: 0.136).  -DGS_PRE_WPE=n -DGS_PRE_NTB=n for A/B runs.
+#ifndef GS_PRE_NTB
+#define GS_PRE_NTB 3
+#endif
 #ifndef GS_PRE_WPE
-#define GS_PRE_WPE 5
+#define GS_PRE_WPE 6
 #endif
 #define GS_PRE_WPE_ATTR __attribute__((amdgpu_waves_per_eu(GS_PRE_WPE, GS_PRE_WPE)))
 template <bool LDS_SH, int BS>
@@ -235,22 +240,27 @@ __global__ __launch_bounds__(BS) GS_PRE_WPE_ATTR void preprocess_kernel(Preproce
             if (hrows == HR) {
                 const v4f* s4 = reinterpret_cast<const v4f*>(src);
                 v4f* d4 = reinterpret_cast<v4f*>(lds_sh);
-                v4f pre[NT];
-                bool ld[NT];
+                // (GS_PRE_NTB float4 columns of a thread in flight at a time: all NT = 6 at once held 24 registers across the staging)
+                constexpr int NTB = GS_PRE_NTB < NT ? GS_PRE_NTB : NT;
 #pragma unroll
-                for (int k = 0; k < NT; k++) {
-                    const int i = threadIdx.x + k * BS;
-                    ld[k] = false;
-                    if (i < NV) {
-                        const int e = 4 * i;
-                        ld[k] = (lds_v[h * HR + e / 45] | lds_v[h * HR + (e + 3) / 45]) != 0;
-                        if (ld[k]) pre[k] = __builtin_nontemporal_load(s4 + i);   // 360 MB read once per forward: past the L2's retention
+                for (int k0 = 0; k0 < NT; k0 += NTB) {
+                    v4f pre[NTB];
+                    bool ld[NTB];
+#pragma unroll
+                    for (int kk = 0; kk < NTB; kk++) {
+                        const int i = threadIdx.x + (k0 + kk) * BS;
+                        ld[kk] = false;
+                        if (k0 + kk < NT && i < NV) {
+                            const int e = 4 * i;
+                            ld[kk] = (lds_v[h * HR + e / 45] | lds_v[h * HR + (e + 3) / 45]) != 0;
+                            if (ld[kk]) pre[kk] = __builtin_nontemporal_load(s4 + i);   // 360 MB read once per forward: past the L2's retention
+                        }
                     }
-                }
 #pragma unroll
-                for (int k = 0; k < NT; k++) {
-                    const int i = threadIdx.x + k * BS;
-                    if (ld[k]) d4[i] = pre[k];
+                    for (int kk = 0; kk < NTB; kk++) {
+                        const int i = threadIdx.x + (k0 + kk) * BS;
+                        if (ld[kk]) d4[i] = pre[kk];
+                    }
                 }
             } else {
                 for (int i = threadIdx.x; i < hrows * 45; i += BS) lds_sh[i] = src[i];

@@ -14,7 +14,7 @@ for r in $(seq $N); do
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); k = d['kernel_ms_per_launch_timed'] or {}; print('$label', d['value'], 'views/s', d['ms_per_step'], 'ms', {n: k[n] for n in ('render_bwd', 'preprocess_bwd', 'render_fwd', 'preprocess', 'keybuild', 'sort_scatter', 'tile_hist', 'tile_scan', 'tile_bin', 'tile_lsort', 'tile_lsort_long') if n in k})
+        d = json.loads(l); k = d['kernel_ms_per_launch_timed'] or {}; print('$label', d['value'], 'views/s', d['ms_per_step'], 'ms', {n: k[n] for n in ('render_bwd', 'preprocess_bwd', 'render_fwd', 'preprocess', 'keybuild', 'sort_scatter', 'tile_hist', 'tile_scan', 'tile_bin', 'tile_lsort', 'tile_lsort_long', 'ssim_fwd', 'ssim_bwd') if n in k})
 "
   done
 done
