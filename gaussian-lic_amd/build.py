@@ -34,7 +34,7 @@ SOURCES = {
 }
 COMMON = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wno-inline-asm",
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]
-HEADERS = ["gslic_common.h", "kernels.h", os.path.join("..", "..", "include", "gslic_hip.h")]
+HEADERS = ["gslic_common.h", "kernels.h", "render_fwd_body.inc", os.path.join("..", "..", "include", "gslic_hip.h")]
 
 
 def _newer(a, b):

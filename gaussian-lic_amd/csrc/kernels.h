@@ -52,6 +52,7 @@ struct RenderFwdArgs {
     float* out_final_T;
     uint32_t capB;             // checkpoint buckets available in bucket_to_tile / ckpt
     uint32_t* status;          // device status words: [2] |= 2 when the buckets did not fit; a non-zero [2] on entry aborts the kernel
+    int tail4_from;            // set by launch_render_fwd: tiles from this index on are blended by FOUR waves (one quadrant each); >= gx * gy: none
 };
 int launch_render_fwd(const RenderFwdArgs& a, hipStream_t s);
 

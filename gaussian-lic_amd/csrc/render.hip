@@ -64,13 +64,15 @@ __device__ __forceinline__ float strip_max_p2(float hA, float hC, float nB, floa
 #ifndef GS_FWD_SKIP
 #define GS_FWD_SKIP 0
 #endif
+#ifndef GS_FWD_TAIL4_DEFAULT
+#define GS_FWD_TAIL4_DEFAULT 0.10f   // measured at 2M / 1080p: 0 -> 0.3496 ms, 0.05 -> 0.339, 0.08 -> 0.332, 0.10 -> 0.330, 0.125 -> 0.330-0.333, 0.15 -> 0.333, 0.25 -> 0.347, 1.0 -> 0.392 (profiles/r06u_fwd_tail4_*.log)
+#endif
 #ifndef GS_FWD_WAVES
 #define GS_FWD_WAVES 7   // (8: 64 VGPRs, 12 spilled — 0.349 ms either way, profiles/r06n_occupancy_others_ab.log)
 #endif
 template <bool STRICT, int SPLIT>
 __global__ __launch_bounds__(64, SPLIT >= 2 ? GS_FWD_WAVES : 5) void render_fwd_kernel(RenderFwdArgs a)
 {
-    constexpr int QN = 4 / SPLIT;          // quadrants (= pixels per lane) of this wave
     __shared__ float4 s_rec[3 * GS_BUCKET];
     // 1-D grid in groups of 8 * SPLIT workgroups: workgroup b of a group works on tile 8 * group + b % 8, quadrants (b / 8) * QN...:
     // consecutive workgroups go to consecutive XCDs (eight L2s), so the SPLIT waves of one tile land on the SAME XCD, a few dispatches
@@ -78,247 +80,41 @@ __global__ __launch_bounds__(64, SPLIT >= 2 ? GS_FWD_WAVES : 5) void render_fwd_
     const uint32_t grp = blockIdx.x / (8u * SPLIT), rem = blockIdx.x % (8u * SPLIT);
     const int tile = (int)(grp * 8u + (rem & 7u));
     if (tile >= a.gx * a.gy) return;
-    const int q0 = (int)(rem >> 3) * QN;   // first quadrant of this wave
-    const int lane = threadIdx.x;
-    const int tx0 = (tile % a.gx) * GS_TILE, ty0 = (tile / a.gx) * GS_TILE;
-    if (a.status[2] != 0u) return;  // capacity mode: the instance lists did not fit; the host re-runs the step with larger buffers
-    if (STRICT && !a.no_color && blockIdx.x == 0 && lane == 0) a.status[GS_FLAG_HITBITS] = 1u;   // this forward records SampleState::hit
-    const uint2 range = a.ranges[tile];
-    const int n = (int)(range.y - range.x);
-    const bool color = !a.no_color;
+    const int q0 = (int)(rem >> 3) * (4 / SPLIT);   // first quadrant of this wave
+#define GS_BODY_SPLIT SPLIT
+#include "render_fwd_body.inc"
+#undef GS_BODY_SPLIT
+}
 
-    uint32_t bbm = 0;
-    bool fits = true;  // capacity mode: this tile's checkpoints have room in the sample buffer
-    if (color) {
-        bbm = (tile == 0) ? 0u : a.bucket_offsets[tile - 1];
-        const int nb = (n + GS_BUCKET - 1) / GS_BUCKET;
-        fits = bbm + (uint32_t)nb <= a.capB;
-        if (!fits && lane == 0) atomicOr(a.status + 2, 2u);
-        if (fits && q0 == 0)
-            for (int b = lane; b < nb; b += 64) a.bucket_to_tile[bbm + b] = (uint32_t)tile;
-    }
-
-    // this lane's pixel in quadrant Q = q0 + q of the tile: (8 (Q & 1) + (lane & 7), 8 (Q >> 1) + (lane >> 3)) — tile_pix_x / tile_pix_y of
-    // element Q * 64 + lane of the tile-major per-pixel arrays (gslic_common.h).  With two waves per tile a wave's two quadrants share
-    // their rows: the y terms of the exponent are formed once per entry.
-    constexpr int MY = QN == 4 ? 2 : 1;    // distinct pixel rows per lane
-    int pxi[QN], pyi[QN];
-#pragma unroll
-    for (int q = 0; q < QN; q++) { pxi[q] = tx0 + tile_pix_x((q0 + q) * 64 + lane); pyi[q] = ty0 + tile_pix_y((q0 + q) * 64 + lane); }
-    // The sign of T carries the `done` flag (forward.cu:352,439-443): T > 0 = still blending, T < 0 = finished with
-    // transmittance |T| (T never reaches 0: blending stops below 1e-4).  One register and no flag bookkeeping per pixel.
-    float T[QN], Cr[QN], Cg[QN], Cb[QN];
-    uint32_t last[QN];
-#pragma unroll
-    for (int q = 0; q < QN; q++) {
-        T[q] = (pxi[q] < a.W && pyi[q] < a.H) ? 1.0f : -1.0f;
-        Cr[q] = Cg[q] = Cb[q] = 0.0f;
-        last[q] = 0;
-    }
-    const float LOG2E = 1.4426950408889634f;
-    // loop constants in VGPRs (a literal or SGPR operand doubles the issue cost of the instruction that reads it: tools/ubench/issue_rate)
-    float c099 = 0.99f, c255 = 1.0f / 255.0f, c1e4 = 0.0001f, ninf = -__builtin_inff();
-    asm volatile("" : "+v"(c099), "+v"(c255), "+v"(c1e4), "+v"(ninf));
-    // pixel coordinates as floats: tile-relative (default arithmetic) or absolute (STRICT), per quadrant column / per row
-    float fxq[QN], fym[MY];
-#pragma unroll
-    for (int q = 0; q < QN; q++) { fxq[q] = (float)(STRICT ? pxi[q] : pxi[q] - tx0); asm volatile("" : "+v"(fxq[q])); }
-#pragma unroll
-    for (int m = 0; m < MY; m++) { fym[m] = (float)(STRICT ? pyi[QN == 4 ? 2 * m : 0] : pyi[QN == 4 ? 2 * m : 0] - ty0); asm volatile("" : "+v"(fym[m])); }
-    // STRICT: the constants of expf_core; default: the exponent below which no pixel reaches alpha >= 1/255 (with a margin: the early-out only)
-    float kL2E = GS_EXP_L2E, kCC = GS_EXP_CC, kmh = -0.5f, kzero = 0.0f, vonef = 1.0f, kp2min = -7.9943534f - 0.001f /* log2(1/255) */;
-    uint32_t ksign = 0x80000000u;
-    if constexpr (STRICT) asm volatile("" : "+v"(kL2E), "+v"(kCC), "+v"(kmh), "+v"(kzero), "+v"(vonef), "+v"(ksign));
-    else asm volatile("" : "+v"(kp2min), "+v"(kzero));
-
-    for (int base = 0; base < n; base += GS_BUCKET) {
-        bool alldone = true;
-#pragma unroll
-        for (int q = 0; q < QN; q++) alldone = alldone && (T[q] < 0.f);
-        if (__all(alldone)) break;
-        if (color && fits && !((GS_FWD_SKIP & 2) && a.gx > -1)) {
-            float4* ck = a.ckpt + ((size_t)(bbm + (uint32_t)(base / GS_BUCKET)) * GS_TILE_PIX) + lane;
-#pragma unroll
-            for (int q = 0; q < QN; q++)
-                if (T[q] > 0.f) ck[(q0 + q) * 64] = make_float4(T[q], Cr[q], Cg[q], Cb[q]);
-        }
-        const int m = (n - base) < GS_BUCKET ? (n - base) : GS_BUCKET;
-        // each lane fetches one record and pre-scales its conic: exponent in base 2, relative to this lane-independent tile origin
-        float fdx = 0, fdy = 0, fhA = 0, fhC = 0, fnB = 0, fop = 0, flop = -__builtin_inff(), fr = 0, fg = 0, fb = 0;
-        uint32_t fmask = 0;
-        float fthr = 0.f;
-        if (lane < m && !((GS_FWD_SKIP & 8) && a.gx > -1)) {
-            const uint32_t g = a.point_list[range.x + (uint32_t)(base + lane)];
-            const float4* rp = a.rec + GS_REC_F4 * (size_t)g;
-            const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-            fdx = r0.x - (float)tx0; fdy = r0.y - (float)ty0;
-            fhA = -0.5f * LOG2E * r0.z; fnB = -LOG2E * r0.w; fhC = -0.5f * LOG2E * r1.x;
-            fop = r1.y; fr = r1.z; fg = r1.w; fb = r2.x;
-            flop = __builtin_amdgcn_logf(fop);  // log2(opacity): alpha = exp2(p2 + log2 opacity), one multiply less per (pixel, entry)
-            // which of this wave's 8x8 quadrants (= the QN pixels of every lane) can this entry reach at all (bit q = quadrant q0 + q)
-#pragma unroll
-            for (int q = 0; q < QN; q++) {
-                const float x0 = (float)(8 * ((q0 + q) & 1)), y0 = (float)(8 * ((q0 + q) >> 1));
-                const float pm = strip_max_p2(fhA, fhC, fnB, fdx, fdy, x0, x0 + 7.0f, y0, y0 + 7.0f);
-                if (!(fop * __builtin_amdgcn_exp2f(pm) < 0.999f * (1.0f / 255.0f))) fmask |= 1u << q;
-            }
-            // STRICT: the power below which alpha = opacity exp(power) < 1/255 for certain (log evaluated to ~1e-6, margin 1e-3): the
-            // early-out of blend_entry compares against it, it decides nothing else
-            fthr = -0.6931472f * (flop + 7.9943534f) - 0.001f;
-        }
-        if constexpr (STRICT) {  // raw record: absolute mean, unscaled conic
-            if (lane < m && !((GS_FWD_SKIP & 8) && a.gx > -1)) {
-                const uint32_t g = a.point_list[range.x + (uint32_t)(base + lane)];
-                const float4* rp = a.rec + GS_REC_F4 * (size_t)g;
-                const float4 r0 = rp[0], r1 = rp[1];
-                fdx = r0.x; fdy = r0.y; fhA = r0.z; fnB = r0.w; fhC = r1.x;
-            }
-        }
-        // the batch's 64 pre-scaled records are parked in LDS and entry j is fetched with three ds_read_b128 at a wave-uniform
-        // address (LDS broadcast; the next entry is in flight while this one is blended): ten v_readlane per entry cost VALU
-        // issue slots, which is what bounds this kernel — LDS reads do not
-        s_rec[3 * lane] = make_float4(fdx, fdy, fhA, fnB);
-        s_rec[3 * lane + 1] = make_float4(fhC, STRICT ? fop : flop, fr, fg);
-        s_rec[3 * lane + 2] = make_float4(fb, __uint_as_float(fmask), fthr, 0.f);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // one list entry against this lane's four pixels.  STRICT: the reference's arithmetic with its branches.  Default: straight-line
-        // code — a pixel the entry does not blend into (finished, power > 0, alpha < 1/255) runs the same instructions with weight 0,
-        // which leaves its colour, transmittance and last contributor unchanged bit for bit; only the per-quadrant skip and the early-out (wave-uniform) branch
-        uint32_t vcontrib = (uint32_t)base, vone = 1u;
-        asm volatile("" : "+v"(vcontrib), "+v"(vone));
-        // STRICT: every pixel collects WHICH entries of this batch it blended (bit j = entry j; one dword at a time: hcur rolls over into
-        // hfirst at entry 32).  The strict backward takes its blend / skip decisions from these bits instead of re-deriving them: they ARE the
-        // reference's decisions.
-        uint32_t hcur[QN], hfirst[QN], vbit = 0u;
-#pragma unroll
-        for (int q = 0; q < QN; q++) hcur[q] = hfirst[q] = 0u;
-        auto blend_entry = [&](const float4 e0, const float4 e1, const float4 e2, const uint32_t contributor) {
-            vcontrib += vone;  // == contributor, kept in a VGPR (an SGPR operand doubles the issue cost of the select that reads it)
-            if constexpr (STRICT) vbit = 1u << ((contributor - 1u) & 31u);   // (wave-uniform; one v_mov per entry)
-            const uint32_t smask = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(e2.y));  // this wave's quadrants
-            if (smask == 0u) return;
-            const float gdx = e0.x, gdy = e0.y, hA = e0.z, nB = e0.w, hC = e1.x, op = e1.y, colr = e1.z, colg = e1.w, colb = e2.x;
-            if constexpr (STRICT) {
-#pragma clang fp contract(off)
-                // forward.cu:424-445 operation for operation: d from absolute coordinates, the three products of the power rounded one by
-                // one, hipcc's expf (expf_core), opacity * exp, (colour * alpha) * T added to C; the entry is applied under an exec mask
-                // (measured against select-masked straight-line code: 0.39 vs 0.40 ms).  (-0.5f * s - c as one fma: halving is exact.)
-                const float thr = e2.z;
-                float dys[MY], cy[MY];
-#pragma unroll
-                for (int m = 0; m < MY; m++) { dys[m] = gdy - fym[m]; cy[m] = (hC * dys[m]) * dys[m]; }   // d.y; con_o.z * d.y * d.y
-#pragma unroll
-                for (int q = 0; q < QN; q++) {
-                    if (!(smask & (1u << q))) continue;  // wave-uniform; conservative (no pixel of the quadrant reaches alpha >= 1/255)
-                    const int m = QN == 4 ? q >> 1 : 0;
-                    const float dxs = gdx - fxq[q];                       // float2 d = { xy.x - pixf.x, xy.y - pixf.y } (forward.cu:424)
-                    const float s2 = (hA * dxs) * dxs + cy[m];            // con_o.x * d.x * d.x + con_o.z * d.y * d.y
-                    const float power = __builtin_fmaf(kmh, s2, -((nB * dxs) * dys[m]));
-                    // early-out: no live pixel of the quadrant can reach alpha >= 1/255 (21 % of the reachable (entry, quadrant) pairs of the
-                    // 2M / 1080p scene: mostly quadrants whose pixels are all finished) — everything below would change nothing
-                    if (!__builtin_amdgcn_ballot_w64((power >= thr) & (T[q] > kzero))) continue;
-                    const float alpha = __builtin_amdgcn_fmed3f(op * expf_core(power, kL2E, kCC), ninf, c099);   // min(0.99f, con_o.w * exp(power))
-                    const float test_T = T[q] * (vonef - alpha);
-                    // A finished pixel (T < 0) needs no test of its own: T (1 - alpha) is negative, hence "< 1e-4", and -|T| leaves it as it is
-                    const bool cand = !(power > kzero) & !(alpha < c255);   // forward.cu:431,437
-                    const bool stop = test_T < c1e4;                        // done; this entry is NOT applied (forward.cu:438-443)
-                    if (cand) {   // exec-masked: skipped when no pixel of the quadrant blends this entry
-                        // (T and last are updated IN PLACE under the branch's exec mask: left to the compiler, the two-sided update costs five copies)
-                        if (stop) {
-                            asm("v_or_b32 %0, %0, %1" : "+v"(T[q]) : "v"(ksign));   // -|T|
-                        } else {
-                            Cr[q] = Cr[q] + (colr * alpha) * T[q]; Cg[q] = Cg[q] + (colg * alpha) * T[q]; Cb[q] = Cb[q] + (colb * alpha) * T[q];
-                            asm("v_mov_b32 %0, %1" : "+v"(T[q]) : "v"(test_T));
-                            asm("v_mov_b32 %0, %1" : "+v"(last[q]) : "v"(vcontrib));
-                            hcur[q] |= vbit;   // this pixel blended this entry
-                        }
-                    }
-                }
-            } else {
-                // e1.y holds log2(opacity) here.  The operation sequence below is repeated verbatim by the backward (GS_BW_BODY), so both
-                // sides compute bit-identical alphas and take the same alpha < 1/255 decisions for every (pixel, entry) pair
-                const float lop = op;
-                float dy[MY], tC[MY];
-#pragma unroll
-                for (int m = 0; m < MY; m++) { dy[m] = gdy - fym[m]; tC[m] = hC * dy[m]; }   // one rounding, as d0.y - py in the backward
-#pragma unroll
-                for (int q = 0; q < QN; q++) {
-                    if (!(smask & (1u << q))) continue;  // wave-uniform
-                    const int m = QN == 4 ? q >> 1 : 0;
-                    const float dx = gdx - fxq[q];
-                    float p2 = __builtin_fmaf(hA * dx, dx, lop);      // log2(e) * (-1/2 A dx^2) + log2(opacity)
-                    p2 = __builtin_fmaf(tC[m], dy[m], p2);
-                    p2 = __builtin_fmaf(nB * dx, dy[m], p2);          // log2(e) * power + log2(opacity)
-                    if (!__builtin_amdgcn_ballot_w64((p2 >= kp2min) & (T[q] > kzero))) continue;   // early-out, as above
-                    const float alpha = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(p2), ninf, c099);  // min(0.99, .) in one instruction, as GS_BW_BODY
-                    const float test_T = T[q] * (1.0f - alpha);  // negative (so < 1e-4) once the pixel is done
-                    const bool ok = !(p2 > lop) & !(alpha < c255);                  // forward.cu:431,437
-                    const bool stop = ok & (test_T < c1e4);                         // done; this entry is NOT applied (forward.cu:438-443) — always
-                    const bool app = ok & !stop;                                    // taken by a finished pixel: test_T < 0, and -|T| = T
-                    const float w = app ? alpha * T[q] : 0.0f;
-                    Cr[q] = __builtin_fmaf(colr, w, Cr[q]); Cg[q] = __builtin_fmaf(colg, w, Cg[q]); Cb[q] = __builtin_fmaf(colb, w, Cb[q]);
-                    const float Tdone = stop ? -__builtin_fabsf(T[q]) : T[q];
-                    T[q] = app ? test_T : Tdone;
-                    last[q] = app ? vcontrib : last[q];
-                }
-            }
-        };
-        // two entries per trip: the records alternate between two register sets, each fetched (LDS broadcast) while the other is blended
-        float4 a0 = s_rec[0], a1 = s_rec[1], a2 = s_rec[2], b0, b1, b2;
-        for (int j = 0; j < (((GS_FWD_SKIP & 1) && a.gx > -1) ? 0 : m); j += 2) {
-            if constexpr (STRICT) {
-                if (j == 32) {
-#pragma unroll
-                    for (int q = 0; q < QN; q++) { hfirst[q] = hcur[q]; hcur[q] = 0u; }
-                }
-            }
-            const int jb = (j + 1 < m) ? j + 1 : j;   // (no second entry: a harmless re-read)
-            b0 = s_rec[3 * jb]; b1 = s_rec[3 * jb + 1]; b2 = s_rec[3 * jb + 2];
-            blend_entry(a0, a1, a2, (uint32_t)(base + j + 1));
-            if (j + 1 >= m) break;
-            const int ja = (j + 2 < m) ? j + 2 : j;
-            a0 = s_rec[3 * ja]; a1 = s_rec[3 * ja + 1]; a2 = s_rec[3 * ja + 2];
-            blend_entry(b0, b1, b2, (uint32_t)(base + j + 2));
-        }
-        if constexpr (STRICT) {
-            if (color && fits && !((GS_FWD_SKIP & 4) && a.gx > -1)) {   // pixel-major like the checkpoints: one coalesced 512-byte store per quadrant
-                uint64_t* hp = a.hit + ((size_t)(bbm + (uint32_t)(base / GS_BUCKET)) * GS_TILE_PIX) + lane;
-#pragma unroll
-                for (int q = 0; q < QN; q++)
-                    hp[(q0 + q) * 64] = m > 32 ? (((uint64_t)hcur[q] << 32) | hfirst[q]) : (uint64_t)hcur[q];
-            }
-        }
-    }
-
-    uint32_t mymax = 0;
-    const size_t plane = (size_t)a.H * a.W;
-#pragma unroll
-    for (int q = 0; q < QN; q++) {
-        if (pxi[q] < a.W && pyi[q] < a.H) {
-            const size_t pid = (size_t)pyi[q] * a.W + pxi[q];
-            a.out_final_T[pid] = fabsf(T[q]);
-            if (color) {
-                a.out_color[pid] = Cr[q];
-                a.out_color[plane + pid] = Cg[q];
-                a.out_color[2 * plane + pid] = Cb[q];
-            }
-        }
-        if (color) {
-            a.pix_final[(size_t)tile * GS_TILE_PIX + (q0 + q) * 64 + lane] = make_float4(Cr[q], Cg[q], Cb[q], __uint_as_float(last[q]));
-            mymax = last[q] > mymax ? last[q] : mymax;
-        }
-    }
-    if (color) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const uint32_t o = (uint32_t)__shfl_xor((int)mymax, d, 64);
-            mymax = o > mymax ? o : mymax;
-        }
-        if (lane == 0) {
-            if constexpr (SPLIT == 1) a.max_contrib[tile] = mymax;
-            else atomicMax(a.max_contrib + tile, mymax);  // zeroed by bucket_scan_kernel
-        }
+// TAIL: the tiles in front of a.tail4_from are blended by two waves (two quadrants each), the tiles from tail4_from on by four, one quadrant each.
+// A wave of the two-per-tile launch lives for 0.44 of the kernel's duration (16 320 waves over 7168 slots at 2M / 1080p), so the launch ends in a
+// long drain at falling occupancy — and the kernel loses 18 % from seven waves per SIMD to five (profiles/r06r_blend_occupancy_sensitivity.log);
+// the tiles dispatched last ARE the drain, and with half the work per wave it is half as long.  What a pixel computes does not depend on which
+// wave owns it: the image is unchanged bit for bit.  Both bodies in one kernel behind a wave-uniform branch, so that neither pays for the other's
+// registers.  Workgroups [0, 2 tail4_from): the two-per-tile mapping of render_fwd_kernel; behind them four per tile (tail4_from is a multiple of
+// eight, so a workgroup's XCD — blockIdx % 8 — is its tile's in both parts).  No workgroup of the grid is empty: a first version that launched four
+// per tile everywhere and let two of them leave ran the two-wave tiles on HALF the machine (the dispatcher's workgroup -> CU pattern is periodic:
+// 0.35 -> 0.52 ms).
+template <bool STRICT>
+__global__ __launch_bounds__(64, GS_FWD_WAVES) void render_fwd_tail_kernel(RenderFwdArgs a)
+{
+    __shared__ float4 s_rec[3 * GS_BUCKET];
+    const uint32_t n2 = 2u * (uint32_t)a.tail4_from;
+    if (blockIdx.x < n2) {
+        const uint32_t grp = blockIdx.x / 16u, rem = blockIdx.x % 16u;
+        const int tile = (int)(grp * 8u + (rem & 7u));
+        const int q0 = (int)(rem >> 3) * 2;
+#define GS_BODY_SPLIT 2
+#include "render_fwd_body.inc"
+#undef GS_BODY_SPLIT
+    } else {
+        const uint32_t bb = blockIdx.x - n2, grp = bb / 32u, rem = bb % 32u;
+        const int tile = a.tail4_from + (int)(grp * 8u + (rem & 7u));
+        if (tile >= a.gx * a.gy) return;
+        const int q0 = (int)(rem >> 3);
+#define GS_BODY_SPLIT 4
+#include "render_fwd_body.inc"
+#undef GS_BODY_SPLIT
     }
 }
 
@@ -655,6 +451,21 @@ int launch_render_fwd(const RenderFwdArgs& a, hipStream_t s)
     const unsigned T = (unsigned)(a.gx * a.gy);
     const int split = forced ? forced : 2;
     const unsigned groups = (T + 7u) / 8u;   // groups of 8 tiles x split waves (the kernel's blockIdx -> (tile, quadrants) mapping)
+    // GSLIC_FWD_TAIL4 = the fraction of the tiles (the last ones of the grid) that four waves blend instead of two (0 = none)
+    static const float tail4 = [] { const char* e = getenv("GSLIC_FWD_TAIL4"); const float v = e ? (float)atof(e) : GS_FWD_TAIL4_DEFAULT; return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }();
+    if (split == 2 && tail4 > 0.f) {
+        RenderFwdArgs b = a;
+        // the drain is about half a round of the chip's wave slots (256 CUs x 28) whatever the number of tiles: the default fraction is capped at
+        // 896 tiles = 3584 four-wave workgroups (at 4K, 32 400 tiles, a tenth of the tiles costs 0.9 % instead of gaining: profiles/r06v_*)
+        static const bool tail4_env = getenv("GSLIC_FWD_TAIL4") != nullptr;
+        unsigned tail_tiles = (unsigned)(tail4 * (float)T);
+        if (!tail4_env && tail_tiles > 896u) tail_tiles = 896u;
+        b.tail4_from = (int)(T - tail_tiles) & ~7;   // whole groups of eight tiles
+        const unsigned grid = 2u * (unsigned)b.tail4_from + 32u * ((T - (unsigned)b.tail4_from + 7u) / 8u);
+        if (g_strict_math) GS_LAUNCH(K_RENDER_FWD, (render_fwd_tail_kernel<true>), dim3(grid), dim3(64), 0, s, b);
+        else GS_LAUNCH(K_RENDER_FWD, (render_fwd_tail_kernel<false>), dim3(grid), dim3(64), 0, s, b);
+        return GSLIC_OK;
+    }
     if (g_strict_math && split == 1) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 1>), dim3(groups * 8u), dim3(64), 0, s, a);
     else if (g_strict_math && split == 4) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 4>), dim3(groups * 32u), dim3(64), 0, s, a);
     else if (g_strict_math) GS_LAUNCH(K_RENDER_FWD, (render_fwd_kernel<true, 2>), dim3(groups * 16u), dim3(64), 0, s, a);   // per-pixel arithmetic does not depend on the split
