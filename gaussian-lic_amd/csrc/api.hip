@@ -571,7 +571,7 @@ static int rasterize_forward_impl(const gslic_raster_params* prm, gslic_alloc_fn
     ra.W = prm->width; ra.H = prm->height; ra.gx = gx; ra.gy = gy; ra.no_color = prm->no_color;
     ra.ranges = img.ranges; ra.point_list = bin.point_list(); ra.rec = geom.rec; ra.bucket_offsets = img.bucket_offsets;
     ra.bucket_to_tile = smp.bucket_to_tile; ra.ckpt = smp.ckpt; ra.hit = smp.hit; ra.pix_final = img.pix_final; ra.max_contrib = img.max_contrib;
-    ra.out_color = out_color; ra.out_final_T = out_final_T; ra.capB = B; ra.status = geom.flags;
+    ra.out_color = out_color; ra.out_final_T = out_final_T; ra.capB = B; ra.status = geom.flags; ra.tail4_from = T;   // (launch_render_fwd decides)
     GS_TRY(launch_render_fwd(ra, s));
     DEBUG_SYNC(prm, s);
     if (cap) {
