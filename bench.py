@@ -498,7 +498,7 @@ def main():
         scan_on = strict_mode and os.environ.get("GSLIC_BWD_SCAN", "1") != "0"
         if pmc is not None and pmc_units_ok:
             pu = pmc.get("units") or {}
-            for key in (f"{kname}_scan_kernel" if scan_on else None, f"{kname}_kernel", kname):
+            for key in (f"{kname}_scan_kernel" if scan_on else None, f"{kname}_tail_kernel", f"{kname}_kernel", kname):
                 hit = [v for n, v in pmc.get("kernels", {}).items() if key and n.split("<")[0].strip() == key]
                 if hit and traffic is None:
                     traffic = hit[0]["hbm_bytes_per_launch"]
@@ -521,7 +521,7 @@ def main():
                 sq_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.txt")))   # the newest tag sorts last
                 for line in (open(sq_files[-1]) if sq_files else []):
                     name, _, rest = line.partition(" {")
-                    if name.split("<")[0].strip() in (f"{kname}_kernel", f"{kname}_scan_kernel" if scan_on else "-") and pmc_units_ok:
+                    if name.split("<")[0].strip() in (f"{kname}_kernel", f"{kname}_tail_kernel", f"{kname}_scan_kernel" if scan_on else "-") and pmc_units_ok:
                         c = ast.literal_eval("{" + rest.strip())
                         insts = c["SQ_INSTS_VALU"] * 32.0   # the extract averages per shader engine; 32 engines
                         cycles = 1024.0 * avg_ms * 1e-3 * SHADER_CLOCK_GHZ * 1e9
