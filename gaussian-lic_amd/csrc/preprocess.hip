@@ -67,6 +67,9 @@ __device__ __forceinline__ void sh_to_rgb(const PreprocessArgs& a, const int idx
 // 97 VGPRs kept it at four waves per SIMD; capped at 96 it ran five (0.1330 -> 0.1304 ms); with the SH staging's float4 columns fetched three at a time
 // instead of six (GS_PRE_NTB: 24 registers held across the staging -> 12) it fits 80 with two spilled and runs SIX: 0.1344 -> 0.1274 ms, same box
 // (profiles/r06s_preprocess_staging_batches_ab.log; seven waves / 72 VGPRs / two columns at a time: 0.136).  -DGS_PRE_WPE=n -DGS_PRE_NTB=n for A/B runs.
+#ifndef GS_PRE_EARLY_REC
+#define GS_PRE_EARLY_REC 1   // 78 VGPRs, no spills, no scratch at six waves: 0.1249 -> 0.1227 ms (seven waves with it: 0.126; profiles/r06ad_preprocess_early_record_ab.log)
+#endif
 #ifndef GS_PRE_NTB
 #define GS_PRE_NTB 3
 #endif
@@ -222,6 +225,16 @@ __global__ __launch_bounds__(BS) GS_PRE_WPE_ATTR void preprocess_kernel(Preproce
     // ---- SH -> RGB (forward.cu:29-77) ----
     float rgb[3] = {0.f, 0.f, 0.f};
     uint32_t clamp_bits = 0;
+#if GS_PRE_EARLY_REC
+    // the geometry half of the record leaves before the SH phase instead of living in eight registers across it (the colour half follows)
+    if (visible) {
+        float4* rec_e = a.rec + GS_REC_F4 * (size_t)idx;
+        rec_e[0] = make_float4(mx, my, cA, cB);
+        *reinterpret_cast<float2*>(rec_e + 1) = make_float2(cC, op);
+        *reinterpret_cast<float2*>(reinterpret_cast<float*>(rec_e + 2) + 1) = make_float2(depth, 0.f);   // (.z rewritten below with the clamp bits)
+        reinterpret_cast<float*>(rec_e + 2)[3] = __int_as_float(radius);
+    }
+#endif
     if constexpr (LDS_SH) {
         // The block's 64 x 45 SH floats are contiguous in memory: they pass through LDS in TWO rounds of 32 rows (5.6 KB instead of 11.3:
         // the kernel is latency-bound and loses 18 % when LDS padding takes it from 13 to 10 waves per CU, profiles/r03t_occupancy_sweep.log),
@@ -275,9 +288,15 @@ __global__ __launch_bounds__(BS) GS_PRE_WPE_ATTR void preprocess_kernel(Preproce
         if (!a.no_color) sh_to_rgb(a, idx, px, py, pz, a.shs ? a.shs + (size_t)3 * a.M * idx : nullptr, rgb, clamp_bits);
     }
     float4* rec = a.rec + GS_REC_F4 * (size_t)idx;
+#if GS_PRE_EARLY_REC
+    *reinterpret_cast<float2*>(reinterpret_cast<float*>(rec + 1) + 2) = make_float2(rgb[0], rgb[1]);
+    reinterpret_cast<float*>(rec + 2)[0] = rgb[2];
+    reinterpret_cast<float*>(rec + 2)[2] = __uint_as_float(clamp_bits | (seqmask << 16));
+#else
     rec[0] = make_float4(mx, my, cA, cB);
     rec[1] = make_float4(cC, op, rgb[0], rgb[1]);
     rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits | (seqmask << 16)), __int_as_float(radius));   // (.z: clamp bits 0-2, tile mask 16-31)
+#endif
 }
 
 // Thread i emits the instances of Gaussian g = i (index order, as duplicateWithKeys does: rasterizer_impl.cu:59-193) into the emission
