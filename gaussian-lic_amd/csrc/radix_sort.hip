@@ -480,7 +480,7 @@ __device__ __forceinline__ void tile_depth_sort_body(const TileDepthSortArgs& a,
 }
 
 // ONE WAVE per tile for segments of up to LW_CAP instances (the common case): no workgroup barrier anywhere, and no match-any either.
-// The pairs ping-pong between two LDS buffers in a BLOCKED layout: lane l owns the E = ceil(n / 64) consecutive elements [l E, (l + 1) E) —
+// The pairs live in ONE LDS buffer (two, ping-pong, until round 6: GS_LSORT_SINGLE below) in a BLOCKED layout: lane l owns the E = ceil(n / 64) consecutive elements [l E, (l + 1) E) —
 // order = (lane, position in the lane's run).  A pass takes FOUR bits: every lane counts the sixteen digits of its run into its own column of a
 // 16 x 64 counter matrix (no conflicts, no atomics between lanes), the matrix is scanned in (digit, lane) order — which IS the stable order —
 // and every lane walks its run once more, taking each element's position from its column's counter.  Eight passes of ~25 instructions per
