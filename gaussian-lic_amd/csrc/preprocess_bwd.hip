@@ -232,6 +232,15 @@ __device__ __forceinline__ void sh_columns_pass(const PreprocessBwdArgs& a, cons
 // groups) run one after the other inside a wave: the waves in flight ARE its memory-level parallelism.  At 131 VGPRs it ran three waves per
 // SIMD; capped at 128 (two spilled outside the column pass) it runs four — 0.50 -> 0.444 ms at 2M / 1080p, same box
 // (profiles/r06n_pbwd_occupancy_ab.log); five (96 VGPRs, 44 spilled) gives the gain back.  -DGS_PBWD_WPE=n for A/B runs.
+// GS_PBWD_STRICT_CHAIN=1: the per-Gaussian chain (cov2D / cov3D / projection backward, bwd_rest) without contraction, as the reference's kernels are
+// built.  Left to the compiler, its contraction choices moved with the occupancy attribute below (round 6: dL_dcov3D / dL_dmean3D / dL_dscale /
+// dL_drot changed in their last bits, profiles/r06ag_case20_digests.log).  Pinned, the four gradients are on average 10-30 % closer to the
+// reference's kernels (profiles/r06ai_chain_contract_off_errors.log), the kernel needs 124 VGPRs without a spill and is as fast — but the raw-parameter
+// path's activation derivatives then differ a little more from LibTorch's autograd of the same activations, and after three Adam steps (sign-like
+// first steps) tests/test_shim_gpu.py::test_dropin_renderer_cpp's image is 5.2e-4 from the reference renderer's instead of < 2e-4.  Off by default.
+#ifndef GS_PBWD_STRICT_CHAIN
+#define GS_PBWD_STRICT_CHAIN 0
+#endif
 #ifndef GS_PBWD_WPE
 #define GS_PBWD_WPE 4
 #endif
@@ -433,6 +442,9 @@ template <bool CAM>
 __device__ __forceinline__ void bwd_rest(const PreprocessBwdArgs& a, const int idx, const PartialSums& ps, const float* sh_row, const float* sk_row,
                                          ShOut& so, float* sg, float* cg)
 {
+#if GS_PBWD_STRICT_CHAIN
+#pragma clang fp contract(off)   // the per-Gaussian chain rounds every product and sum on its own, as the reference's kernels are built (oracle/ref_build: -ffp-contract=off)
+#endif
     const float s_mx = ps.mx, s_my = ps.my, s_cx = ps.cx, s_cy = ps.cy, s_cw = ps.cw, s_op = ps.op, s_r = ps.r, s_g = ps.g, s_b = ps.b;
     const float* __restrict__ V = a.view;
     const float* __restrict__ Pm = a.proj;
