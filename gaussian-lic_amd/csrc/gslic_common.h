@@ -384,8 +384,11 @@ __device__ __forceinline__ void get_rect(float px, float py, int radius, int gx,
     const float r = (float)radius;
     x0 = trunc_clamped((px - r) / (float)GS_TILE, gx);
     y0 = trunc_clamped((py - r) / (float)GS_TILE, gy);
-    x1 = trunc_clamped((px + r + (float)(GS_TILE - 1)) / (float)GS_TILE, gx);
-    y1 = trunc_clamped((py + r + (float)(GS_TILE - 1)) / (float)GS_TILE, gy);
+    // the reference's LITERAL order, ((p + radius) + BLOCK) - 1 (auxiliary.h:52-53: `p.x + max_radius + BLOCK_X - 1`), not p + radius + 15: the two
+    // round differently when (p + radius) + 16 is a tie of the next binade — 215.99998 + 25 + 16 = 257.0 exactly, so the rectangle reaches tile column
+    // 15; + 15 gives 255.99998 and stops at 14 (found by fuzz scene 845806 at the end of round 6: one Gaussian in about 3e7 lost a tile it blends into)
+    x1 = trunc_clamped((((px + r) + (float)GS_TILE) - 1.0f) / (float)GS_TILE, gx);
+    y1 = trunc_clamped((((py + r) + (float)GS_TILE) - 1.0f) / (float)GS_TILE, gy);
 }
 
 __device__ __forceinline__ float saturate_f(float v) { return (v > 0.0f) ? ((v < 1.0f) ? v : 1.0f) : 0.0f; }

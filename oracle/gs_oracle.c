@@ -204,8 +204,19 @@ static inline void get_rect(real px, real py, int radius, int gx, int gy, int* r
     real r = (real)radius;
     rmin[0] = trunc_clamped((px - r) / (real)TILE, gx);
     rmin[1] = trunc_clamped((py - r) / (real)TILE, gy);
-    rmax[0] = trunc_clamped((px + r + (real)(TILE - 1)) / (real)TILE, gx);
-    rmax[1] = trunc_clamped((py + r + (real)(TILE - 1)) / (real)TILE, gy);
+    /* auxiliary.h:52-53 literally: ((p + radius) + BLOCK) - 1.  (Until round 6 this read p + radius + 15, which rounds differently when (p + radius) + 16
+     * is a tie of the next binade: 215.99998 + 25 + 16 = 257.0, the reference's rectangle reaches one tile column further.  Found by the reference's own
+     * kernels on fuzz scene 845806; tests/test_oracle_cpu.py::test_get_rect_follows_the_reference_order pins it.) */
+    rmax[0] = trunc_clamped((((px + r) + (real)TILE) - RC(1.0)) / (real)TILE, gx);
+    rmax[1] = trunc_clamped((((py + r) + (real)TILE) - RC(1.0)) / (real)TILE, gy);
+}
+
+/* test hook: the rectangle of one mean / radius (out = x0, y0, x1, y1) */
+void orc_get_rect(real px, real py, int radius, int gx, int gy, int* out)
+{
+    int rmin[2], rmax[2];
+    get_rect(px, py, radius, gx, gy, rmin, rmax);
+    out[0] = rmin[0]; out[1] = rmin[1]; out[2] = rmax[0]; out[3] = rmax[1];
 }
 
 /* forward.h:39-78: minimum of 1/2 d^T Q d over the rectangle of pixel centres [tx*16, tx*16+15]x[ty*16, ..]. */

@@ -62,6 +62,15 @@ class Oracle:
     def logf(self, x):
         return float(self.lib.orc_logf(ctypes.c_float(x)))
 
+    def get_rect(self, px, py, radius, gx, gy):
+        """getRect of auxiliary.h:46-56 for one mean (pixels) and radius: (x0, y0, x1, y1) in tiles."""
+        out = (ctypes.c_int * 4)()
+        real = self.real
+        self.lib.orc_get_rect.argtypes = [real, real, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        self.lib.orc_get_rect.restype = None
+        self.lib.orc_get_rect(real(px), real(py), int(radius), int(gx), int(gy), out)
+        return tuple(out)
+
     # ------------------------------------------------------------------ stages
     def preprocess(self, sc, cam, no_color=False):
         """sc: dict(means,scales,rots,opac,dc,shs,D) activated parameters; cam: dict(W,H,view,proj,campos,tanfovx,...)"""

@@ -77,3 +77,26 @@ def test_fuzz_scene_is_bit_identical_to_the_reference_kernels(case):
     st = res["fast"]   # opt-in arithmetic: threshold flips only — a handful of elements (printed above), the image never off by more than a contribution
     assert st["color"]["over"] <= max(8, 1e-4 * st["color"]["n"]) and st["color"]["max_rel"] < 5e-2, st["color"]
     assert st["n_contrib_mismatch"] <= max(8, 1e-4 * st["pixels"])
+
+
+def test_rectangle_tie_scene_matches_the_reference_kernels():
+    """Fuzz scene 845806 (case 385 of `tests/fuzz_vs_reference.py 600 8001`, round 6): one Gaussian whose mean, 215.99998474, plus radius 25 plus BLOCK_X
+    16 is a rounding tie — the reference's getRect (`p.x + max_radius + BLOCK_X - 1`, auxiliary.h:52-53) reaches tile column 15, a restatement that adds
+    15 at once does not, and the Gaussian lost a tile it blends into (tiles_touched 9 against the reference kernels' 10).  The whole scene, both forced
+    paths, against the reference's own kernels."""
+    from oracle.ref_build import refkernels
+    if not refkernels.available():
+        pytest.skip("oracle/_ref/libref_hip.so not built")
+    from refcompare import GRADS, assert_path, compare, summarize
+    for binning, morton in (("radix", False), ("atomic", True)):
+        res = compare("random", 25600, 320, 180, 3, 845806, binning=binning, morton=morton)
+        print("\n" + summarize(res))
+        assert_path(res)
+        for mode in ("strict", "fast"):
+            st = res[mode]
+            assert st["radii_mismatch"] == 0 and st["tiles_touched_mismatch"] == 0, (mode, st["radii_mismatch"], st["tiles_touched_mismatch"])
+            assert st["R"] == res["ref"]["R"] and st["point_list_equal"] and st["ranges_equal"], mode
+        st = res["strict"]
+        assert st["color"]["bit_equal"] and st["final_T"]["bit_equal"] and st["n_contrib_mismatch"] == 0
+        for k in GRADS:
+            assert st[k]["over"] == st[k].get("over_excused", 0), (k, st[k])

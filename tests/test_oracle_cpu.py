@@ -237,3 +237,21 @@ def test_rigid_motion_of_scene_and_camera_leaves_the_render_unchanged(oracle64, 
     # ... and the identity-pose render is NOT reproduced when the camera alone moves (the test has teeth)
     f2 = oracle64.forward(sc0, camd1)
     assert rel_err(f2["color"], f0["color"]) > 1e-2
+
+
+def test_get_rect_follows_the_reference_order(oracle32, oracle64):
+    """getRect (auxiliary.h:46-56) adds the radius, then BLOCK_X, then subtracts 1 — `p.x + max_radius + BLOCK_X - 1` evaluated left to right in
+    fp32.  p + radius + 15 is NOT the same function: for p.x = 216 - 2^-16 (= 215.99998474, a mean the reference's ndc2Pix produces) and radius 25,
+    (p + 25) + 16 = 256.99998474 is a tie of the binade [256, 512) and rounds to 257.0 (even), so the rectangle ends at tile column 16 (exclusive);
+    with + 15 the sum is 255.99998474 exactly and it ends at 15.  The reference's own kernels list the Gaussian in tile column 15 (fuzz scene 845806,
+    tools/experiments/tile_count_mismatch_probe.py); round 1-6's restatement dropped it.  One Gaussian in about 3e7."""
+    px = float(np.float32(216.0) - np.float32(2.0 ** -16))
+    assert np.float32(px) == np.float32(215.99998474)
+    assert oracle32.get_rect(px, 151.11269, 25, 20, 12) == (11, 7, 16, 11)
+    # a neighbouring mean (one ulp further left: no tie) and the double-precision twin (no tie either) stop one column earlier
+    assert oracle32.get_rect(float(np.float32(216.0) - np.float32(2.0 ** -15)), 151.11269, 25, 20, 12)[2] == 15
+    assert oracle64.get_rect(px, 151.11269, 25, 20, 12)[2] == 15
+    # the literal fp32 sequence in numpy
+    s = ((np.float32(px) + np.float32(25.0)) + np.float32(16.0)) - np.float32(1.0)
+    assert s == np.float32(256.0) and int(s / np.float32(16.0)) == 16
+    assert int(((np.float32(px) + np.float32(25.0)) + np.float32(15.0)) / np.float32(16.0)) == 15
