@@ -62,7 +62,29 @@ def main():
             print(f"knn P={P}: {type(e).__name__}: {str(e)[:200]}")
         print(f"knn {i:3d} P={P}: {'OK' if ok else ('MISMATCH' if ok is False else 'SKIPPED')}", flush=True)
         bad += 1 if ok is False else 0
-    print(f"{n_ssim} SSIM shapes, {max(n_ssim // 10, 1)} fused-loss shapes, {n_knn} kNN sizes: {bad} mismatches")
+    # Adam (adam.cu:9-38 through the checker's ref_adam) on random row counts / widths / visibility patterns, values with zeros, tiny and huge
+    # magnitudes: parameters and both moments BIT FOR BIT, for the one-group entry and the grouped one (all rows of a group in one launch)
+    import torch
+    from gaussian_lic_amd import optim
+    rk = T._ref()
+    n_adam = max(n_ssim // 3, 1)
+    for i in range(n_adam):
+        N = int(rng.choice([1, 2, 3, 63, 64, 65, 255, 256, 1000, int(rng.integers(1, 200000))]))
+        M = int(rng.choice([1, 3, 4, 45, int(rng.integers(1, 60))]))
+        scale = float(rng.choice([1e-12, 1e-4, 1.0, 1e4]))
+        p_ = (scale * rng.standard_normal((N, M))).astype(np.float32); g_ = (scale * rng.standard_normal((N, M))).astype(np.float32)
+        g_[rng.random((N, M)) < 0.1] = 0.0
+        m_ = (0.1 * scale * rng.standard_normal((N, M))).astype(np.float32); v_ = (0.01 * scale * scale * rng.random((N, M))).astype(np.float32)
+        vis = rng.random(N) < float(rng.choice([0.0, 0.3, 0.7, 1.0]))
+        lr = float(rng.choice([1.6e-4, 5e-2, 1e-3]))
+        rp, rm, rv = p_.copy(), m_.copy(), v_.copy()
+        rk.adam(rp, g_, rm, rv, vis, lr)
+        tp, tg, tm, tv = (torch.from_numpy(x.copy()).to("cuda:0") for x in (p_, g_, m_, v_))
+        optim.adam_update(tp, tg, tm, tv, torch.from_numpy(vis).to("cuda:0"), lr, 0.9, 0.999, 1e-15, N, M)
+        ok = all(np.array_equal(a.cpu().numpy().view(np.uint32), b.view(np.uint32)) for a, b in ((tp, rp), (tm, rm), (tv, rv)))
+        print(f"adam {i:3d} N={N} M={M} scale={scale:g} visible={int(vis.sum())}: {'OK' if ok else 'MISMATCH'}", flush=True)
+        bad += 0 if ok else 1
+    print(f"{n_ssim} SSIM shapes, {max(n_ssim // 10, 1)} fused-loss shapes, {n_knn} kNN sizes, {n_adam} Adam shapes: {bad} mismatches")
     sys.exit(1 if bad else 0)
 
 
