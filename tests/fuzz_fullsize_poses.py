@@ -2,7 +2,8 @@
 """Integer stages and image of the HIP forward against the reference's OWN kernels at FULL size on random SE(3) poses and scene seeds — tile
 assignment is a 1e-8-per-Gaussian business (the getRect tie of round 6 affects one Gaussian in about 3e7): every view here is 0.35-1.4 million visible
 Gaussians.  Forward only, strict arithmetic, the timed configuration's grouping (atomic, Morton rows) and the radix path alternating.
-    python tests/fuzz_fullsize_poses.py [n = 24] [seed = 1] [P = 2000128]"""
+    python tests/fuzz_fullsize_poses.py [n = 24] [seed = 1] [P = 2000128] [backward = 0]
+backward = 1: the nine gradients too (zero elements beyond 1e-4 of a tensor's max-abs counted per view; no conditioning probe at this size)."""
 import os
 import sys
 
@@ -16,7 +17,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     P = int(sys.argv[3]) if len(sys.argv) > 3 else 2000128
-    from refcompare import assert_path, compare
+    bwd = len(sys.argv) > 4 and int(sys.argv[4]) != 0
+    from refcompare import GRADS, assert_path, compare
     rng = np.random.default_rng(seed0)
     bad, views = 0, 0
     for i in range(n):
@@ -27,15 +29,20 @@ def main():
         view = dict(ypr=ypr, t=t, place=bool(rng.random() < 0.5))
         seed = int(rng.integers(0, 10 ** 6))
         binning, morton = (("atomic", True), ("radix", False))[i % 2]
-        res = compare(kind, Pi, 1920, 1080, 3, seed, modes=("strict",), backward=False, view=view, binning=binning, morton=morton)
+        res = compare(kind, Pi, 1920, 1080, 3, seed, modes=("strict",), backward=bwd, view=view, binning=binning, morton=morton)
         assert_path(res)
         st = res["strict"]
         ok = (st["radii_mismatch"] == 0 and st["tiles_touched_mismatch"] == 0 and st["R"] == res["ref"]["R"] and st["point_list_equal"] and st["ranges_equal"]
               and all(st[k + "_bit_equal"] for k in ("means2D", "depths", "conic_opacity", "rgb")) and st["color"]["bit_equal"] and st["final_T"]["bit_equal"]
               and st["n_contrib_mismatch"] == 0)
+        gtxt = ""
+        if bwd:
+            over = sum(st[k]["over"] for k in GRADS)
+            gtxt = f" gradients: {over} elements over 1e-4, largest {max(st[k]['max_rel'] for k in GRADS):.1e}"
+            ok = ok and over == 0
         views += res["ref"]["visible"]
         print(f"{i:3d} {kind:6s} P={Pi} seed={seed} ypr={ypr} t={t} place={view['place']} [{binning}, {'Morton' if morton else 'insertion'} rows -> ran {st['binning_path']}]: "
-              f"visible={res['ref']['visible']} R={res['ref']['R']} {'OK' if ok else 'MISMATCH ' + str({k: st[k] for k in ('radii_mismatch', 'tiles_touched_mismatch', 'point_list_equal', 'n_contrib_mismatch')})}", flush=True)
+              f"visible={res['ref']['visible']} R={res['ref']['R']} {'OK' if ok else 'MISMATCH ' + str({k: st[k] for k in ('radii_mismatch', 'tiles_touched_mismatch', 'point_list_equal', 'n_contrib_mismatch')})}{gtxt}", flush=True)
         bad += 0 if ok else 1
     print(f"{n} full-size views, {views} visible Gaussian-views in total, {bad} mismatches")
     sys.exit(1 if bad else 0)
