@@ -2,7 +2,7 @@
 """Integer stages and image of the HIP forward against the reference's OWN kernels at FULL size on random SE(3) poses and scene seeds — tile
 assignment is a 1e-8-per-Gaussian business (the getRect tie of round 6 affects one Gaussian in about 3e7): every view here is 0.35-1.4 million visible
 Gaussians.  Forward only, strict arithmetic, the timed configuration's grouping (atomic, Morton rows) and the radix path alternating.
-    python tests/fuzz_fullsize_poses.py [n = 24] [seed = 1] [P = 2000128] [backward = 0]
+    python tests/fuzz_fullsize_poses.py [n = 24] [seed = 1] [P = 2000128] [backward = 0] [W = 1920] [H = 1080]
 backward = 1: the nine gradients too (zero elements beyond 1e-4 of a tensor's max-abs counted per view; no conditioning probe at this size)."""
 import os
 import sys
@@ -18,18 +18,20 @@ def main():
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     P = int(sys.argv[3]) if len(sys.argv) > 3 else 2000128
     bwd = len(sys.argv) > 4 and int(sys.argv[4]) != 0
+    W = int(sys.argv[5]) if len(sys.argv) > 5 else 1920
+    H = int(sys.argv[6]) if len(sys.argv) > 6 else 1080
     from refcompare import GRADS, assert_path, compare
     rng = np.random.default_rng(seed0)
     bad, views = 0, 0
     for i in range(n):
         kind = "random" if rng.random() < 0.7 else "lidar"
-        Pi = P if kind == "random" else 500224
+        Pi = P if kind == "random" else min(P, 500224)
         ypr = tuple(float(round(v, 2)) for v in rng.uniform(-35.0, 35.0, 3))
         t = tuple(float(round(v, 3)) for v in rng.uniform(-1.0, 1.0, 3))
         view = dict(ypr=ypr, t=t, place=bool(rng.random() < 0.5))
         seed = int(rng.integers(0, 10 ** 6))
         binning, morton = (("atomic", True), ("radix", False))[i % 2]
-        res = compare(kind, Pi, 1920, 1080, 3, seed, modes=("strict",), backward=bwd, view=view, binning=binning, morton=morton)
+        res = compare(kind, Pi, W, H, 3, seed, modes=("strict",), backward=bwd, view=view, binning=binning, morton=morton)
         assert_path(res)
         st = res["strict"]
         ok = (st["radii_mismatch"] == 0 and st["tiles_touched_mismatch"] == 0 and st["R"] == res["ref"]["R"] and st["point_list_equal"] and st["ranges_equal"]
